@@ -1,0 +1,24 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+sys.dont_write_bytecode = True
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """Vectors produced by the unmodified reference (oracle/gen_golden.py)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+
+
+GOLDEN_SIZES = (3, 4, 5, 8, 16)
