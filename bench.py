@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- JacobiGNN sweeps/s on the 2-D Laplacian (BASELINE.json metric), 1..8 MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 4096] [--sweeps 20] [--no-cpu-baseline]
+
+A "step" is one `JacobiGNN.forward(n_iters=20, ...)` call (BASELINE config 2: 20 sweeps, 4096 x 4096
+Laplacian, fp64) through the drop-in nn.Module surface with all inputs resident in HBM: the per-call AoS
+column split, the cached-plan lookup and the 20 fused CSR sweeps are inside the timed region; building the
+graph / CSR plan (once per graph) is not.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): WEAK scaling.  Every rank owns a row block
+of `n` grid lines x `n` vertices of the (n*N_gpus) x n grid Laplacian (at N=1 exactly config 2); after each
+sweep the ranks exchange their boundary grid lines with one all-gather (gnn_applied_linear_algebra_amd/dist.py).
+`value` = (rank-block sweeps done by all ranks) / wall time = N_gpus * sweeps/s of the coupled system.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def algorithmic_bytes_jacobi(n, nnz):
+    """12*nnz (val f64 + col i32) + 4*(n+1) (rowptr) + 32*n (read x, b, A_ii; write x)."""
+    return 12 * nnz + 4 * (n + 1) + 32 * n
+
+
+def cpu_baseline(n_grid, sweeps):
+    """Reference formulation (oracle/reference_port.py: gather -> mul -> cat -> scatter_add, torch CPU) timed on
+    the host cores: a bounded sample (`sweeps` sweeps) of the same 4096^2 workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import reference_port as rp
+    ei, ev = rp.laplacianfun_torch(n_grid)
+    n = n_grid * n_grid
+    gen = torch.Generator().manual_seed(24601)
+    b = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    x = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    va = torch.cat([-4 * torch.ones(n, 1, dtype=torch.float64), b, x], 1)
+    ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+    g = torch.tensor([0.7], dtype=torch.float64)
+    rp.jacobi_forward(1, va, ei, ea, g)                        # warm-up
+    t0 = time.perf_counter()
+    rp.jacobi_forward(sweeps, va, ei, ea, g)
+    dt = time.perf_counter() - t0
+    return {"value": sweeps / dt, "unit": "sweeps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sweeps} sweeps of the {n_grid}x{n_grid} fp64 JacobiGNN in the reference's COO "
+                      f"gather/cat/scatter_add formulation (oracle/reference_port.py), torch CPU, "
+                      f"{torch.get_num_threads()} threads of {os.cpu_count()} logical cores",
+            "ms_per_sweep": 1e3 * dt / sweeps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=4096, help="grid lines per rank and vertices per line")
+    ap.add_argument("--sweeps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sweeps", type=int, default=4)
+    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: exchange, then compute (no overlap)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import gnn_applied_linear_algebra_amd as gla
+    from gnn_applied_linear_algebra_amd import UtilsGNN
+
+    Nx, lines = args.n, args.n
+    Ny = lines * world
+    n_local = Nx * lines
+    lo, hi = rank * n_local, (rank + 1) * n_local
+    ei, ev = UtilsGNN.laplacianfun_torch(Nx, Ny=Ny, row_range=(lo, hi), device=dev)
+    nnz_local = ei.shape[1]
+    gen = torch.Generator().manual_seed(24601 + rank)
+    b = torch.rand(n_local, 1, generator=gen, dtype=torch.float64).to(dev)
+    x0 = torch.rand(n_local, 1, generator=gen, dtype=torch.float64).to(dev)
+    diag = torch.full((n_local, 1), -4.0, dtype=torch.float64, device=dev)
+    vertex_attr = torch.cat([diag, b, x0], 1)
+    edge_attr = torch.cat([ev, torch.zeros_like(ev)], 1)
+    g = torch.tensor([0.7], dtype=torch.float64, device=dev)
+
+    if world == 1:
+        jac = gla.JacobiGNN.JacobiGNN()
+
+        def step():
+            return jac(args.sweeps, vertex_attr, ei, edge_attr, g)
+
+        plan = gla.plan_for(ei, n_local, edge_attr=edge_attr)
+
+        def kernel_only():
+            return plan.jacobi_sweeps(diag.reshape(-1), b, x0, 0.7, args.sweeps)
+    else:
+        from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi
+        drv = RowBlockJacobi(ei, edge_attr, n_global=Nx * Ny, row_lo=lo, row_hi=hi, overlap=not args.no_overlap)
+
+        def step():
+            return drv.forward(args.sweeps, vertex_attr, g)
+
+        kernel_only = None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_sweeps = args.steps * args.sweeps
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * total_sweeps / elapsed
+    B = algorithmic_bytes_jacobi(n_local, nnz_local)
+
+    # roofline of the dominant kernel (spmv_stream_kernel<double, EpiJacobi>): HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        if kernel_only is not None:
+            kernel_only()
+            torch.cuda.synchronize()
+            reps = 5
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                kernel_only()
+            e1.record()
+            torch.cuda.synchronize()
+            t_launch = e0.elapsed_time(e1) * 1e-3 / (reps * args.sweeps)
+        else:
+            t_launch = elapsed / total_sweeps                # per-rank sweep incl. halo exchange
+        achieved = B / t_launch / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_jacobi.json")
+        if world == 1 and os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("n") == args.n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "kernel": "spmv_stream_kernel<double,EpiJacobi>", "algorithmic_bytes_per_launch": B,
+                "avg_launch_us": round(t_launch * 1e6, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.n, args.cpu_sweeps)
+        cpu["value"] = round(cpu["value"], 4)
+        cpu["ms_per_sweep"] = round(cpu["ms_per_sweep"], 1)
+
+    if rank == 0:
+        out = {
+            "metric": "Jacobi-GNN sweeps/sec (2D Laplacian, fp64)", "value": round(value, 2), "unit": "sweeps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"JacobiGNN.forward, {args.sweeps} sweeps/step, 5-pt Laplacian, "
+                                   f"{lines}x{Nx} vertices per GPU (global grid {Ny}x{Nx}), fp64, w=0.7"
+                                   + ("" if world == 1 else ", row-block partition + RCCL halo all-gather"),
+                       "N": Nx, "rows_per_gpu": n_local, "nnz_per_gpu": nnz_local, "sweeps_per_step": args.sweeps,
+                       "achieved_GBps_per_gpu_whole_step": round(B * total_sweeps / elapsed / 1e9, 1)},
+            "roofline": roof,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

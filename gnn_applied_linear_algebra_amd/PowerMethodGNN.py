@@ -1,0 +1,45 @@
+"""Power iteration + Rayleigh quotient -- mirror of /root/reference/pytorch/PowerMethodGNN.py (:296-334).
+
+Per iteration the reference runs three MetaLayers (b <- A b; n = sqrt(sum b^2); b <- b / n); here that is one
+fused SpMV (gla_spmm), one deterministic column reduction (gla_col_dot) and one scale pass
+(gla_col_scale_rsqrt).  The Rayleigh block is an SpMV plus two reductions.
+"""
+import torch
+
+from ._common import back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
+from .plan import col_dot, col_scale_rsqrt
+
+
+class PowerMethodGNN(torch.nn.Module):
+    def __init__(self, num_iter, return_edge_attr=True):
+        super().__init__()
+        self.num_iter = int(num_iter)
+        self.return_edge_attr = return_edge_attr
+
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch=None):
+        """vertex_attr [n,2] = [b, y]; edge_attr [nnz,2] = [A_ij, c_ij]; g [3] = [n, n_A, lambda]
+        -> (vertex_attr [n,2] = [b, b^2], edge_attr [nnz,2] = [A_ij, A_ij*b_j], g [3]); lambda_max = g[2].
+        Multi-RHS extension: vertex_attr [n,2,K], g [3,K] runs K independent power iterations."""
+        dev = compute_device(vertex_attr, edgeij_pair, edge_attr)
+        va, ei, ea = to_dev(vertex_attr, dev), to_dev(edgeij_pair, dev), to_dev(edge_attr, dev)
+        float_dtype(va)
+        if va.shape[1] != 2:
+            raise ValueError("vertex_attr must be [n, 2] = [b, y]")
+        plan = plan_for(ei, va.shape[0], edge_attr=ea)
+        b = cols(va, 0)
+        K = b.shape[1]
+        out_dtype = torch.result_type(va, g)
+        gd = to_dev(g, dev).to(out_dtype).reshape(3, -1)
+        nrm, n_A = gd[0].expand(K).clone(), gd[1].expand(K).clone()
+        for _ in range(self.num_iter):
+            y = plan.spmm(b)                          # Layer 1: b_i <- sum_j A_ij b_j        (:86-158)
+            ss = col_dot(y, y)                        # Layer 2: y = b*b ; n = sqrt(sum y)    (:109-185)
+            b = col_scale_rsqrt(y, ss)                # Layer 3: b <- b / n                   (:187-207)
+            nrm = torch.sqrt(ss).to(out_dtype)
+        Ab = plan.spmm(b)                             # Rayleigh layer 1: y = b * (A b); n_A = sum y  (:209-266)
+        n_A = col_dot(b, Ab).to(out_dtype)
+        lam = n_A / col_dot(b, b).to(out_dtype)       # Rayleigh layer 2: lambda = n_A / sum b^2      (:268-294)
+        g_out = torch.stack([nrm, n_A, lam], 0)
+        g_out = g_out.reshape(3) if g.dim() == 1 else g_out
+        ea_out = edge_cols(ea, plan.edge_products(b)) if self.return_edge_attr else None
+        return (back(stack_cols([b, b * b], va), vertex_attr), back(ea_out, edge_attr), back(g_out, g))

@@ -1,0 +1,15 @@
+"""gnn_applied_linear_algebra_amd -- MI355X-native kernels behind the operator surface of
+sandialabs/gnn-applied-linear-algebra's sparse message-passing hot path.
+
+Module names mirror the reference's flat `pytorch/` directory (UtilsGNN, MatVecGNN, GNNResidual, JacobiGNN,
+ChebyGNN, PowerMethodGNN, SOCClassicGNN, DirectInterpGNN, VCycle, SOCSAGNN, MatrixWeightedNorm).  All arithmetic
+runs in libgla_hip.so (csrc/, C ABI in include/gla.h); there is no CPU fallback.
+"""
+from . import _lib  # noqa: F401
+from .meta import MetaLayer  # noqa: F401
+from .plan import CsrPlan, plan_for, col_dot, col_scale_rsqrt  # noqa: F401
+from . import (UtilsGNN, MatVecGNN, GNNResidual, JacobiGNN, ChebyGNN, PowerMethodGNN, SOCClassicGNN,  # noqa: F401
+               DirectInterpGNN, SOCSAGNN, MatrixWeightedNorm)
+
+__all__ = ["MetaLayer", "CsrPlan", "plan_for", "UtilsGNN", "MatVecGNN", "GNNResidual", "JacobiGNN", "ChebyGNN",
+           "PowerMethodGNN", "SOCClassicGNN", "DirectInterpGNN", "SOCSAGNN", "MatrixWeightedNorm"]

@@ -1,0 +1,72 @@
+"""Host-side helpers shared by the nn.Module mirror of the reference's operator surface."""
+import torch
+
+from . import _lib
+from .plan import plan_for
+
+
+def compute_device(*tensors):
+    """GPU the call runs on: the device of the first GPU operand, else the current HIP device.
+    The reference is CPU-only, so CPU operands are accepted, moved once, and results moved back."""
+    _lib.require_gpu()
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_dev(t, dev):
+    """Move to `dev`, caching the copy on the source tensor so that plans cached on the copy survive
+    repeated calls with the same CPU tensor."""
+    if t is None or t.device == dev:
+        return t
+    key = (t._version, dev)
+    cached = getattr(t, "_gla_dev_copy", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    c = t.to(dev)
+    try:
+        t._gla_dev_copy = (key, c)
+    except Exception:
+        pass
+    return c
+
+
+def back(t, like):
+    """Return `t` on the device of the caller's operand `like`."""
+    if t is None or not isinstance(like, torch.Tensor) or t.device == like.device:
+        return t
+    return t.to(like.device)
+
+
+def float_dtype(*tensors):
+    dt = tensors[0].dtype
+    if dt not in (torch.float32, torch.float64):
+        raise TypeError(f"vertex/edge attributes must be float32 or float64, got {dt}")
+    return dt
+
+
+def cols(t, idx):
+    """Column(s) `idx` of an AoS attribute tensor as a contiguous [n, K] operand.
+    t is [n, a] (K = 1) or [n, a, K] (multi-RHS extension: trailing dimension K)."""
+    if t.dim() == 2:
+        return t[:, idx].reshape(-1, 1).contiguous()
+    if t.dim() == 3:
+        return t[:, idx, :].contiguous()
+    raise ValueError(f"attribute tensor must be [n, a] or [n, a, K], got {tuple(t.shape)}")
+
+
+def stack_cols(parts, like):
+    """Inverse of `cols`: list of [n, K] -> [n, a] (like.dim()==2) or [n, a, K]."""
+    if like.dim() == 2:
+        return torch.cat(parts, 1)
+    return torch.stack(parts, 1)
+
+
+def edge_cols(edge_attr, c):
+    """edge_attr column 0 (A_ij) next to freshly computed per-edge products c [nnz, K] -> [nnz, 1+K]."""
+    A = edge_attr[:, 0].reshape(-1, 1) if edge_attr.dim() == 2 else edge_attr.reshape(-1, 1)
+    return torch.cat([A, c], 1)
+
+
+__all__ = ["compute_device", "to_dev", "back", "float_dtype", "cols", "stack_cols", "edge_cols", "plan_for"]

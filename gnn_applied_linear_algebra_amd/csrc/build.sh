@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libgla_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+#   -ffp-contract=off : no FMA contraction, so row sums and vertex updates round exactly like the
+#                       reference's separate torch mul / add ops (bit-exact parity)
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-result"
+OUT=../libgla_hip.so
+for f in gla_kernels gla_plan; do
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gla_internal.h -nt $f.o ] || [ ../../include/gla.h -nt $f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o $f.o &
+  fi
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC gla_kernels.o gla_plan.o -o $OUT
+echo "built $(realpath $OUT)"

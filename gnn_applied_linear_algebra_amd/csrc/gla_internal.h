@@ -1,0 +1,37 @@
+// Internal declarations shared by the translation units of libgla_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gla.h"
+
+#define GLA_HIP_CHECK(expr)                                   \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) return -(1000 + (int)_e);           \
+  } while (0)
+
+#define GLA_LAUNCH_CHECK() GLA_HIP_CHECK(hipGetLastError())
+
+constexpr int GLA_BLOCK = 256;          // 4 wavefronts of 64 lanes
+constexpr int GLA_XCDS = 8;             // MI355X: 8 XCDs, each with a private L2
+constexpr int GLA_LDS_ELEMS_MAX = 4096; // staged nnz per workgroup (32 KiB of f64 products)
+constexpr int GLA_TILE_NNZ_MIN = 1024;
+constexpr int GLA_PAD = 8;              // over-read slack (elements) behind val/col
+
+struct gla_csr {
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;     // [n_rows + 1]
+  int32_t* col = nullptr;        // [nnz + GLA_PAD], CSR order
+  int32_t* perm = nullptr;       // [nnz] CSR position -> edge id, or nullptr (identity)
+  void* val = nullptr;           // [nnz + GLA_PAD] * 8 bytes, CSR order
+  int val_dtype = -1;
+  int32_t* tile_row = nullptr;   // [n_tiles + 1] first row of each tile
+  int32_t* tile_lists = nullptr; // [2 * n_tiles]: interior tiles then boundary tiles
+  int32_t n_tiles = 0, n_interior = 0, n_boundary = 0;
+  int32_t tile_nnz = 0, lds_elems = 0, max_row_len = 0;
+  int32_t sorted_input = 1, long_rows = 0;
+};
+
+// plan.hip
+int gla_sort_rows_stable(int64_t nnz, int64_t n_rows, const int64_t* row, int32_t* perm_out,
+                         uint32_t* keys_sorted, hipStream_t stream);

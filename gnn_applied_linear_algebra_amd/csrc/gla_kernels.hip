@@ -1,0 +1,683 @@
+// libgla_hip.so -- hot-path kernels (gfx950 / MI355X only; wave = 64 lanes).
+//
+// One CSR "row-tile" kernel family replaces the reference's per-layer
+//   gather x[col] -> multiply -> torch.cat -> torch_scatter.scatter(sum) -> vertex update -> torch.cat
+// (e.g. pytorch/JacobiGNN.py:52-123) with a single pass over HBM:
+//
+//   phase 1  the workgroup streams its tile's nnz (val f64/f32 + col int32, CSR order) with fully
+//            coalesced loads, gathers x[col] (served by the XCD's L2: a tile's column window is a few
+//            grid lines) and parks the products in LDS;
+//   phase 2  one lane per row adds its products IN EDGE ORDER (sequential, no FMA contraction, so the
+//            sum is bit-identical to the reference's CPU scatter-add) and applies the fused vertex
+//            update (residual / Jacobi / Chebyshev ...), reading and writing the dense vectors once.
+//
+// Tiles are contiguous row ranges holding ~tile_nnz nonzeros (CSR-adaptive "stream" binning computed at
+// plan creation); blockIdx is remapped so that each XCD walks a contiguous span of tiles and the x window
+// stays in that XCD's 4 MiB L2.  Matrices with a row longer than the LDS tile fall back to a
+// wave-per-row (CSR-vector) kernel whose sums are tree-ordered (documented in DESIGN.md).
+//
+// Multi-RHS (K > 1, row-major [n, K]): val/col are staged in LDS instead of products, and the lanes
+// are (row, rhs) pairs so that every gather reads K contiguous values of one X row.
+#include "gla_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// device views
+// ------------------------------------------------------------------------------------------------
+struct TileMap {
+  const int32_t* tile_row;
+  const int32_t* tile_list;   // nullptr = identity
+  int n_tiles;                // tiles to run in this launch
+  int tiles_per_xcd;
+};
+
+__device__ __forceinline__ int map_tile(const TileMap& m) {
+  const int bid = blockIdx.x;
+  const int slot = (bid % GLA_XCDS) * m.tiles_per_xcd + bid / GLA_XCDS;
+  if (slot >= m.n_tiles) return -1;
+  return m.tile_list ? m.tile_list[slot] : slot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused vertex updates ("epilogues"): called once per (row, rhs) with the finished row sum
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct EpiStore {                       // y = A x                       MatVecGNN.py:95-114
+  T* y; int64_t ldy;
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { y[r * ldy + k] = acc; }
+};
+
+template <typename T>
+struct EpiResidual {                    // r = b - A x                   GNNResidual.py:97-118
+  const T* b; int64_t ldb; T* res; int64_t ldr;
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {
+    res[r * ldr + k] = b[r * ldb + k] - acc;
+  }
+};
+
+template <typename T>
+struct EpiJacobi {                      // x + (w*(b - A x))/A_ii        JacobiGNN.py:100-123 (:119)
+  const T* diag; const T* b; int64_t ldb; const T* x; int64_t ldx; T* xo; int64_t ldxo; T w;
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {
+    const T xi = x[r * ldx + k];
+    xo[r * ldxo + k] = xi + (w * (b[r * ldb + k] - acc)) / diag[r];
+  }
+};
+
+template <typename T>
+struct EpiChebyFirst {                  // r = b - A x; p = r; x += alpha p    ChebyGNN.py:91-163
+  const T* b; int64_t ldb; const T* x; int64_t ldx; T* res; int64_t ldr; T* p; int64_t ldp;
+  T* xo; int64_t ldxo; T alpha;
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {
+    const T ri = b[r * ldb + k] - acc;
+    res[r * ldr + k] = ri;
+    p[r * ldp + k] = ri;
+    xo[r * ldxo + k] = x[r * ldx + k] + alpha * ri;
+  }
+};
+
+template <typename T>
+struct EpiChebyNext {                   // r -= a_old*(A p); p = r + beta p; x += a_new p   ChebyGNN.py:186-243
+  const T* p; int64_t ldp; T* po; int64_t ldpo; T* res; int64_t ldr; T* x; int64_t ldx;
+  T a_old, a_new, beta;
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {
+    const T ri = res[r * ldr + k] - a_old * acc;
+    res[r * ldr + k] = ri;
+    const T pn = ri + beta * p[r * ldp + k];
+    po[r * ldpo + k] = pn;
+    x[r * ldx + k] = x[r * ldx + k] + a_new * pn;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// K = 1: products staged in LDS
+// ------------------------------------------------------------------------------------------------
+constexpr int SPMV_UNROLL = 4;
+
+template <typename T, class Epi>
+__global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ x, TileMap tm, Epi epi) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* prod = reinterpret_cast<T*>(smem_raw);
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  if (r0 >= r1) return;
+  const int s = rowptr[r0];
+  const int len = rowptr[r1] - s;
+  const int tid = threadIdx.x;
+
+  for (int base = 0; base < len; base += GLA_BLOCK * SPMV_UNROLL) {
+    T v[SPMV_UNROLL];
+    int c[SPMV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; ++u) {
+      const int i = base + u * GLA_BLOCK + tid;
+      const bool ok = i < len;
+      c[u] = ok ? col[s + i] : 0;
+      v[u] = ok ? val[s + i] : T(0);
+    }
+    T xv[SPMV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; ++u) xv[u] = x[c[u]];
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; ++u) {
+      const int i = base + u * GLA_BLOCK + tid;
+      if (i < len) prod[i] = v[u] * xv[u];
+    }
+  }
+  __syncthreads();
+
+  for (int r = r0 + tid; r < r1; r += GLA_BLOCK) {
+    const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
+    T acc = T(0);
+    for (int j = a; j < b; ++j) acc = acc + prod[j];
+    epi((int64_t)r, 0, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K > 1: val/col staged in LDS, lanes = (row, rhs)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KP, class Epi>
+__global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ X, int64_t ldx, int K, int lds_elems, TileMap tm, Epi epi) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sval = reinterpret_cast<T*>(smem_raw);
+  int32_t* scol = reinterpret_cast<int32_t*>(sval + lds_elems);
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  if (r0 >= r1) return;
+  const int s = rowptr[r0];
+  const int len = rowptr[r1] - s;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < len; i += GLA_BLOCK) {
+    sval[i] = val[s + i];
+    scol[i] = col[s + i];
+  }
+  __syncthreads();
+  constexpr int RPP = GLA_BLOCK / KP;          // rows per pass
+  const int k0 = tid % KP, rsub = tid / KP;
+  for (int r = r0 + rsub; r < r1; r += RPP) {
+    const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
+    for (int k = k0; k < K; k += KP) {
+      T acc = T(0);
+#pragma unroll 4
+      for (int j = a; j < b; ++j) acc = acc + sval[j] * X[(int64_t)scol[j] * ldx + k];
+      epi((int64_t)r, k, acc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fallback for plans with a row longer than the LDS tile: one wave per row, tree-ordered sum
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = v + __shfl_down(v, off, 64);
+  return v;
+}
+
+template <typename T, class Epi>
+__global__ __launch_bounds__(GLA_BLOCK) void spmm_vector_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ X, int64_t ldx, int K, int64_t n_rows, Epi epi) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * GLA_BLOCK) >> 6;
+  for (int64_t r = wave; r < n_rows; r += n_waves) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    for (int k = 0; k < K; ++k) {
+      T acc = T(0);
+      for (int j = a + lane; j < b; j += 64) acc = acc + val[j] * X[(int64_t)col[j] * ldx + k];
+      acc = wave_sum(acc);
+      if (lane == 0) epi(r, k, acc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helper
+// ------------------------------------------------------------------------------------------------
+template <typename T, class Epi>
+int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int which, hipStream_t st) {
+  if (A->n_rows == 0) return GLA_OK;
+  const T* val = static_cast<const T*>(A->val);
+  if (A->long_rows) {
+    if (which == 1) return GLA_OK;        // nothing is "interior" for the fallback: all rows run after the halo
+    const int64_t waves_needed = A->n_rows;
+    int64_t blocks = (waves_needed * 64 + GLA_BLOCK - 1) / GLA_BLOCK;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((spmm_vector_kernel<T, Epi>), dim3((unsigned)blocks), dim3(GLA_BLOCK), 0, st,
+                       A->rowptr, A->col, val, X, ldx, K, A->n_rows, epi);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  }
+  TileMap tm;
+  tm.tile_row = A->tile_row;
+  if (which == 0) { tm.tile_list = nullptr; tm.n_tiles = A->n_tiles; }
+  else if (which == 1) { tm.tile_list = A->tile_lists; tm.n_tiles = A->n_interior; }
+  else if (which == 2) { tm.tile_list = A->tile_lists + A->n_tiles; tm.n_tiles = A->n_boundary; }
+  else return GLA_ERR_INVALID_ARG;
+  if (which != 0 && A->tile_lists == nullptr) return GLA_ERR_INVALID_ARG;
+  if (tm.n_tiles == 0) return GLA_OK;
+  tm.tiles_per_xcd = (tm.n_tiles + GLA_XCDS - 1) / GLA_XCDS;
+  const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
+  if (K == 1) {
+    const size_t lds = (size_t)A->lds_elems * sizeof(T);
+    hipLaunchKernelGGL((spmv_stream_kernel<T, Epi>), grid, block, lds, st, A->rowptr, A->col, val, X, tm, epi);
+  } else {
+    const size_t lds = (size_t)A->lds_elems * (sizeof(T) + sizeof(int32_t));
+#define GLA_SPMM_CASE(KP_)                                                                              \
+  hipLaunchKernelGGL((spmm_stream_kernel<T, KP_, Epi>), grid, block, lds, st, A->rowptr, A->col, val, X, \
+                     ldx, K, A->lds_elems, tm, epi)
+    if (K <= 2) GLA_SPMM_CASE(2);
+    else if (K <= 4) GLA_SPMM_CASE(4);
+    else if (K <= 8) GLA_SPMM_CASE(8);
+    else if (K <= 16) GLA_SPMM_CASE(16);
+    else if (K <= 32) GLA_SPMM_CASE(32);
+    else GLA_SPMM_CASE(64);
+#undef GLA_SPMM_CASE
+  }
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+inline int check_plan(gla_csr* A, int dtype, int K) {
+  if (!A || K < 1 || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
+  return GLA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge-wise kernels (outputs in EDGE order)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void edge_products_kernel(
+    const int32_t* __restrict__ col, const T* __restrict__ val, const int32_t* __restrict__ perm,
+    const T* __restrict__ X, int64_t ldx, T* __restrict__ C, int64_t ldc, int64_t nnz, int K) {
+  const int64_t total = nnz * K;
+  for (int64_t idx = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int64_t p = idx / K;
+    const int k = (int)(idx - p * K);
+    const int64_t e = perm ? perm[p] : p;
+    C[e * ldc + k] = val[p] * X[(int64_t)col[p] * ldx + k];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T nan_max(T m, T a) { return (a > m || a != a) ? a : m; }
+
+// v_i = max_j(-A_ij); S = relu(-A/v - theta).  SOCClassicGNN.py:50-129
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void soc_classic_kernel(
+    const int32_t* __restrict__ rowptr, const T* __restrict__ val, const int32_t* __restrict__ perm,
+    TileMap tm, T theta, T* __restrict__ v_out, T* __restrict__ S_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sv = reinterpret_cast<T*>(smem_raw);
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  if (r0 >= r1) return;
+  const int s = rowptr[r0];
+  const int len = rowptr[r1] - s;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < len; i += GLA_BLOCK) sv[i] = val[s + i];
+  __syncthreads();
+  for (int r = r0 + tid; r < r1; r += GLA_BLOCK) {
+    const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
+    T m = T(0);                                   // torch_scatter: empty segment -> 0
+    if (a < b) {
+      m = T(-1) * sv[a];
+      for (int j = a + 1; j < b; ++j) m = nan_max(m, T(-1) * sv[j]);
+    }
+    v_out[r] = m;
+    for (int j = a; j < b; ++j) {
+      const T q = (T(-1) * sv[j]) / m - theta;
+      sv[j] = (q != q) ? q : (q > T(0) ? q : T(0));   // relu keeps NaN, like torch.nn.ReLU
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < len; i += GLA_BLOCK) {
+    const int64_t e = perm ? perm[s + i] : (int64_t)(s + i);
+    S_out[e] = sv[i];
+  }
+}
+
+// DirectInterpGNN.py:50-152
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void direct_interp_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const int32_t* __restrict__ perm, TileMap tm, int lds_elems, const T* __restrict__ diag,
+    const T* __restrict__ cf, const T* __restrict__ S, T* __restrict__ w_out, T* __restrict__ alpha_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sa = reinterpret_cast<T*>(smem_raw);         // A_ik, later w_ik
+  T* sd = sa + lds_elems;                         // A_ik * S_ik * C_k
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  if (r0 >= r1) return;
+  const int s = rowptr[r0];
+  const int len = rowptr[r1] - s;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < len; i += GLA_BLOCK) {
+    const int64_t e = perm ? perm[s + i] : (int64_t)(s + i);
+    const T a = val[s + i];
+    sa[i] = a;
+    sd[i] = (a * S[e]) * cf[col[s + i]];
+  }
+  __syncthreads();
+  for (int r = r0 + tid; r < r1; r += GLA_BLOCK) {
+    const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
+    T num = T(0), den = T(0);
+    for (int j = a; j < b; ++j) { num = num + sa[j]; den = den + sd[j]; }
+    const T gamma = num / den;
+    const T alpha = (T(1) / diag[r]) * gamma;
+    if (alpha_out) alpha_out[r] = alpha;
+    const T omc = T(1) - cf[r];
+    for (int j = a; j < b; ++j) sa[j] = omc * ((T(-1) * sa[j]) * alpha);
+  }
+  __syncthreads();
+  for (int i = tid; i < len; i += GLA_BLOCK) {
+    const int64_t e = perm ? perm[s + i] : (int64_t)(s + i);
+    w_out[e] = sa[i];
+  }
+}
+
+// SOCSAGNN.py:49-71: S = (A*A)/(A_ii*A_jj); the row endpoint is known per row-lane, the column endpoint
+// is gathered while streaming
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void soc_sa_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const int32_t* __restrict__ perm, TileMap tm, int lds_elems, const T* __restrict__ diag,
+    T* __restrict__ S_out) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sa = reinterpret_cast<T*>(smem_raw);         // A_ij^2, later S_ij
+  T* sd = sa + lds_elems;                         // A_jj
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  if (r0 >= r1) return;
+  const int s = rowptr[r0];
+  const int len = rowptr[r1] - s;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < len; i += GLA_BLOCK) {
+    const T a = val[s + i];
+    sa[i] = a * a;
+    sd[i] = diag[col[s + i]];
+  }
+  __syncthreads();
+  for (int r = r0 + tid; r < r1; r += GLA_BLOCK) {
+    const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
+    const T di = diag[r];
+    for (int j = a; j < b; ++j) sa[j] = sa[j] / (di * sd[j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < len; i += GLA_BLOCK) {
+    const int64_t e = perm ? perm[s + i] : (int64_t)(s + i);
+    S_out[e] = sa[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column dots / scaling (global aggregations of the power method)
+// ------------------------------------------------------------------------------------------------
+constexpr int DOT_BLOCKS_MAX = 1024;
+
+template <typename T, int KP>
+__global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage1(const T* __restrict__ X, int64_t ldx,
+                                                            const T* __restrict__ Y, int64_t ldy, int64_t n,
+                                                            int K, T* __restrict__ partial) {
+  __shared__ T red[GLA_BLOCK];
+  constexpr int RPP = GLA_BLOCK / KP;
+  const int tid = threadIdx.x, k0 = tid % KP, rsub = tid / KP;
+  for (int kb = 0; kb < K; kb += KP) {
+    const int k = kb + k0;
+    T acc = T(0);
+    if (k < K)
+      for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n; r += (int64_t)gridDim.x * RPP)
+        acc = acc + X[r * ldx + k] * Y[r * ldy + k];
+    red[tid] = acc;
+    __syncthreads();
+    for (int st = GLA_BLOCK / 2; st >= KP; st >>= 1) {
+      if (tid < st) red[tid] = red[tid] + red[tid + st];
+      __syncthreads();
+    }
+    if (tid < KP && k < K) partial[(int64_t)blockIdx.x * K + k] = red[tid];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage2(const T* __restrict__ partial, int nblocks, int K,
+                                                            T* __restrict__ out) {
+  __shared__ T red[GLA_BLOCK];
+  const int tid = threadIdx.x;
+  for (int k = 0; k < K; ++k) {
+    T acc = T(0);
+    for (int b = tid; b < nblocks; b += GLA_BLOCK) acc = acc + partial[(int64_t)b * K + k];
+    red[tid] = acc;
+    __syncthreads();
+    for (int st = GLA_BLOCK / 2; st > 0; st >>= 1) {
+      if (tid < st) red[tid] = red[tid] + red[tid + st];
+      __syncthreads();
+    }
+    if (tid == 0) out[k] = red[0];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void col_scale_rsqrt_kernel(const T* __restrict__ X, int64_t ldx,
+                                                                    const T* __restrict__ sumsq,
+                                                                    T* __restrict__ Y, int64_t ldy, int64_t n,
+                                                                    int K) {
+  const int64_t total = n * K;
+  for (int64_t idx = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int64_t r = idx / K;
+    const int k = (int)(idx - r * K);
+    Y[r * ldy + k] = X[r * ldx + k] / sqrt(sumsq[k]);
+  }
+}
+
+inline unsigned grid_for(int64_t work, int per_block = GLA_BLOCK, int cap = 256 * 8) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+inline TileMap all_tiles(gla_csr* A) {
+  TileMap tm;
+  tm.tile_row = A->tile_row;
+  tm.tile_list = nullptr;
+  tm.n_tiles = A->n_tiles;
+  tm.tiles_per_xcd = (A->n_tiles + GLA_XCDS - 1) / GLA_XCDS;
+  return tm;
+}
+
+template <typename T>
+int launch_col_dot(int64_t n, int K, const T* x, int64_t ldx, const T* y, int64_t ldy, T* out, T* pw,
+                   hipStream_t st) {
+  int kp = 1;
+  while (kp < K && kp < 64) kp <<= 1;
+  const int rpp = GLA_BLOCK / kp;
+  const unsigned nb = grid_for(n, rpp * 8, DOT_BLOCKS_MAX);
+#define GLA_DOT_CASE(KP_) \
+  hipLaunchKernelGGL((col_dot_stage1<T, KP_>), dim3(nb), dim3(GLA_BLOCK), 0, st, x, ldx, y, ldy, n, K, pw)
+  switch (kp) {
+    case 1: GLA_DOT_CASE(1); break;
+    case 2: GLA_DOT_CASE(2); break;
+    case 4: GLA_DOT_CASE(4); break;
+    case 8: GLA_DOT_CASE(8); break;
+    case 16: GLA_DOT_CASE(16); break;
+    case 32: GLA_DOT_CASE(32); break;
+    default: GLA_DOT_CASE(64); break;
+  }
+#undef GLA_DOT_CASE
+  GLA_LAUNCH_CHECK();
+  hipLaunchKernelGGL((col_dot_stage2<T>), dim3(1), dim3(GLA_BLOCK), 0, st, pw, (int)nb, K, out);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+#define GLA_DISPATCH(dtype, ...)                              \
+  if ((dtype) == GLA_F64) { using T = double; __VA_ARGS__; }  \
+  else { using T = float; __VA_ARGS__; }
+
+extern "C" {
+
+int gla_spmm(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* Y, int64_t ldy, int which,
+             gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!X || !Y || ldx < K || ldy < K) return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiStore<T> epi{(T*)Y, ldy};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_residual(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, const void* X, int64_t ldx, void* R,
+                 int64_t ldr, int which, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!B || !X || !R || ldb < K || ldx < K || ldr < K) return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiResidual<T> epi{(const T*)B, ldb, (T*)R, ldr};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X,
+                     int64_t ldx, void* Xout, int64_t ldxo, double w, int which, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!diag || !B || !X || !Xout || X == Xout || ldb < K || ldx < K || ldxo < K) return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiJacobi<T> epi{(const T*)diag, (const T*)B, ldb, (const T*)X, ldx, (T*)Xout, ldxo, (T)w};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X0,
+                      int64_t ldx0, void* Xout, void* Xtmp, int64_t ldw, double w, int n_iters,
+                      gla_stream_t stream) {
+  if (!A || n_iters < 0) return GLA_ERR_INVALID_ARG;
+  if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
+  if (n_iters == 0) return GLA_OK;
+  if (!Xout || (n_iters > 1 && !Xtmp) || Xout == Xtmp) return GLA_ERR_INVALID_ARG;
+  const void* src = X0;
+  int64_t lds_ = ldx0;
+  for (int i = 1; i <= n_iters; ++i) {
+    void* dst = ((n_iters - i) % 2 == 0) ? Xout : Xtmp;
+    int rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, src, lds_, dst, ldw, w, 0, stream);
+    if (rc) return rc;
+    src = dst;
+    lds_ = ldw;
+  }
+  return GLA_OK;
+}
+
+int gla_cheby_first(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, const void* X, int64_t ldx, void* R,
+                    int64_t ldr, void* P, int64_t ldp, void* Xout, int64_t ldxo, double alpha, int which,
+                    gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!B || !X || !R || !P || !Xout || X == Xout || ldb < K || ldx < K || ldr < K || ldp < K || ldxo < K)
+    return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiChebyFirst<T> epi{(const T*)B, ldb, (const T*)X, ldx, (T*)R, ldr, (T*)P, ldp, (T*)Xout, ldxo, (T)alpha};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, void* Pout, int64_t ldpo, void* R,
+                   int64_t ldr, void* X, int64_t ldx, double alpha_old, double alpha_new, double beta, int which,
+                   gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!P || !Pout || !R || !X || P == Pout || ldp < K || ldpo < K || ldr < K || ldx < K)
+    return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiChebyNext<T> epi{(const T*)P, ldp, (T*)Pout, ldpo, (T*)R, ldr, (T*)X, ldx,
+                        (T)alpha_old, (T)alpha_new, (T)beta};
+    return launch_rows<T>(A, K, (const T*)P, ldp, epi, which, (hipStream_t)stream);
+  })
+}
+
+int64_t gla_dot_work_bytes(int64_t n, int K, int dtype) {
+  (void)n;
+  return (int64_t)DOT_BLOCKS_MAX * (K < 1 ? 1 : K) * (dtype == GLA_F64 ? 8 : 4);
+}
+
+int gla_col_dot(int dtype, int64_t n, int K, const void* X, int64_t ldx, const void* Y, int64_t ldy, void* out,
+                void* work, gla_stream_t stream) {
+  if (n < 0 || K < 1 || !out || !work || (n > 0 && (!X || !Y)) || ldx < K || ldy < K ||
+      (dtype != GLA_F32 && dtype != GLA_F64))
+    return GLA_ERR_INVALID_ARG;
+  if (dtype == GLA_F64)
+    return launch_col_dot<double>(n, K, (const double*)X, ldx, (const double*)Y, ldy, (double*)out, (double*)work,
+                                  (hipStream_t)stream);
+  return launch_col_dot<float>(n, K, (const float*)X, ldx, (const float*)Y, ldy, (float*)out, (float*)work,
+                               (hipStream_t)stream);
+}
+
+int gla_col_scale_rsqrt(int dtype, int64_t n, int K, const void* X, int64_t ldx, const void* sumsq, void* Y,
+                        int64_t ldy, gla_stream_t stream) {
+  if (n < 0 || K < 1 || !sumsq || (n > 0 && (!X || !Y)) || ldx < K || ldy < K ||
+      (dtype != GLA_F32 && dtype != GLA_F64))
+    return GLA_ERR_INVALID_ARG;
+  if (n == 0) return GLA_OK;
+  GLA_DISPATCH(dtype, {
+    hipLaunchKernelGGL((col_scale_rsqrt_kernel<T>), dim3(grid_for(n * K, GLA_BLOCK * 4)), dim3(GLA_BLOCK), 0,
+                       (hipStream_t)stream, (const T*)X, ldx, (const T*)sumsq, (T*)Y, ldy, n, K);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  })
+}
+
+int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,
+                      gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!X || (A->nnz > 0 && !C) || ldx < K || ldc < K) return GLA_ERR_INVALID_ARG;
+  if (A->nnz == 0) return GLA_OK;
+  GLA_DISPATCH(dtype, {
+    hipLaunchKernelGGL((edge_products_kernel<T>), dim3(grid_for(A->nnz * K, GLA_BLOCK * 4, 256 * 16)),
+                       dim3(GLA_BLOCK), 0, (hipStream_t)stream, A->col, (const T*)A->val, A->perm,
+                       (const T*)X, ldx, (T*)C, ldc, A->nnz, K);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  })
+}
+
+int gla_soc_classic(gla_csr_t A, int dtype, double theta, void* v_out, void* S_out, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, 1);
+  if (rc) return rc;
+  if (!v_out && A->n_rows > 0) return GLA_ERR_INVALID_ARG;
+  if (!S_out && A->nnz > 0) return GLA_ERR_INVALID_ARG;
+  if (A->long_rows) return GLA_ERR_UNSUPPORTED;
+  if (A->n_rows == 0) return GLA_OK;
+  TileMap tm = all_tiles(A);
+  GLA_DISPATCH(dtype, {
+    hipLaunchKernelGGL((soc_classic_kernel<T>), dim3(tm.tiles_per_xcd * GLA_XCDS), dim3(GLA_BLOCK),
+                       (size_t)A->lds_elems * sizeof(T), (hipStream_t)stream, A->rowptr, (const T*)A->val,
+                       A->perm, tm, (T)theta, (T*)v_out, (T*)S_out);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  })
+}
+
+int gla_direct_interp(gla_csr_t A, int dtype, const void* diag, const void* cf, const void* S, void* w_out,
+                      void* alpha_out, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, 1);
+  if (rc) return rc;
+  if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
+  if (A->n_rows > 0 && (!diag || !cf)) return GLA_ERR_INVALID_ARG;
+  if (A->nnz > 0 && (!S || !w_out)) return GLA_ERR_INVALID_ARG;
+  if (A->long_rows) return GLA_ERR_UNSUPPORTED;
+  if (A->n_rows == 0) return GLA_OK;
+  TileMap tm = all_tiles(A);
+  GLA_DISPATCH(dtype, {
+    hipLaunchKernelGGL((direct_interp_kernel<T>), dim3(tm.tiles_per_xcd * GLA_XCDS), dim3(GLA_BLOCK),
+                       (size_t)A->lds_elems * sizeof(T) * 2, (hipStream_t)stream, A->rowptr, A->col,
+                       (const T*)A->val, A->perm, tm, A->lds_elems, (const T*)diag, (const T*)cf, (const T*)S,
+                       (T*)w_out, (T*)alpha_out);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  })
+}
+
+int gla_soc_sa(gla_csr_t A, int dtype, const void* diag, void* S_out, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, 1);
+  if (rc) return rc;
+  if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
+  if ((A->n_rows > 0 && !diag) || (A->nnz > 0 && !S_out)) return GLA_ERR_INVALID_ARG;
+  if (A->long_rows) return GLA_ERR_UNSUPPORTED;
+  if (A->n_rows == 0) return GLA_OK;
+  TileMap tm = all_tiles(A);
+  GLA_DISPATCH(dtype, {
+    hipLaunchKernelGGL((soc_sa_kernel<T>), dim3(tm.tiles_per_xcd * GLA_XCDS), dim3(GLA_BLOCK),
+                       (size_t)A->lds_elems * sizeof(T) * 2, (hipStream_t)stream, A->rowptr, A->col,
+                       (const T*)A->val, A->perm, tm, A->lds_elems, (const T*)diag, (T*)S_out);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  })
+}
+
+}  // extern "C"

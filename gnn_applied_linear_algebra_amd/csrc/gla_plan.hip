@@ -1,0 +1,523 @@
+// libgla_hip.so -- plan construction (COO edge list -> CSR row tiles) and graph builders (gfx950 only).
+//
+// The reference hands every layer a COO edge list (edgeij_pair int64 [2,nnz]) and lets
+// torch_scatter.scatter re-discover the row structure on every call.  Here that work is
+// done once per graph: validate indices, stable-sort by row if needed (edge order is preserved inside a
+// row so that row sums keep the reference's summation order), build rowptr, measure the longest row and
+// cut the rows into tiles of ~tile_nnz nonzeros for the CSR-stream kernels.
+#include <cstring>
+#include "gla_internal.h"
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+constexpr int FLAG_UNSORTED = 1, FLAG_RANGE = 2;
+
+__global__ __launch_bounds__(GLA_BLOCK) void validate_kernel(const int64_t* __restrict__ row,
+                                                             const int64_t* __restrict__ col, int64_t nnz,
+                                                             int64_t n_rows, int64_t n_cols, int* flags) {
+  int f = 0;
+  for (int64_t e = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int64_t r = row[e], c = col[e];
+    if (r < 0 || r >= n_rows || c < 0 || c >= n_cols) f |= FLAG_RANGE;
+    if (e > 0 && row[e - 1] > r) f |= FLAG_UNSORTED;
+  }
+  if (f) atomicOr(flags, f);
+}
+
+// rowptr from a row-sorted key array: every edge that starts a new row fills the gap of (possibly empty)
+// rows in front of it.
+template <typename KeyT>
+__global__ __launch_bounds__(GLA_BLOCK) void rowptr_kernel(const KeyT* __restrict__ rows_sorted, int64_t nnz,
+                                                           int64_t n_rows, int32_t* __restrict__ rowptr) {
+  for (int64_t e = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; e <= nnz; e += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int64_t prev = (e == 0) ? -1 : (int64_t)rows_sorted[e - 1];
+    const int64_t cur = (e == nnz) ? n_rows : (int64_t)rows_sorted[e];
+    for (int64_t q = prev + 1; q <= cur; ++q) rowptr[q] = (int32_t)e;
+  }
+}
+
+__global__ __launch_bounds__(GLA_BLOCK) void keys_kernel(const int64_t* __restrict__ row, int64_t nnz,
+                                                         uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
+  for (int64_t e = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * GLA_BLOCK) {
+    keys[e] = (uint32_t)row[e];
+    ids[e] = (int32_t)e;
+  }
+}
+
+__global__ __launch_bounds__(GLA_BLOCK) void gather_col_kernel(const int64_t* __restrict__ col,
+                                                               const int32_t* __restrict__ perm, int64_t nnz,
+                                                               int32_t* __restrict__ col32) {
+  for (int64_t p = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; p < nnz + GLA_PAD;
+       p += (int64_t)gridDim.x * GLA_BLOCK)
+    col32[p] = (p < nnz) ? (int32_t)col[perm ? perm[p] : p] : 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void gather_val_kernel(const T* __restrict__ edge_val, int64_t stride,
+                                                               const int32_t* __restrict__ perm, int64_t nnz,
+                                                               T* __restrict__ val) {
+  for (int64_t p = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; p < nnz + GLA_PAD;
+       p += (int64_t)gridDim.x * GLA_BLOCK)
+    val[p] = (p < nnz) ? edge_val[(perm ? (int64_t)perm[p] : p) * stride] : T(0);
+}
+
+__global__ __launch_bounds__(GLA_BLOCK) void max_row_len_kernel(const int32_t* __restrict__ rowptr, int64_t n_rows,
+                                                                int* out) {
+  int m = 0;
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK)
+    m = max(m, rowptr[r + 1] - rowptr[r]);
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+// tile_row[k] = first row r with rowptr[r] >= k * tile_nnz (k < n_tiles); tile_row[n_tiles] = n_rows
+__global__ __launch_bounds__(GLA_BLOCK) void tile_rows_kernel(const int32_t* __restrict__ rowptr, int64_t n_rows,
+                                                              int n_tiles, int tile_nnz, int32_t* __restrict__ tile_row) {
+  const int k = blockIdx.x * GLA_BLOCK + threadIdx.x;
+  if (k > n_tiles) return;
+  if (k == n_tiles) { tile_row[k] = (int32_t)n_rows; return; }
+  if (k == 0) { tile_row[0] = 0; return; }
+  const int64_t target = (int64_t)k * tile_nnz;
+  int64_t lo = 0, hi = n_rows;                    // rowptr is non-decreasing on [0, n_rows]
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)rowptr[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  tile_row[k] = (int32_t)lo;
+}
+
+// a tile is "boundary" when any of its columns is >= col_limit (a halo column of a row-block partition)
+__global__ __launch_bounds__(GLA_BLOCK) void tile_flag_kernel(const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ col,
+                                                              const int32_t* __restrict__ tile_row, int n_tiles,
+                                                              int32_t col_limit, int32_t* __restrict__ flag) {
+  const int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  const int s = rowptr[tile_row[t]], e = rowptr[tile_row[t + 1]];
+  int f = 0;
+  for (int i = s + threadIdx.x; i < e; i += GLA_BLOCK) f |= (col[i] >= col_limit);
+  if (__syncthreads_or(f) && threadIdx.x == 0) flag[t] = 1;
+}
+
+// ---- builders --------------------------------------------------------------------------------
+// nnz in rows [0, k) of the Ny x Nx 5-point grid (vertex k = j*Nx + i)
+__host__ __device__ inline int64_t lap_offset(int64_t k, int64_t Nx, int64_t Ny) {
+  const int64_t j = k / Nx, i = k - j * Nx;
+  int64_t off = 5 * k;
+  off -= j + (i > 0 ? 1 : 0);             // rows < k with i == 0       (no left neighbour)
+  off -= j;                               // rows < k with i == Nx - 1  (no right neighbour)
+  off -= (j == 0 ? i : Nx);               // rows < k with j == 0       (no lower neighbour)
+  off -= (j == Ny - 1 ? i : 0);           // rows < k with j == Ny - 1  (no upper neighbour)
+  if (j >= Ny) off = 5 * Nx * Ny - 2 * Nx - 2 * Ny;   // k == Nx*Ny (one past the end)
+  return off;
+}
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void laplacian2d_kernel(int64_t Nx, int64_t Ny, int64_t row_lo,
+                                                                int64_t row_hi, int64_t base,
+                                                                int64_t* __restrict__ row, int64_t* __restrict__ col,
+                                                                T* __restrict__ val) {
+  for (int64_t k = row_lo + (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; k < row_hi;
+       k += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int64_t j = k / Nx, i = k - j * Nx;
+    int64_t o = lap_offset(k, Nx, Ny) - base;
+    if (j > 0) { row[o] = k; col[o] = k - Nx; val[o] = T(1); ++o; }
+    if (i > 0) { row[o] = k; col[o] = k - 1; val[o] = T(1); ++o; }
+    row[o] = k; col[o] = k; val[o] = T(-4); ++o;
+    if (i < Nx - 1) { row[o] = k; col[o] = k + 1; val[o] = T(1); ++o; }
+    if (j < Ny - 1) { row[o] = k; col[o] = k + Nx; val[o] = T(1); ++o; }
+  }
+}
+
+// ---- order-preserving compaction (remove self loops) ---------------------------------------------
+constexpr int CMP_ITEMS = 4;
+constexpr int CMP_TILE = GLA_BLOCK * CMP_ITEMS;
+
+__global__ __launch_bounds__(GLA_BLOCK) void compact_count_kernel(const int64_t* __restrict__ row,
+                                                                   const int64_t* __restrict__ col, int64_t nnz,
+                                                                   int64_t* __restrict__ block_count) {
+  __shared__ int wsum[GLA_BLOCK / 64];
+  const int64_t base = (int64_t)blockIdx.x * CMP_TILE;
+  int c = 0;
+  // blocked layout: thread t owns elements [base + t*ITEMS, base + (t+1)*ITEMS) so ranks are ordered
+#pragma unroll
+  for (int u = 0; u < CMP_ITEMS; ++u) {
+    const int64_t e = base + (int64_t)threadIdx.x * CMP_ITEMS + u;
+    if (e < nnz && row[e] != col[e]) ++c;
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < GLA_BLOCK / 64; ++w) tot += wsum[w];
+    block_count[blockIdx.x] = tot;
+  }
+}
+
+// exclusive scan of block counts in place (single workgroup, sequential over chunks)
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int64_t* __restrict__ block_count, int64_t nblocks,
+                                                            int64_t* __restrict__ total) {
+  __shared__ int64_t buf[1024];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nblocks; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int64_t v = (i < nblocks) ? block_count[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      int64_t add = (threadIdx.x >= (unsigned)off) ? buf[threadIdx.x - off] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nblocks) block_count[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void compact_apply_kernel(const int64_t* __restrict__ row,
+                                                                  const int64_t* __restrict__ col,
+                                                                  const T* __restrict__ val, int64_t val_stride,
+                                                                  int64_t nnz, const int64_t* __restrict__ block_off,
+                                                                  int64_t* __restrict__ row_out,
+                                                                  int64_t* __restrict__ col_out, T* __restrict__ val_out) {
+  __shared__ int tsum[GLA_BLOCK];
+  const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+  int keep[CMP_ITEMS];
+  int c = 0;
+#pragma unroll
+  for (int u = 0; u < CMP_ITEMS; ++u) {
+    const int64_t e = base + u;
+    keep[u] = (e < nnz && row[e] != col[e]) ? 1 : 0;
+    c += keep[u];
+  }
+  tsum[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < GLA_BLOCK; off <<= 1) {       // inclusive Hillis-Steele scan over the block
+    int add = (threadIdx.x >= (unsigned)off) ? tsum[threadIdx.x - off] : 0;
+    __syncthreads();
+    tsum[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int64_t o = block_off[blockIdx.x] + tsum[threadIdx.x] - c;
+#pragma unroll
+  for (int u = 0; u < CMP_ITEMS; ++u) {
+    if (keep[u]) {
+      const int64_t e = base + u;
+      row_out[o] = row[e];
+      col_out[o] = col[e];
+      if (val) val_out[o] = val[e * val_stride];
+      ++o;
+    }
+  }
+}
+
+inline unsigned grid_for(int64_t work, int64_t per_block = GLA_BLOCK, int64_t cap = 256 * 16) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+int gla_sort_rows_stable(int64_t nnz, int64_t n_rows, const int64_t* row, int32_t* perm_out, uint32_t* keys_sorted,
+                         hipStream_t st) {
+  uint32_t* keys_in = nullptr;
+  int32_t* ids_in = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int rc = GLA_OK;
+  hipError_t e;
+  unsigned end_bit = 1;
+  while (end_bit < 32 && ((int64_t)1 << end_bit) < n_rows) ++end_bit;
+  if ((e = hipMalloc(&keys_in, nnz * sizeof(uint32_t))) != hipSuccess) { rc = -(1000 + (int)e); goto done; }
+  if ((e = hipMalloc(&ids_in, nnz * sizeof(int32_t))) != hipSuccess) { rc = -(1000 + (int)e); goto done; }
+  hipLaunchKernelGGL(keys_kernel, dim3(grid_for(nnz)), dim3(GLA_BLOCK), 0, st, row, nnz, keys_in, ids_in);
+  e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_sorted, ids_in, perm_out, (size_t)nnz, 0u,
+                                end_bit, st);
+  if (e != hipSuccess) { rc = -(1000 + (int)e); goto done; }
+  if ((e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16)) != hipSuccess) { rc = -(1000 + (int)e); goto done; }
+  e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_sorted, ids_in, perm_out, (size_t)nnz, 0u, end_bit,
+                                st);
+  if (e != hipSuccess) { rc = -(1000 + (int)e); goto done; }
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) rc = -(1000 + (int)e);
+done:
+  if (keys_in) (void)hipFree(keys_in);
+  if (ids_in) (void)hipFree(ids_in);
+  if (tmp) (void)hipFree(tmp);
+  return rc;
+}
+
+extern "C" {
+
+int gla_version(void) { return 100; }
+
+const char* gla_error_string(int code) {
+  switch (code) {
+    case GLA_OK: return "ok";
+    case GLA_ERR_INVALID_ARG: return "invalid argument";
+    case GLA_ERR_INDEX_RANGE: return "edge index out of range";
+    case GLA_ERR_TOO_LARGE: return "problem exceeds int32 CSR index range";
+    case GLA_ERR_NO_VALUES: return "plan holds no values of the requested dtype";
+    case GLA_ERR_UNSUPPORTED: return "unsupported configuration";
+    case GLA_ERR_NO_DEVICE: return "no HIP device";
+    default:
+      if (code <= -1000) return hipGetErrorString((hipError_t)(-code - 1000));
+      return "unknown error";
+  }
+}
+
+int gla_csr_destroy(gla_csr_t p) {
+  if (!p) return GLA_OK;
+  if (p->rowptr) (void)hipFree(p->rowptr);
+  if (p->col) (void)hipFree(p->col);
+  if (p->perm) (void)hipFree(p->perm);
+  if (p->val) (void)hipFree(p->val);
+  if (p->tile_row) (void)hipFree(p->tile_row);
+  if (p->tile_lists) (void)hipFree(p->tile_lists);
+  delete p;
+  return GLA_OK;
+}
+
+int gla_csr_create_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col,
+                            gla_stream_t stream, gla_csr_t* out) {
+  if (!out || n_rows < 0 || n_cols < 0 || nnz < 0 || (nnz > 0 && (!row || !col))) return GLA_ERR_INVALID_ARG;
+  if (nnz > 0 && (n_rows == 0 || n_cols == 0)) return GLA_ERR_INDEX_RANGE;
+  if (nnz >= (int64_t)INT32_MAX - GLA_PAD || n_rows >= INT32_MAX || n_cols >= INT32_MAX) return GLA_ERR_TOO_LARGE;
+  hipStream_t st = (hipStream_t)stream;
+  *out = nullptr;
+  gla_csr* p = new gla_csr();
+  p->n_rows = n_rows; p->n_cols = n_cols; p->nnz = nnz;
+  int* d_flags = nullptr;                 // [0] validation flags, [1] max row length
+  int h_flags[2] = {0, 0};
+  uint32_t* keys_sorted = nullptr;
+  int rc = GLA_OK;
+  hipError_t e;
+#define PLAN_CHECK(expr) do { e = (expr); if (e != hipSuccess) { rc = -(1000 + (int)e); goto fail; } } while (0)
+  PLAN_CHECK(hipMalloc(&d_flags, 2 * sizeof(int)));
+  PLAN_CHECK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st));
+  PLAN_CHECK(hipMalloc(&p->rowptr, (n_rows + 1) * sizeof(int32_t)));
+  PLAN_CHECK(hipMalloc(&p->col, (nnz + GLA_PAD) * sizeof(int32_t)));
+  PLAN_CHECK(hipMalloc(&p->val, (nnz + GLA_PAD) * sizeof(double)));
+  if (nnz > 0) {
+    hipLaunchKernelGGL(validate_kernel, dim3(grid_for(nnz)), dim3(GLA_BLOCK), 0, st, row, col, nnz, n_rows, n_cols,
+                       d_flags);
+    PLAN_CHECK(hipGetLastError());
+  }
+  PLAN_CHECK(hipMemcpyAsync(h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+  PLAN_CHECK(hipStreamSynchronize(st));
+  if (h_flags[0] & FLAG_RANGE) { rc = GLA_ERR_INDEX_RANGE; goto fail; }
+  p->sorted_input = (h_flags[0] & FLAG_UNSORTED) ? 0 : 1;
+  if (!p->sorted_input) {
+    PLAN_CHECK(hipMalloc(&p->perm, nnz * sizeof(int32_t)));
+    PLAN_CHECK(hipMalloc(&keys_sorted, nnz * sizeof(uint32_t)));
+    rc = gla_sort_rows_stable(nnz, n_rows, row, p->perm, keys_sorted, st);
+    if (rc) goto fail;
+    hipLaunchKernelGGL((rowptr_kernel<uint32_t>), dim3(grid_for(nnz + 1)), dim3(GLA_BLOCK), 0, st, keys_sorted, nnz,
+                       n_rows, p->rowptr);
+  } else {
+    hipLaunchKernelGGL((rowptr_kernel<int64_t>), dim3(grid_for(nnz + 1)), dim3(GLA_BLOCK), 0, st, row, nnz, n_rows,
+                       p->rowptr);
+  }
+  PLAN_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(gather_col_kernel, dim3(grid_for(nnz + GLA_PAD)), dim3(GLA_BLOCK), 0, st, col, p->perm, nnz,
+                     p->col);
+  PLAN_CHECK(hipGetLastError());
+  if (n_rows > 0) {
+    hipLaunchKernelGGL(max_row_len_kernel, dim3(grid_for(n_rows)), dim3(GLA_BLOCK), 0, st, p->rowptr, n_rows,
+                       d_flags + 1);
+    PLAN_CHECK(hipGetLastError());
+  }
+  PLAN_CHECK(hipMemcpyAsync(h_flags + 1, d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+  PLAN_CHECK(hipStreamSynchronize(st));
+  p->max_row_len = h_flags[1];
+  {
+    // CSR-stream binning: ~256 rows per tile for the average row, bounded by the LDS tile.
+    const double avg = n_rows > 0 ? (double)nnz / (double)n_rows : 0.0;
+    int64_t target = (int64_t)(GLA_BLOCK * (avg < 1.0 ? 1.0 : avg) + 0.5);
+    if (target < GLA_TILE_NNZ_MIN) target = GLA_TILE_NNZ_MIN;
+    p->long_rows = (p->max_row_len > GLA_LDS_ELEMS_MAX - GLA_TILE_NNZ_MIN) ? 1 : 0;
+    if (!p->long_rows && target > GLA_LDS_ELEMS_MAX - p->max_row_len) target = GLA_LDS_ELEMS_MAX - p->max_row_len;
+    p->tile_nnz = (int32_t)target;
+    p->lds_elems = p->long_rows ? 0 : (int32_t)(target + p->max_row_len);
+    int64_t nt = (nnz + target - 1) / target;
+    if (nt < 1) nt = 1;
+    p->n_tiles = (int32_t)nt;
+    PLAN_CHECK(hipMalloc(&p->tile_row, (nt + 1) * sizeof(int32_t)));
+    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((nt + 1 + GLA_BLOCK - 1) / GLA_BLOCK)), dim3(GLA_BLOCK), 0,
+                       st, p->rowptr, n_rows, p->n_tiles, p->tile_nnz, p->tile_row);
+    PLAN_CHECK(hipGetLastError());
+  }
+  PLAN_CHECK(hipStreamSynchronize(st));
+  (void)hipFree(d_flags);
+  if (keys_sorted) (void)hipFree(keys_sorted);
+  *out = p;
+  return GLA_OK;
+fail:
+  if (d_flags) (void)hipFree(d_flags);
+  if (keys_sorted) (void)hipFree(keys_sorted);
+  gla_csr_destroy(p);
+  return rc;
+#undef PLAN_CHECK
+}
+
+int gla_csr_set_values(gla_csr_t p, const void* edge_val, int64_t stride, int dtype, gla_stream_t stream) {
+  if (!p || (dtype != GLA_F32 && dtype != GLA_F64) || stride < 1 || (p->nnz > 0 && !edge_val))
+    return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GLA_F64)
+    hipLaunchKernelGGL((gather_val_kernel<double>), dim3(grid_for(p->nnz + GLA_PAD)), dim3(GLA_BLOCK), 0, st,
+                       (const double*)edge_val, stride, p->perm, p->nnz, (double*)p->val);
+  else
+    hipLaunchKernelGGL((gather_val_kernel<float>), dim3(grid_for(p->nnz + GLA_PAD)), dim3(GLA_BLOCK), 0, st,
+                       (const float*)edge_val, stride, p->perm, p->nnz, (float*)p->val);
+  GLA_LAUNCH_CHECK();
+  p->val_dtype = dtype;
+  return GLA_OK;
+}
+
+int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
+  if (!p || !info) return GLA_ERR_INVALID_ARG;
+  info->n_rows = p->n_rows; info->n_cols = p->n_cols; info->nnz = p->nnz;
+  info->sorted_input = p->sorted_input; info->max_row_len = p->max_row_len;
+  info->n_tiles = p->n_tiles; info->tile_nnz = p->tile_nnz; info->lds_elems = p->lds_elems;
+  info->long_rows = p->long_rows; info->val_dtype = p->val_dtype;
+  return GLA_OK;
+}
+
+__global__ __launch_bounds__(GLA_BLOCK) static void iota_kernel(int32_t* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GLA_BLOCK)
+    out[i] = (int32_t)i;
+}
+
+int gla_csr_export(gla_csr_t p, int32_t* rowptr_out, int32_t* col_out, int32_t* perm_out, gla_stream_t stream) {
+  if (!p) return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (rowptr_out)
+    GLA_HIP_CHECK(hipMemcpyAsync(rowptr_out, p->rowptr, (p->n_rows + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  if (col_out && p->nnz)
+    GLA_HIP_CHECK(hipMemcpyAsync(col_out, p->col, p->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  if (perm_out && p->nnz) {
+    if (p->perm)
+      GLA_HIP_CHECK(hipMemcpyAsync(perm_out, p->perm, p->nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    else {
+      hipLaunchKernelGGL(iota_kernel, dim3(grid_for(p->nnz)), dim3(GLA_BLOCK), 0, st, perm_out, p->nnz);
+      GLA_LAUNCH_CHECK();
+    }
+  }
+  return GLA_OK;
+}
+
+int gla_csr_classify_tiles(gla_csr_t p, int64_t col_limit, gla_stream_t stream, int32_t* n_interior,
+                           int32_t* n_boundary) {
+  if (!p || col_limit < 0) return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nt = p->n_tiles;
+  if (!p->tile_lists) GLA_HIP_CHECK(hipMalloc(&p->tile_lists, 2 * (size_t)nt * sizeof(int32_t)));
+  int32_t* d_flag = nullptr;
+  GLA_HIP_CHECK(hipMalloc(&d_flag, nt * sizeof(int32_t)));
+  GLA_HIP_CHECK(hipMemsetAsync(d_flag, 0, nt * sizeof(int32_t), st));
+  if (!p->long_rows && p->n_rows > 0) {
+    const int32_t lim = (int32_t)(col_limit > INT32_MAX ? INT32_MAX : col_limit);
+    hipLaunchKernelGGL(tile_flag_kernel, dim3(nt), dim3(GLA_BLOCK), 0, st, p->rowptr, p->col, p->tile_row, nt, lim,
+                       d_flag);
+  }
+  int32_t* h_flag = new int32_t[nt];
+  hipError_t e = hipMemcpyAsync(h_flag, d_flag, nt * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  int rc = GLA_OK;
+  if (e != hipSuccess) rc = -(1000 + (int)e);
+  else {
+    int32_t* h_list = new int32_t[2 * (size_t)nt];
+    int ni = 0, nb = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (h_flag[t]) h_list[nt + nb++] = t; else h_list[ni++] = t;
+    }
+    e = hipMemcpyAsync(p->tile_lists, h_list, 2 * (size_t)nt * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = -(1000 + (int)e);
+    delete[] h_list;
+    p->n_interior = ni; p->n_boundary = nb;
+    if (n_interior) *n_interior = ni;
+    if (n_boundary) *n_boundary = nb;
+  }
+  delete[] h_flag;
+  (void)hipFree(d_flag);
+  return rc;
+}
+
+// ---- builders --------------------------------------------------------------------------------
+int64_t gla_laplacian2d_nnz(int64_t Nx, int64_t Ny, int64_t row_lo, int64_t row_hi) {
+  if (Nx < 1 || Ny < 1 || row_lo < 0 || row_hi > Nx * Ny || row_lo > row_hi) return -1;
+  return lap_offset(row_hi, Nx, Ny) - lap_offset(row_lo, Nx, Ny);
+}
+
+int gla_laplacian2d_coo(int64_t Nx, int64_t Ny, int64_t row_lo, int64_t row_hi, int64_t* row, int64_t* col,
+                        void* val, int dtype, gla_stream_t stream) {
+  if (Nx < 1 || Ny < 1 || row_lo < 0 || row_hi > Nx * Ny || row_lo > row_hi || !row || !col || !val ||
+      (dtype != GLA_F32 && dtype != GLA_F64))
+    return GLA_ERR_INVALID_ARG;
+  if (row_lo == row_hi) return GLA_OK;
+  const int64_t base = lap_offset(row_lo, Nx, Ny);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GLA_F64)
+    hipLaunchKernelGGL((laplacian2d_kernel<double>), dim3(grid_for(row_hi - row_lo)), dim3(GLA_BLOCK), 0, st, Nx, Ny,
+                       row_lo, row_hi, base, row, col, (double*)val);
+  else
+    hipLaunchKernelGGL((laplacian2d_kernel<float>), dim3(grid_for(row_hi - row_lo)), dim3(GLA_BLOCK), 0, st, Nx, Ny,
+                       row_lo, row_hi, base, row, col, (float*)val);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+int64_t gla_compact_work_bytes(int64_t nnz) {
+  const int64_t nb = (nnz + CMP_TILE - 1) / CMP_TILE;
+  return (nb + 2) * (int64_t)sizeof(int64_t);
+}
+
+int gla_remove_diag_count(int64_t nnz, const int64_t* row, const int64_t* col, void* work, int64_t* kept_host,
+                          gla_stream_t stream) {
+  if (nnz < 0 || !work || !kept_host || (nnz > 0 && (!row || !col))) return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = (nnz + CMP_TILE - 1) / CMP_TILE;
+  int64_t* w = (int64_t*)work;            // [0..nb) block offsets, [nb] total
+  if (nb > 0) {
+    hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nb), dim3(GLA_BLOCK), 0, st, row, col, nnz, w);
+    GLA_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, w, nb, w + nb);
+  GLA_LAUNCH_CHECK();
+  GLA_HIP_CHECK(hipMemcpyAsync(kept_host, w + nb, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  GLA_HIP_CHECK(hipStreamSynchronize(st));
+  return GLA_OK;
+}
+
+int gla_remove_diag_apply(int64_t nnz, const int64_t* row, const int64_t* col, const void* val, int64_t val_stride,
+                          int dtype, const void* work, int64_t* row_out, int64_t* col_out, void* val_out,
+                          gla_stream_t stream) {
+  if (nnz < 0 || !work || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  if (nnz == 0) return GLA_OK;
+  if (!row || !col || !row_out || !col_out || (val && (!val_out || val_stride < 1))) return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = (nnz + CMP_TILE - 1) / CMP_TILE;
+  if (dtype == GLA_F64)
+    hipLaunchKernelGGL((compact_apply_kernel<double>), dim3((unsigned)nb), dim3(GLA_BLOCK), 0, st, row, col,
+                       (const double*)val, val_stride, nnz, (const int64_t*)work, row_out, col_out, (double*)val_out);
+  else
+    hipLaunchKernelGGL((compact_apply_kernel<float>), dim3((unsigned)nb), dim3(GLA_BLOCK), 0, st, row, col,
+                       (const float*)val, val_stride, nnz, (const int64_t*)work, row_out, col_out, (float*)val_out);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+"""MetaLayer: the graph-network block runner the reference takes from PyTorch-Geometric.
+
+`MetaLayer(edge_model, node_model, global_model)(x, edge_index, edge_attr, u, batch)` keeps PyG's contract
+(edge -> node -> global; returns (x, edge_attr, u)).  When the three models form one of the reference's
+linear-algebra blocks (they carry a `gla_block` tag), the whole layer runs as fused libgla_hip kernels on the
+CSR plan of `edge_index`; any other combination of user modules runs the generic gather/callback sequence
+(x[row], x[col] gathers with torch indexing on the operands' device), which is PyG's semantics, not a hot path.
+"""
+import torch
+
+
+class MetaLayer(torch.nn.Module):
+    def __init__(self, edge_model=None, node_model=None, global_model=None):
+        super().__init__()
+        self.edge_model = edge_model
+        self.node_model = node_model
+        self.global_model = global_model
+
+    def _fused(self):
+        tags = tuple(getattr(m, "gla_block", None) if m is not None else None
+                     for m in (self.edge_model, self.node_model, self.global_model))
+        return _FUSED.get(tags)
+
+    def forward(self, x, edge_index, edge_attr=None, u=None, batch=None):
+        fused = self._fused()
+        if fused is not None:
+            return fused(self, x, edge_index, edge_attr, u, batch)
+        row, col = edge_index[0], edge_index[1]
+        if self.edge_model is not None:
+            edge_attr = self.edge_model(x[row], x[col], edge_attr, u, batch if batch is None else batch[row])
+        if self.node_model is not None:
+            x = self.node_model(x, edge_index, edge_attr, u, batch)
+        if self.global_model is not None:
+            u = self.global_model(x, edge_index, edge_attr, u, batch)
+        return x, edge_attr, u
+
+
+_FUSED = {}
+
+
+def register_fused(edge_tag, node_tag, global_tag, fn):
+    _FUSED[(edge_tag, node_tag, global_tag)] = fn

@@ -1,0 +1,274 @@
+"""CsrPlan: Python handle of a libgla_hip CSR plan + shape-checked wrappers of the C-ABI hot-path calls.
+
+A plan is the once-per-graph replacement for what `torch_scatter.scatter(src, edgeij_pair[0], ...)`
+re-derives on every layer call in the reference: the row structure of the COO edge list.
+Plans are cached on the edge-index tensor (see `plan_for`) so that the nn.Module surface, which receives
+`edgeij_pair` / `edge_attr` on every forward like the reference's, only pays for the conversion once.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import check, dtype_code, lib, ptr, stream_ptr
+
+ALL_TILES, INTERIOR_TILES, BOUNDARY_TILES = 0, 1, 2
+
+
+def _dense(t, rows, name):
+    """Validate a row-major [rows, K] (or [rows]) GPU operand; return (2-D view, K, leading dimension)."""
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor")
+    if t.dim() == 1:
+        t = t.unsqueeze(1)
+    if t.dim() != 2 or t.shape[0] != rows:
+        raise ValueError(f"{name} must have shape [{rows}, K], got {tuple(t.shape)}")
+    K = t.shape[1]
+    if K < 1:
+        raise ValueError(f"{name} needs at least one column")
+    if K > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name} must be row-major (unit stride along K)")
+    ld = t.stride(0) if rows > 1 else K
+    if ld < K:
+        raise ValueError(f"{name}: leading dimension {ld} < K={K}")
+    return t, K, ld
+
+
+class CsrPlan:
+    """Owns a gla_csr_t.  Not copyable; freed on garbage collection."""
+
+    def __init__(self, edgeij_pair, n_rows, n_cols=None):
+        _lib.require_gpu()
+        if edgeij_pair.dim() != 2 or edgeij_pair.shape[0] != 2:
+            raise ValueError(f"edgeij_pair must be [2, nnz], got {tuple(edgeij_pair.shape)}")
+        if edgeij_pair.dtype != torch.int64:
+            raise TypeError("edgeij_pair must be int64 (torch.long), as in the reference")
+        if not edgeij_pair.is_cuda:
+            raise ValueError("edgeij_pair must be a GPU tensor")
+        ei = edgeij_pair.contiguous()
+        n_cols = n_rows if n_cols is None else n_cols
+        self.device = ei.device
+        self.n_rows, self.n_cols, self.nnz = int(n_rows), int(n_cols), int(ei.shape[1])
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().gla_csr_create_from_coo(self.n_rows, self.n_cols, self.nnz, ptr(ei[0]), ptr(ei[1]),
+                                                stream_ptr(self.device), ctypes.byref(self._h)))
+        info = _lib.CsrInfo()
+        check(lib().gla_csr_info(self._h, ctypes.byref(info)))
+        self.info = info
+        self.sorted_input = bool(info.sorted_input)
+        self.val_dtype = None
+        self._val_key = None
+        self._val_ref = None
+        self.n_interior = self.n_boundary = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and _lib._lib is not None:
+            _lib._lib.gla_csr_destroy(h)
+            self._h = None
+
+    # ---- values ---------------------------------------------------------------------------------
+    def set_values(self, edge_val):
+        """edge_val: [nnz] or [nnz, n_e] (column 0 holds A_ij, as in the reference's edge_attr)."""
+        if edge_val.shape[0] != self.nnz:
+            raise ValueError(f"edge values have {edge_val.shape[0]} rows, plan has {self.nnz} edges")
+        if not edge_val.is_cuda:
+            raise ValueError("edge values must be a GPU tensor")
+        stride = edge_val.stride(0) if edge_val.dim() > 1 or self.nnz > 1 else 1
+        if edge_val.dim() == 2 and edge_val.shape[1] > 1 and edge_val.stride(1) != 1:
+            edge_val = edge_val[:, 0].contiguous()
+            stride = 1
+        check(lib().gla_csr_set_values(self._h, ptr(edge_val), max(int(stride), 1), dtype_code(edge_val.dtype),
+                                       stream_ptr(self.device)))
+        self.val_dtype = edge_val.dtype
+
+    def set_values_cached(self, edge_attr):
+        """Refresh the CSR-ordered values unless `edge_attr` is the very tensor object they were gathered from
+        and it has not been written since (identity via weakref: a data_ptr alone can be recycled by the
+        allocator for a different tensor)."""
+        key = (edge_attr._version, tuple(edge_attr.shape), tuple(edge_attr.stride()), edge_attr.dtype)
+        ref = self._val_ref() if self._val_ref is not None else None
+        if ref is not edge_attr or key != self._val_key:
+            self.set_values(edge_attr)
+            self._val_key = key
+            self._val_ref = weakref.ref(edge_attr)
+
+    def arrays(self):
+        """(rowptr, col, perm) as int32 GPU tensors -- for the CSR-indexing parity tests."""
+        rowptr = torch.empty(self.n_rows + 1, dtype=torch.int32, device=self.device)
+        col = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+        perm = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+        check(lib().gla_csr_export(self._h, ptr(rowptr), ptr(col), ptr(perm), stream_ptr(self.device)))
+        return rowptr, col, perm
+
+    def classify_tiles(self, col_limit):
+        ni, nb = ctypes.c_int32(), ctypes.c_int32()
+        check(lib().gla_csr_classify_tiles(self._h, int(col_limit), stream_ptr(self.device), ctypes.byref(ni),
+                                           ctypes.byref(nb)))
+        self.n_interior, self.n_boundary = ni.value, nb.value
+        return ni.value, nb.value
+
+    # ---- hot path -------------------------------------------------------------------------------
+    def _need(self, dtype):
+        if self.nnz and self.val_dtype != dtype:
+            raise _lib.GlaError(f"plan holds values of dtype {self.val_dtype}, operands are {dtype}")
+
+    def spmm(self, X, out=None, which=ALL_TILES):
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        self._need(X.dtype)
+        Y = torch.empty((self.n_rows, K), dtype=X.dtype, device=self.device) if out is None else out
+        Y, Ky, ldy = _dense(Y, self.n_rows, "Y")
+        assert Ky == K and Y.dtype == X.dtype
+        check(lib().gla_spmm(self._h, dtype_code(X.dtype), K, ptr(X), ldx, ptr(Y), ldy, which,
+                             stream_ptr(self.device)))
+        return Y
+
+    def residual(self, B, X, out=None, which=ALL_TILES):
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        B, Kb, ldb = _dense(B, self.n_rows, "B")
+        self._need(X.dtype)
+        R = torch.empty((self.n_rows, K), dtype=X.dtype, device=self.device) if out is None else out
+        R, Kr, ldr = _dense(R, self.n_rows, "R")
+        assert Kb == K and Kr == K and B.dtype == X.dtype == R.dtype
+        check(lib().gla_residual(self._h, dtype_code(X.dtype), K, ptr(B), ldb, ptr(X), ldx, ptr(R), ldr, which,
+                                 stream_ptr(self.device)))
+        return R
+
+    def jacobi_sweep(self, diag, B, X, Xout, w, which=ALL_TILES):
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        B, Kb, ldb = _dense(B, self.n_rows, "B")
+        Xout, Ko, ldxo = _dense(Xout, self.n_rows, "Xout")
+        self._need(X.dtype)
+        assert diag.numel() == self.n_rows and diag.is_contiguous() and diag.is_cuda
+        assert Kb == K and Ko == K and B.dtype == X.dtype == Xout.dtype == diag.dtype
+        assert X.data_ptr() != Xout.data_ptr()
+        check(lib().gla_jacobi_sweep(self._h, dtype_code(X.dtype), K, ptr(diag), ptr(B), ldb, ptr(X), ldx,
+                                     ptr(Xout), ldxo, float(w), which, stream_ptr(self.device)))
+        return Xout
+
+    def jacobi_sweeps(self, diag, B, X0, w, n_iters):
+        """n_iters fused sweeps; returns a new [n, K] tensor, X0 untouched (JacobiGNN.py:138-148)."""
+        assert self.n_rows == self.n_cols
+        X0, K, ldx0 = _dense(X0, self.n_cols, "X0")
+        B, Kb, ldb = _dense(B, self.n_rows, "B")
+        self._need(X0.dtype)
+        assert diag.numel() == self.n_rows and diag.is_contiguous() and diag.is_cuda
+        assert Kb == K and B.dtype == X0.dtype == diag.dtype
+        if n_iters <= 0:
+            return X0.clone()
+        Xout = torch.empty((self.n_rows, K), dtype=X0.dtype, device=self.device)
+        Xtmp = torch.empty_like(Xout) if n_iters > 1 else None
+        check(lib().gla_jacobi_sweeps(self._h, dtype_code(X0.dtype), K, ptr(diag), ptr(B), ldb, ptr(X0), ldx0,
+                                      ptr(Xout), ptr(Xtmp), K, float(w), int(n_iters), stream_ptr(self.device)))
+        return Xout
+
+    def cheby_first(self, B, X, R, P, Xout, alpha, which=ALL_TILES):
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        B, _, ldb = _dense(B, self.n_rows, "B")
+        R, _, ldr = _dense(R, self.n_rows, "R")
+        P, _, ldp = _dense(P, self.n_rows, "P")
+        Xout, _, ldxo = _dense(Xout, self.n_rows, "Xout")
+        self._need(X.dtype)
+        assert B.shape[1] == R.shape[1] == P.shape[1] == Xout.shape[1] == K
+        assert B.dtype == R.dtype == P.dtype == Xout.dtype == X.dtype
+        assert X.data_ptr() != Xout.data_ptr()
+        check(lib().gla_cheby_first(self._h, dtype_code(X.dtype), K, ptr(B), ldb, ptr(X), ldx, ptr(R), ldr, ptr(P),
+                                    ldp, ptr(Xout), ldxo, float(alpha), which, stream_ptr(self.device)))
+
+    def cheby_next(self, P, Pout, R, X, alpha_old, alpha_new, beta, which=ALL_TILES):
+        P, K, ldp = _dense(P, self.n_cols, "P")
+        Pout, _, ldpo = _dense(Pout, self.n_rows, "Pout")
+        R, _, ldr = _dense(R, self.n_rows, "R")
+        X, _, ldx = _dense(X, self.n_rows, "X")
+        self._need(P.dtype)
+        assert Pout.shape[1] == R.shape[1] == X.shape[1] == K
+        assert Pout.dtype == R.dtype == X.dtype == P.dtype
+        assert P.data_ptr() != Pout.data_ptr()
+        check(lib().gla_cheby_next(self._h, dtype_code(P.dtype), K, ptr(P), ldp, ptr(Pout), ldpo, ptr(R), ldr,
+                                   ptr(X), ldx, float(alpha_old), float(alpha_new), float(beta), which,
+                                   stream_ptr(self.device)))
+
+    def edge_products(self, X):
+        """c_e = A_e * X[col_e] in EDGE order, [nnz, K]."""
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        self._need(X.dtype)
+        C = torch.empty((self.nnz, K), dtype=X.dtype, device=self.device)
+        check(lib().gla_edge_products(self._h, dtype_code(X.dtype), K, ptr(X), ldx, ptr(C), K,
+                                      stream_ptr(self.device)))
+        return C
+
+    def soc_classic(self, theta, dtype):
+        self._need(dtype)
+        v = torch.empty((self.n_rows, 1), dtype=dtype, device=self.device)
+        S = torch.empty((self.nnz,), dtype=dtype, device=self.device)
+        check(lib().gla_soc_classic(self._h, dtype_code(dtype), float(theta), ptr(v), ptr(S),
+                                    stream_ptr(self.device)))
+        return v, S
+
+    def direct_interp(self, diag, cf, S, want_alpha=False):
+        dtype = diag.dtype
+        self._need(dtype)
+        for name, t, n in (("diag", diag, self.n_rows), ("cf", cf, self.n_rows), ("S", S, self.nnz)):
+            if t.numel() != n or not t.is_contiguous() or t.dtype != dtype or not t.is_cuda:
+                raise ValueError(f"{name} must be a contiguous {dtype} GPU vector of {n} elements")
+        w = torch.empty((self.nnz,), dtype=dtype, device=self.device)
+        alpha = torch.empty((self.n_rows,), dtype=dtype, device=self.device) if want_alpha else None
+        check(lib().gla_direct_interp(self._h, dtype_code(dtype), ptr(diag), ptr(cf), ptr(S), ptr(w), ptr(alpha),
+                                      stream_ptr(self.device)))
+        return (w, alpha) if want_alpha else w
+
+    def soc_sa(self, diag):
+        dtype = diag.dtype
+        self._need(dtype)
+        if diag.numel() != self.n_rows or not diag.is_contiguous() or not diag.is_cuda:
+            raise ValueError("diag must be a contiguous GPU vector of n_rows elements")
+        S = torch.empty((self.nnz,), dtype=dtype, device=self.device)
+        check(lib().gla_soc_sa(self._h, dtype_code(dtype), ptr(diag), ptr(S), stream_ptr(self.device)))
+        return S
+
+
+# ---- dense helpers ------------------------------------------------------------------------------
+def col_dot(X, Y):
+    """Column sums of X .* Y -> [K] on the device (PowerMethodGNN.py:50-61 vertex_to_global_aggregation)."""
+    n = X.shape[0]
+    X, K, ldx = _dense(X, n, "X")
+    Y, Ky, ldy = _dense(Y, n, "Y")
+    assert K == Ky and X.dtype == Y.dtype
+    code = dtype_code(X.dtype)
+    work = torch.empty(lib().gla_dot_work_bytes(n, K, code), dtype=torch.uint8, device=X.device)
+    out = torch.empty(K, dtype=X.dtype, device=X.device)
+    check(lib().gla_col_dot(code, n, K, ptr(X), ldx, ptr(Y), ldy, ptr(out), ptr(work), stream_ptr(X.device)))
+    return out
+
+
+def col_scale_rsqrt(X, sumsq):
+    """X[:, k] / sqrt(sumsq[k]) (PowerMethodGNN.py:160-207)."""
+    n = X.shape[0]
+    X, K, ldx = _dense(X, n, "X")
+    assert sumsq.numel() == K and sumsq.dtype == X.dtype and sumsq.is_cuda
+    Y = torch.empty((n, K), dtype=X.dtype, device=X.device)
+    check(lib().gla_col_scale_rsqrt(dtype_code(X.dtype), n, K, ptr(X), ldx, ptr(sumsq), ptr(Y), K,
+                                    stream_ptr(X.device)))
+    return Y
+
+
+# ---- plan cache ---------------------------------------------------------------------------------
+def plan_for(edgeij_pair, n_rows, n_cols=None, edge_attr=None):
+    """Plan cached on the edge-index tensor object itself (lifetime = the tensor's); rebuilt if the tensor
+    was modified in place (version counter) or is used with another shape."""
+    n_cols = n_rows if n_cols is None else n_cols
+    key = (edgeij_pair.data_ptr(), edgeij_pair._version, tuple(edgeij_pair.shape), int(n_rows), int(n_cols))
+    cached = getattr(edgeij_pair, "_gla_plan", None)
+    if cached is None or cached[0] != key:
+        plan = CsrPlan(edgeij_pair, n_rows, n_cols)
+        try:
+            edgeij_pair._gla_plan = (key, plan)
+        except Exception:
+            pass
+    else:
+        plan = cached[1]
+    if edge_attr is not None:
+        plan.set_values_cached(edge_attr)
+    return plan

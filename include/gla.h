@@ -1,0 +1,174 @@
+/*
+ * gla.h -- C ABI of libgla_hip.so: MI355X (gfx950) kernels for the sparse message-passing
+ * hot path of sandialabs/gnn-applied-linear-algebra.
+ *
+ * The reference has no FFI boundary (pure Python).  Its arithmetic lives in two
+ * third-party primitives -- PyG `MetaLayer` (gather x[row], x[col]) and `torch_scatter.scatter`
+ * (segment reduction keyed by edgeij_pair[0]) -- composed by per-algorithm nn.Modules.  Each entry
+ * point below replaces one such composition, i.e. everything between a module's `forward()` and the
+ * tensors it returns; the comment on each names the reference file:line it stands for.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the library never frees or
+ *     keeps caller memory beyond the call (plans copy what they need);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued there, nothing synchronises
+ *     except plan creation (gla_csr_create_from_coo) which returns sizes to the host;
+ *   - dense operands are row-major [rows, K] with a leading dimension in ELEMENTS (ld >= K);
+ *     K is the number of right-hand sides (1 = SpMV);
+ *   - "edge order" = the order of the caller's COO edge list (reference tensors edgeij_pair /
+ *     edge_attr); "CSR order" = stable sort of the edges by row (edge order kept inside a row, so
+ *     in-order row sums equal the reference's sequential scatter-add bit for bit);
+ *   - return value: 0 on success, <0 = GLA_ERR_* below, <= -1000 = -(1000 + hipError_t).
+ *   - inputs are never mutated unless documented (reference modules return new tensors).
+ */
+#ifndef GLA_H
+#define GLA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gla_csr* gla_csr_t;
+typedef void* gla_stream_t;
+
+enum { GLA_F32 = 0, GLA_F64 = 1 };
+
+enum {
+  GLA_OK = 0,
+  GLA_ERR_INVALID_ARG = -1,      /* null pointer, negative size, bad dtype, ld < K ... */
+  GLA_ERR_INDEX_RANGE = -2,      /* an edge index outside [0, n_rows) x [0, n_cols) */
+  GLA_ERR_TOO_LARGE = -3,        /* nnz or n exceeds the int32 CSR index range */
+  GLA_ERR_NO_VALUES = -4,        /* plan has no values of the requested dtype (call gla_csr_set_values) */
+  GLA_ERR_UNSUPPORTED = -5,
+  GLA_ERR_NO_DEVICE = -6
+};
+
+int gla_version(void);
+const char* gla_error_string(int code);
+
+/* ---- plan: COO edge list -> CSR (replaces nothing 1:1; it is the index side of every
+ * `torch_scatter.scatter(src, edgeij_pair[0], dim=0, dim_size=n)` call) ----------- */
+/* row/col: int64 [nnz] (the two rows of the reference's edgeij_pair [2,nnz]).  Stable-sorts by row
+ * when the list is not already row-sorted.  Synchronises `stream` once. */
+int gla_csr_create_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                            const int64_t* row, const int64_t* col,
+                            gla_stream_t stream, gla_csr_t* out);
+int gla_csr_destroy(gla_csr_t plan);
+
+/* Gather edge values into CSR order: val_csr[p] = edge_val[perm[p] * stride] (stride in elements;
+ * the reference keeps A_ij in column 0 of edge_attr [nnz, n_e], so stride = n_e). */
+int gla_csr_set_values(gla_csr_t plan, const void* edge_val, int64_t stride, int dtype, gla_stream_t stream);
+
+typedef struct {
+  int64_t n_rows, n_cols, nnz;
+  int32_t sorted_input;     /* 1: edge order == CSR order (perm is identity, not stored) */
+  int32_t max_row_len;
+  int32_t n_tiles;          /* row tiles of the CSR-stream kernels */
+  int32_t tile_nnz;         /* target nnz per tile */
+  int32_t lds_elems;        /* staged nnz capacity per workgroup */
+  int32_t long_rows;        /* 1: some row exceeds the LDS tile -> CSR-vector kernels are used */
+  int32_t val_dtype;        /* GLA_F32 / GLA_F64 / -1 */
+} gla_csr_info_t;
+int gla_csr_info(gla_csr_t plan, gla_csr_info_t* info_host);
+
+/* Copy the plan's index arrays into caller buffers (for parity tests: CSR indexing must be bit-exact).
+ * rowptr_out int32 [n_rows+1], col_out int32 [nnz], perm_out int32 [nnz] (CSR position -> edge id; written as
+ * the identity when sorted_input); any of them may be NULL. */
+int gla_csr_export(gla_csr_t plan, int32_t* rowptr_out, int32_t* col_out, int32_t* perm_out,
+                   gla_stream_t stream);
+
+/* Restrict later launches to a subset of row tiles (multi-GPU overlap: interior tiles run while the
+ * halo is in flight, boundary tiles after).  which: 0 = all, 1 = tiles whose columns are all < col_limit,
+ * 2 = the others.  gla_csr_classify_tiles builds the two lists once per plan. */
+int gla_csr_classify_tiles(gla_csr_t plan, int64_t col_limit, gla_stream_t stream,
+                           int32_t* n_interior_host, int32_t* n_boundary_host);
+
+/* ---- hot path ----------------------------------------------------------------------------------- */
+/* Y = A X.  MatVecGNN.py:43-114 (EdgeUpdate c=A_ij*x_j :66-84, scatter-sum :60, VertexUpdate :95-114). */
+int gla_spmm(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* Y, int64_t ldy,
+             int which_tiles, gla_stream_t stream);
+
+/* R = B - A X.  GNNResidual.py:43-132 (r_i = b_i - cbar_i, :110). */
+int gla_residual(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, const void* X, int64_t ldx,
+                 void* R, int64_t ldr, int which_tiles, gla_stream_t stream);
+
+/* One weighted-Jacobi sweep, Xout = X + (w*(B - A X))/diag, diag [n_rows] (one per row, shared by the K
+ * columns).  JacobiGNN.py:52-123 (x_i + w*(b_i - cbar_i)/A_ii, :119).  X has n_cols rows (halo included),
+ * Xout/B n_rows. */
+int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb,
+                     const void* X, int64_t ldx, void* Xout, int64_t ldxo, double w,
+                     int which_tiles, gla_stream_t stream);
+
+/* n_iters sweeps ping-ponging between Xout and Xtmp so that the last sweep lands in Xout; X0 is not
+ * mutated.  JacobiGNN.forward, JacobiGNN.py:138-148.  Square plans only. */
+int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb,
+                      const void* X0, int64_t ldx0, void* Xout, void* Xtmp, int64_t ldw, double w,
+                      int n_iters, gla_stream_t stream);
+
+/* Chebyshev, first degree (two MetaLayers fused): R = B - A X; P = R; Xout = X + alpha*R.
+ * ChebyGNN.py:49-163. */
+int gla_cheby_first(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, const void* X, int64_t ldx,
+                    void* R, int64_t ldr, void* P, int64_t ldp, void* Xout, int64_t ldxo, double alpha,
+                    int which_tiles, gla_stream_t stream);
+
+/* Chebyshev, degree >= 2 step (two MetaLayers fused): R -= alpha_old * (A P); Pout = R + beta*P;
+ * X += alpha_new * Pout (X, R updated in place; P is gathered so Pout must not alias it).
+ * ChebyGNN.py:166-243. */
+int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, void* Pout, int64_t ldpo,
+                   void* R, int64_t ldr, void* X, int64_t ldx, double alpha_old, double alpha_new, double beta,
+                   int which_tiles, gla_stream_t stream);
+
+/* Column sums of X .* Y over `n` rows -> out[K] (device, same dtype).  PowerMethodGNN.py:50-61
+ * (torch.sum(vertex_attr[:,1]) with y = b*b :124 or y = b*cbar :233).  `work` needs gla_dot_work_bytes(n,K). */
+int64_t gla_dot_work_bytes(int64_t n, int K, int dtype);
+int gla_col_dot(int dtype, int64_t n, int K, const void* X, int64_t ldx, const void* Y, int64_t ldy,
+                void* out, void* work, gla_stream_t stream);
+
+/* Y[i,k] = X[i,k] / sqrt(sumsq[k]) (op=0, PowerMethodGNN.py:160-207: n = sqrt(ybar); b = b/n)
+ * out[k] = num[k] / den[k] is done by the caller on K scalars. */
+int gla_col_scale_rsqrt(int dtype, int64_t n, int K, const void* X, int64_t ldx, const void* sumsq,
+                        void* Y, int64_t ldy, gla_stream_t stream);
+
+/* Edge products in EDGE order: C[e,k] = A_e * X[col_e,k] -- the `c_ij`/`z_ij` column every EdgeUpdate
+ * returns (e.g. JacobiGNN.py:83-88); materialised only when a caller asks for edge_attr. */
+int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,
+                      gla_stream_t stream);
+
+/* Classical strength of connection on the OFF-DIAGONAL plan: v_i = max_j(-A_ij) (0 for empty rows),
+ * S_e = relu(-A_e / v_row(e) - theta), S in edge order.  SOCClassicGNN.py:50-147. */
+int gla_soc_classic(gla_csr_t A_od, int dtype, double theta, void* v_out, void* S_out, gla_stream_t stream);
+
+/* Direct interpolation on the off-diagonal plan: gamma_i = sum_k A_ik / sum_k (A_ik*S_ik*C_k),
+ * alpha_i = (1/A_ii)*gamma_i, w_e = (1 - C_i) * (-A_e * alpha_i); S, w in edge order, cf/diag [n].
+ * DirectInterpGNN.py:50-174.  alpha_out may be NULL. */
+int gla_direct_interp(gla_csr_t A_od, int dtype, const void* diag, const void* cf, const void* S,
+                      void* w_out, void* alpha_out, gla_stream_t stream);
+
+/* SA strength of connection, S_e = A_e^2 / (A_ii * A_jj) in edge order.  SOCSAGNN.py:49-71. */
+int gla_soc_sa(gla_csr_t A_od, int dtype, const void* diag, void* S_out, gla_stream_t stream);
+
+/* ---- builders ----------------------------------------------------------------------------------- */
+/* 5-point negative Laplacian on an Ny x Nx grid (reference: Ny == Nx == N), COO sorted row-major with
+ * ascending columns: row/col int64 [nnz], val [nnz], nnz = 5*Nx*Ny - 2*Nx - 2*Ny.
+ * UtilsGNN.py:53-67 (laplacianfun_torch).  row_offset shifts vertex ids (row blocks of a larger grid):
+ * rows [row_lo, row_hi) of the global grid are emitted; pass 0, Nx*Ny for the whole matrix. */
+int64_t gla_laplacian2d_nnz(int64_t Nx, int64_t Ny, int64_t row_lo, int64_t row_hi);
+int gla_laplacian2d_coo(int64_t Nx, int64_t Ny, int64_t row_lo, int64_t row_hi,
+                        int64_t* row, int64_t* col, void* val, int dtype, gla_stream_t stream);
+
+/* Order-preserving removal of self loops.  UtilsGNN.py:69-72 (PyG remove_self_loops).
+ * Step 1 returns the kept count (synchronises); step 2 writes the compacted arrays.
+ * `work` needs gla_compact_work_bytes(nnz). */
+int64_t gla_compact_work_bytes(int64_t nnz);
+int gla_remove_diag_count(int64_t nnz, const int64_t* row, const int64_t* col, void* work,
+                          int64_t* kept_host, gla_stream_t stream);
+int gla_remove_diag_apply(int64_t nnz, const int64_t* row, const int64_t* col, const void* val,
+                          int64_t val_stride, int dtype, const void* work,
+                          int64_t* row_out, int64_t* col_out, void* val_out, gla_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLA_H */

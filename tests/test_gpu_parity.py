@@ -1,0 +1,409 @@
+"""GPU parity: the HIP path (through the C ABI, via the nn.Module mirror) against
+  (1) the golden vectors produced by the unmodified reference, BIT-EXACT for every in-order kernel,
+  (2) the CPU oracle (oracle/reference_port.py) on seeded inputs at sizes it finishes in seconds,
+  (3) at BASELINE's full size (4096^2) the oracle for 2 sweeps plus size-independent properties.
+Tolerances: bit-exact for CSR indices, SOC flags and all in-order fp sums (MatVec, Residual, Jacobi, Chebyshev,
+SOC, DI); 1e-12 relative for quantities that pass through a global reduction (power method, weighted norm),
+far inside north_star's 1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_SIZES
+
+pytestmark = pytest.mark.gpu
+
+gla = None
+rp = None
+DEV = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _setup():
+    global gla, rp, DEV
+    import gnn_applied_linear_algebra_amd as _gla
+    import reference_port as _rp
+    assert torch.cuda.is_available()
+    gla, rp, DEV = _gla, _rp, torch.device("cuda:0")
+    yield
+
+
+def t(a, dtype=None):
+    x = torch.from_numpy(np.array(a))
+    return x.to(dtype) if dtype is not None else x
+
+
+def d(x):
+    return x.to(DEV)
+
+
+def eq(got, want):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    np.testing.assert_array_equal(got, want)
+
+
+def close(got, want, rtol=1e-12):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=0)
+
+
+def lap(golden, N, od=False):
+    tag = f"lap{N}_od" if od else f"lap{N}"
+    return t(golden[tag + "_ei"], torch.long), t(golden[tag + "_ev"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# builders + CSR indexing (integer work: bit-exact)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", GOLDEN_SIZES + (64,))
+def test_builders_vs_golden(golden, N):
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    assert ei.dtype == torch.long and ev.dtype == torch.float64 and ev.shape == (5 * N * N - 4 * N, 1)
+    eq(ei, golden[f"lap{N}_ei"])
+    eq(ev, golden[f"lap{N}_ev"])
+    eio, evo = gla.UtilsGNN.remove_diag_entries(ei, ev)
+    eq(eio, golden[f"lap{N}_od_ei"])
+    eq(evo, golden[f"lap{N}_od_ev"])
+
+
+def test_builders_edge_cases():
+    for Nx, Ny in ((1, 1), (1, 5), (5, 1), (2, 3), (7, 4)):
+        ei, ev = gla.UtilsGNN.laplacianfun_torch(Nx, Ny=Ny, device=DEV)
+        ei_c, ev_c = rp.laplacianfun_torch(Nx, Ny)
+        eq(ei, ei_c)
+        eq(ev, ev_c)
+        lo, hi = (Nx * Ny) // 3, (2 * Nx * Ny) // 3 + 1
+        ei_b, ev_b = gla.UtilsGNN.laplacianfun_torch(Nx, Ny=Ny, row_range=(lo, hi), device=DEV)
+        m = (ei_c[0] >= lo) & (ei_c[0] < hi)
+        eq(ei_b, ei_c[:, m])
+        eq(ev_b, ev_c[m])
+    # remove_diag: all-diagonal, none-diagonal, empty
+    ei = torch.tensor([[0, 1, 2], [0, 1, 2]], device=DEV)
+    o_i, o_v = gla.UtilsGNN.remove_diag_entries(ei, torch.ones(3, 1, dtype=torch.float64, device=DEV))
+    assert o_i.shape == (2, 0) and o_v.shape == (0, 1)
+    o_i, o_v = gla.UtilsGNN.remove_diag_entries(ei.flip(0)[:, :0], torch.ones(0, 1, dtype=torch.float64, device=DEV))
+    assert o_i.shape == (2, 0)
+
+
+def test_remove_diag_large_random():
+    gen = torch.Generator().manual_seed(5)
+    nnz, n = 1_000_003, 5000
+    ei = torch.randint(0, n, (2, nnz), generator=gen)
+    ei[1, ::3] = ei[0, ::3]
+    ev = torch.rand(nnz, 1, generator=gen, dtype=torch.float64)
+    o_i, o_v = gla.UtilsGNN.remove_diag_entries(d(ei), d(ev))
+    w_i, w_v = rp.remove_diag_entries(ei, ev)
+    eq(o_i, w_i)
+    eq(o_v, w_v)
+
+
+@pytest.mark.parametrize("N", GOLDEN_SIZES)
+def test_csr_indexing(golden, N):
+    ei, _ = lap(golden, N)
+    perm = t(golden[f"N{N}_perm"], torch.long)
+    for e in (ei, ei[:, perm]):
+        plan = gla.CsrPlan(d(e), N * N)
+        rowptr, col, pm = (a.cpu().numpy() for a in plan.arrays())
+        order = np.argsort(e[0].numpy(), kind="stable")
+        eq(pm, order)
+        eq(col, e[1].numpy()[order])
+        eq(rowptr, np.concatenate([[0], np.cumsum(np.bincount(e[0].numpy(), minlength=N * N))]))
+        assert plan.sorted_input == bool(np.all(np.diff(e[0].numpy()) >= 0))
+
+
+def test_csr_edge_cases():
+    # empty graph, vertices without edges, duplicate edges, out-of-range index
+    plan = gla.CsrPlan(torch.zeros((2, 0), dtype=torch.long, device=DEV), 7)
+    eq(plan.arrays()[0], np.zeros(8))
+    plan.set_values(torch.zeros((0, 1), dtype=torch.float64, device=DEV))
+    y = plan.spmm(torch.ones(7, 1, dtype=torch.float64, device=DEV))
+    eq(y, np.zeros((7, 1)))
+    ei = torch.tensor([[5, 2, 5, 2, 2], [0, 6, 0, 1, 6]])
+    plan = gla.CsrPlan(d(ei), 7)
+    eq(plan.arrays()[0], [0, 0, 0, 3, 3, 3, 5, 5])
+    eq(plan.arrays()[2], [1, 3, 4, 0, 2])
+    plan.set_values(d(torch.tensor([1.0, 2, 4, 8, 16], dtype=torch.float64)))
+    x = torch.arange(1, 8, dtype=torch.float64).reshape(-1, 1)
+    y = plan.spmm(d(x))
+    eq(y, rp.scatter_sum(torch.tensor([1.0, 2, 4, 8, 16], dtype=torch.float64).reshape(-1, 1) * x[ei[1]], ei[0], 7))
+    with pytest.raises(gla._lib.GlaError):
+        gla.CsrPlan(d(torch.tensor([[0, 7], [0, 0]])), 7)
+    with pytest.raises(gla._lib.GlaError):
+        gla.CsrPlan(d(torch.tensor([[0, 1], [0, -1]])), 7)
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden vectors of the reference: bit-exact
+# ---------------------------------------------------------------------------------------------------
+def test_kat_3x3(golden):
+    ei, A = d(t(golden["kat3_ei"])), d(t(golden["kat3_A"]))
+    M = gla.MatVecGNN
+    gnn = gla.MetaLayer(M.EdgeUpdate(), M.VertexUpdate(M.edge_to_vertex_aggregation))
+    for tag in ("k1", "k2"):
+        va, ea, _ = gnn(d(t(golden[f"kat3_matvec_{tag}_x"])), ei, A, None, batch=None)
+        eq(va, golden[f"kat3_matvec_{tag}_va"])
+        eq(ea, golden[f"kat3_matvec_{tag}_ea"])
+    eq(va[:, 2:], [[20.0, 140.0], [301.0, 2107.0], [1030.0, 7210.0]])       # MatVecGNN.py demo output
+    r = gla.GNNResidual.GNNResidual()(d(torch.cat([t(golden["kat3_residual_b"]), t(golden["kat3_matvec_k1_x"])], 1)), ei, A)
+    eq(r, np.zeros((3, 1)))
+
+
+@pytest.mark.parametrize("N", GOLDEN_SIZES)
+def test_matvec_residual_golden(golden, N):
+    ei, ev = lap(golden, N)
+    x, b, X16 = t(golden[f"N{N}_x"]), t(golden[f"N{N}_b"]), t(golden[f"N{N}_X16"])
+    M = gla.MatVecGNN
+    gnn = gla.MetaLayer(M.EdgeUpdate(), M.VertexUpdate(M.edge_to_vertex_aggregation))
+    ei_d, ev_d = d(ei), d(ev)
+    for k, X in ((1, x), (2, X16[:, :2].contiguous()), (16, X16)):
+        va, ea, _ = gnn(d(X), ei_d, ev_d, None, batch=None)
+        eq(va, golden[f"N{N}_matvec_k{k}_va"])
+        if k <= 2:
+            eq(ea, golden[f"N{N}_matvec_k{k}_ea"])
+    perm = t(golden[f"N{N}_perm"], torch.long)
+    va, ea, _ = gnn(d(x), d(ei[:, perm]), d(ev[perm]), None)
+    eq(va, golden[f"N{N}_matvec_perm_va"])
+    eq(ea, golden[f"N{N}_matvec_perm_ea"])
+    eq(gla.GNNResidual.GNNResidual()(d(torch.cat([b, x], 1)), ei_d, ev_d), golden[f"N{N}_residual_r"])
+    # the aggregation function on its own (SC1): segment sum of arbitrary edge values
+    c = t(golden[f"N{N}_matvec_k2_ea"])[:, 1:]
+    eq(M.edge_to_vertex_aggregation(ei_d, d(c), N * N), golden[f"N{N}_matvec_k2_va"][:, 2:])
+
+
+@pytest.mark.parametrize("N", GOLDEN_SIZES)
+def test_jacobi_golden(golden, N):
+    ei, ev = lap(golden, N)
+    n = N * N
+    va0 = torch.cat([-4 * torch.ones((n, 1), dtype=torch.float64), t(golden[f"N{N}_b"]), t(golden[f"N{N}_x"])], 1)
+    ea0 = torch.cat([ev, torch.zeros_like(ev)], 1)
+    jac = gla.JacobiGNN.JacobiGNN()
+    w64 = torch.tensor(0.7, dtype=torch.float64).reshape(-1)
+    va_d, ei_d, ea_d = d(va0), d(ei), d(ea0)
+    for wtag, g in (("w32", torch.tensor(0.7).reshape(-1)), ("w64", w64)):
+        for it in (1, 10, 20):
+            eq(jac(it, va_d, ei_d, ea_d, d(g)), golden[f"N{N}_jacobi_{wtag}_it{it}_x"])
+    eq(va_d, va0)                                                   # inputs are never mutated
+    va1, ea1, _ = jac.iterate(va_d, ei_d, ea_d, d(w64))
+    eq(va1, golden[f"N{N}_jacobi_iterate_va"])
+    eq(ea1, golden[f"N{N}_jacobi_iterate_ea"])
+    perm = t(golden[f"N{N}_perm"], torch.long)
+    eq(jac(10, va_d, d(ei[:, perm]), d(ea0[perm]), d(w64)), golden[f"N{N}_jacobi_perm_it10_x"])
+    # CPU tensors in -> CPU tensors out (the reference is CPU-only)
+    out = jac(10, va0, ei, ea0, w64)
+    assert out.device.type == "cpu"
+    eq(out, golden[f"N{N}_jacobi_w64_it10_x"])
+
+
+@pytest.mark.parametrize("N", GOLDEN_SIZES)
+def test_cheby_golden(golden, N):
+    ei, ev = lap(golden, N)
+    va0 = d(torch.cat([t(golden[f"N{N}_b"]), t(golden[f"N{N}_x"])], 1))
+    g0 = t(golden[f"N{N}_cheby_g0"])
+    for deg in (0, 1, 2, 3, 4, 8):
+        va, ea, g = gla.ChebyGNN.ChebyRelaxGNN(deg)(va0, d(ei), d(ev), g0)
+        eq(va, golden[f"N{N}_cheby_deg{deg}_va"])
+        eq(ea, golden[f"N{N}_cheby_deg{deg}_ea"])
+        eq(g, golden[f"N{N}_cheby_deg{deg}_g"])
+
+
+@pytest.mark.parametrize("N", GOLDEN_SIZES)
+def test_power_golden(golden, N):
+    ei, ev = lap(golden, N)
+    b = t(golden[f"N{N}_b"])
+    for it in (1, 10):
+        va, ea, g = gla.PowerMethodGNN.PowerMethodGNN(it)(
+            d(torch.cat([b, torch.zeros_like(b)], 1)), d(ei), d(torch.cat([ev, torch.zeros_like(ev)], 1)),
+            torch.zeros(3, dtype=torch.float64), None)
+        close(va, golden[f"N{N}_power_it{it}_va"])
+        close(ea, golden[f"N{N}_power_it{it}_ea"])
+        close(g, golden[f"N{N}_power_it{it}_g"])
+        assert g.dtype == torch.float64 and g.shape == (3,)
+
+
+@pytest.mark.parametrize("N", GOLDEN_SIZES)
+def test_soc_di_golden(golden, N):
+    eio, evo = lap(golden, N, od=True)
+    n = N * N
+    z = torch.zeros((n, 1), dtype=torch.float64)
+    soc = gla.SOCClassicGNN.SOCClassicGNN(0.25)
+    eio_d = d(eio)
+    eq(soc(d(z), eio_d, d(evo)), golden[f"N{N}_soc_S"])
+    evr = t(golden[f"N{N}_socr_ev"])
+    S = soc(d(z), eio_d, d(evr))
+    eq(S, golden[f"N{N}_socr_S"])
+    eq(S > 0, golden[f"N{N}_socr_S"] > 0)                           # strong/weak classification (VCycle.py:90)
+    diag = -4 * torch.ones((n, 1), dtype=torch.float64)
+    split = t(golden[f"N{N}_split"]).reshape(-1, 1).to(torch.float64)
+    Sflag = (S.reshape(-1, 1) > 0).to(torch.float64).cpu()
+    di = gla.DirectInterpGNN.DirectInterpGNN()
+    for tag, ea_in in (("lap", torch.hstack([evo, torch.ones_like(evo)])), ("rnd", torch.hstack([evr, Sflag]))):
+        eq(di(d(torch.hstack([diag, split])), eio_d, d(ea_in)), golden[f"N{N}_di_{tag}_w"])   # NaN == NaN here
+    _, ea, _ = gla.MetaLayer(gla.SOCSAGNN.EdgeUpdate())(d(diag), eio_d, d(evo), batch=None)
+    eq(ea, golden[f"N{N}_socsa_ea"])
+    ei, ev = lap(golden, N)
+    W = gla.MatrixWeightedNorm
+    gnn = gla.MetaLayer(W.EdgeUpdate(), W.VertexUpdate(W.EdgeToVertexAggregation), W.GlobalUpdate(W.VertexToGlobalAggregation))
+    _, _, gn = gnn(d(t(golden[f"N{N}_x"])), d(ei), d(-ev), torch.zeros(1), batch=None)
+    close(gn, golden[f"N{N}_wnorm"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# seeded inputs vs the CPU oracle at larger sizes (fp64 and fp32), ragged / unsorted / long rows
+# ---------------------------------------------------------------------------------------------------
+def _problem(N, dtype, seed=24601, K=None):
+    gen = torch.Generator().manual_seed(seed)
+    ei, ev = rp.laplacianfun_torch(N)
+    n = N * N
+    shape = (n, 1) if K is None else (n, K)
+    b = torch.rand(*shape, generator=gen, dtype=torch.float64).to(dtype)
+    x = torch.rand(*shape, generator=gen, dtype=torch.float64).to(dtype)
+    return ei, ev.to(dtype), b, x
+
+
+@pytest.mark.parametrize("N,dtype", [(64, torch.float64), (257, torch.float64), (64, torch.float32), (300, torch.float32)])
+def test_jacobi_cheby_vs_oracle(N, dtype):
+    ei, ev, b, x = _problem(N, dtype)
+    n = N * N
+    diag = -4 * torch.ones((n, 1), dtype=dtype)
+    ea0 = torch.cat([ev, torch.zeros_like(ev)], 1)
+    g = torch.tensor([0.7], dtype=dtype)
+    want = rp.jacobi_forward(7, torch.cat([diag, b, x], 1), ei, ea0, g)
+    got = gla.JacobiGNN.JacobiGNN()(7, d(torch.cat([diag, b, x], 1)), d(ei), d(ea0), d(g))
+    eq(got, want)
+    gch = torch.tensor([-3.4, -4.0], dtype=dtype)                   # VCycle.py:221-222
+    va_w, ea_w, g_w = rp.cheby_forward(4, torch.cat([b, x], 1), ei, ev, gch)
+    va_g, ea_g, g_g = gla.ChebyGNN.ChebyRelaxGNN(4)(d(torch.cat([b, x], 1)), d(ei), d(ev), gch)
+    eq(va_g, va_w)
+    eq(ea_g, ea_w)
+    eq(g_g, g_w)
+    assert va_g.dtype == dtype
+    r_w = rp.residual_forward(torch.cat([b, x], 1), ei, ev)
+    eq(gla.GNNResidual.GNNResidual()(d(torch.cat([b, x], 1)), d(ei), d(ev)), r_w)
+
+
+def test_multi_rhs_equals_column_runs():
+    """Multi-RHS extension: column k of the K=16 run == the single-RHS run on column k (bit-exact)."""
+    N, K = 48, 16
+    ei, ev, B, X = _problem(N, torch.float64, K=K)
+    n = N * N
+    ei_d, ev_d = d(ei), d(ev)
+    diag = -4 * torch.ones((n, 1, K), dtype=torch.float64)
+    ea0 = torch.cat([ev, torch.zeros_like(ev)], 1)
+    g = torch.tensor([0.7], dtype=torch.float64)
+    xk = gla.JacobiGNN.JacobiGNN()(5, d(torch.stack([diag[:, 0], B, X], 1)), ei_d, d(ea0), g)
+    assert xk.shape == (n, 1, K)
+    gch = torch.tensor([-3.4, -4.0], dtype=torch.float64)
+    vk, _, gk = gla.ChebyGNN.ChebyRelaxGNN(4, return_edge_attr=False)(d(torch.stack([B, X], 1)), ei_d, ev_d, gch)
+    assert vk.shape == (n, 4, K)
+    pk, _, gp = gla.PowerMethodGNN.PowerMethodGNN(10, return_edge_attr=False)(
+        d(torch.stack([B, torch.zeros_like(B)], 1)), ei_d, d(ea0), torch.zeros(3, K, dtype=torch.float64), None)
+    assert gp.shape == (3, K)
+    for k in (0, 5, 15):
+        b, x = B[:, k:k + 1].contiguous(), X[:, k:k + 1].contiguous()
+        eq(xk[:, 0, k:k + 1], rp.jacobi_forward(5, torch.cat([diag[:, :, 0], b, x], 1), ei, ea0, g))
+        va_w, _, g_w = rp.cheby_forward(4, torch.cat([b, x], 1), ei, ev, gch)
+        eq(vk[:, :, k], va_w)
+        eq(gk, g_w)
+        _, _, g_w = rp.power_forward(10, torch.cat([b, torch.zeros_like(b)], 1), ei, ea0, torch.zeros(3, dtype=torch.float64))
+        close(gp[:, k], g_w)
+
+
+def test_ragged_unsorted_and_long_rows():
+    gen = torch.Generator().manual_seed(11)
+    n = 3000
+    # ragged: row lengths 0..40, unsorted edge list, duplicates allowed
+    lens = torch.randint(0, 41, (n,), generator=gen)
+    lens[::17] = 0
+    rows = torch.repeat_interleave(torch.arange(n), lens)
+    cols = torch.randint(0, n, (rows.numel(),), generator=gen)
+    shuffle = torch.randperm(rows.numel(), generator=gen)
+    ei = torch.stack([rows, cols])[:, shuffle]
+    ev = torch.rand(ei.shape[1], 1, generator=gen, dtype=torch.float64) - 0.5
+    X = torch.rand(n, 3, generator=gen, dtype=torch.float64)
+    M = gla.MatVecGNN
+    gnn = gla.MetaLayer(M.EdgeUpdate(), M.VertexUpdate(M.edge_to_vertex_aggregation))
+    va, ea, _ = gnn(d(X), d(ei), d(ev), None)
+    va_w, ea_w, _ = rp.matvec_layer(X, ei, ev)
+    eq(va, va_w)
+    eq(ea, ea_w)
+    # dense 100 x 100 weight matrix (MatrixWeightedNorm.py demo): 100 nnz per row, still the in-order path
+    W = torch.rand(100, 100, generator=gen, dtype=torch.float64)
+    ei_w = torch.stack([torch.arange(100).repeat_interleave(100), torch.arange(100).repeat(100)])
+    x = torch.rand(100, 1, generator=gen, dtype=torch.float64)
+    va, _, _ = gnn(d(x), d(ei_w), d(W.reshape(-1, 1)), None)
+    eq(va, rp.matvec_layer(x, ei_w, W.reshape(-1, 1))[0])
+    # one row of 6000 nnz forces the CSR-vector fallback (tree-ordered sums): tolerance, not bit-exact
+    rows = torch.cat([torch.full((6000,), 5), torch.arange(50)])
+    cols = torch.cat([torch.randint(0, 50, (6000,), generator=gen), torch.arange(50)])
+    ei_l = torch.stack([rows, cols])
+    ev_l = torch.rand(6050, 1, generator=gen, dtype=torch.float64)
+    x = torch.rand(50, 2, generator=gen, dtype=torch.float64)
+    plan = gla.CsrPlan(d(ei_l), 50)
+    assert plan.info.long_rows == 1
+    va, _, _ = gnn(d(x), d(ei_l), d(ev_l), None)
+    close(va, rp.matvec_layer(x, ei_l, ev_l)[0], rtol=1e-13)
+
+
+def test_soc_di_vs_oracle_fem_like():
+    """9-point FEM stencil (heateqnfem2dfun restatement, alpha = 4): SOC flags bit-exact, DI weights bit-exact."""
+    m = 40
+    ei, ev = rp.heateqnfem2dfun([m + 1, m + 1], [1.0, 4.0])
+    n = m * m
+    eio, evo = rp.remove_diag_entries(ei, ev)
+    diag = ev[ei[0] == ei[1]].reshape(-1, 1)
+    z = torch.zeros((n, 1), dtype=torch.float64)
+    S_w, v_w = rp.soc_classic_forward(0.25, z, eio, evo, return_v=True)
+    S_g, v_g = gla.SOCClassicGNN.SOCClassicGNN(0.25)(d(z), d(eio), d(evo), return_v=True)
+    eq(S_g, S_w)
+    eq(v_g, v_w)
+    assert 0 < int((S_w > 0).sum()) < S_w.numel()                   # both classes present
+    split = torch.zeros(n, 1, dtype=torch.float64)
+    split[0::2] = 1
+    ea = torch.hstack([evo, (S_w.reshape(-1, 1) > 0).to(torch.float64)])
+    w_w = rp.direct_interp_forward(torch.hstack([diag, split]), eio, ea)
+    w_g = gla.DirectInterpGNN.DirectInterpGNN()(d(torch.hstack([diag, split])), d(eio), d(ea))
+    eq(w_g, w_w)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE full size (config 2: 4096 x 4096, fp64)
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_jacobi():
+    N = 4096
+    n = N * N
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    assert ei.shape == (2, 5 * n - 4 * N)
+    gen = torch.Generator().manual_seed(24601)
+    b = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    x = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    diag = -4 * torch.ones(n, 1, dtype=torch.float64)
+    va = torch.cat([diag, b, x], 1)
+    ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+    g = torch.tensor([0.7], dtype=torch.float64)
+    jac = gla.JacobiGNN.JacobiGNN()
+    va_d, g_d = d(va), d(g)
+    x2 = jac(2, va_d, ei, ea, g_d)
+    # (a) the oracle itself, 2 sweeps on the host (about 10 s)
+    ei_c, ev_c = ei.cpu(), ev.cpu()
+    want = rp.jacobi_forward(2, va, ei_c, torch.cat([ev_c, torch.zeros_like(ev_c)], 1), g)
+    eq(x2, want)
+    del want
+    # (b) composition: 20 sweeps == 10 sweeps applied twice (bit-exact, size independent)
+    x20 = jac(20, va_d, ei, ea, g_d)
+    x10 = jac(10, va_d, ei, ea, g_d)
+    x10b = jac(10, torch.cat([va_d[:, :2], x10], 1), ei, ea, g_d)
+    eq(x20, x10b)
+    # (c) fixed point: with b = A x*, x* is reproduced exactly by a sweep up to rounding of (b - A x*) = 0
+    xs = d(x)
+    plan = gla.plan_for(ei, n, edge_attr=ea)
+    bs = plan.spmm(xs)
+    xf = jac(3, torch.cat([va_d[:, :1], bs, xs], 1), ei, ea, g_d)
+    eq(xf, xs)
+    # (d) residual norm decreases monotonically over sweeps for this SPD-like system
+    res = gla.GNNResidual.GNNResidual()
+    r0 = torch.linalg.norm(res(torch.cat([d(b), xs], 1), ei, ev))
+    r20 = torch.linalg.norm(res(torch.cat([d(b), x20], 1), ei, ev))
+    assert r20 < r0
