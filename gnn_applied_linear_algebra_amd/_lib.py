@@ -36,6 +36,7 @@ _D = ctypes.c_double
 SIGNATURES = {
     "gla_version": (_I, []),
     "gla_error_string": (ctypes.c_char_p, [_I]),
+    "gla_set_option": (_I, [ctypes.c_char_p, _I64]),
     "gla_csr_create_from_coo": (_I, [_I64, _I64, _I64, _P, _P, _P, ctypes.POINTER(_P)]),
     "gla_csr_destroy": (_I, [_P]),
     "gla_csr_set_values": (_I, [_P, _P, _I64, _I, _P]),

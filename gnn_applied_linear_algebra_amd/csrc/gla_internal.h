@@ -26,11 +26,18 @@ struct gla_csr {
   void* val = nullptr;           // [nnz + GLA_PAD] * 8 bytes, CSR order
   int val_dtype = -1;
   int32_t* tile_row = nullptr;   // [n_tiles + 1] first row of each tile
+  int32_t* tile_info = nullptr;  // [4 * n_tiles] {first row, end row, first nnz, end nnz} per tile (int4)
   int32_t* tile_lists = nullptr; // [2 * n_tiles]: interior tiles then boundary tiles
   int32_t n_tiles = 0, n_interior = 0, n_boundary = 0;
   int32_t tile_nnz = 0, lds_elems = 0, max_row_len = 0;
   int32_t sorted_input = 1, long_rows = 0;
 };
+
+struct gla_tuning {
+  int spmv_variant = 0;     // experimental kernel selection for K = 1 (see launch_rows)
+  int tile_nnz = 0;         // 0 = automatic (256 * average row length)
+};
+extern gla_tuning g_tuning;
 
 // plan.hip
 int gla_sort_rows_stable(int64_t nnz, int64_t n_rows, const int64_t* row, int32_t* perm_out,

@@ -28,6 +28,7 @@ namespace {
 // device views
 // ------------------------------------------------------------------------------------------------
 struct TileMap {
+  const int4* tile_info;      // per tile {first row, end row, first nnz, end nnz}
   const int32_t* tile_row;
   const int32_t* tile_list;   // nullptr = identity
   int n_tiles;                // tiles to run in this launch
@@ -44,60 +45,87 @@ __device__ __forceinline__ int map_tile(const TileMap& m) {
 // ------------------------------------------------------------------------------------------------
 // fused vertex updates ("epilogues"): called once per (row, rhs) with the finished row sum
 // ------------------------------------------------------------------------------------------------
+// Each epilogue is split into load() -- the row's dense operands, issued EARLY so their latency overlaps the
+// nnz stream -- and apply() with the finished row sum.  operator() = both, for kernels that do not prefetch.
+struct NoPre {};
+
 template <typename T>
 struct EpiStore {                       // y = A x                       MatVecGNN.py:95-114
   T* y; int64_t ldy;
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { y[r * ldy + k] = acc; }
+  typedef NoPre Pre;
+  __device__ __forceinline__ Pre load(int64_t, int) const { return Pre{}; }
+  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre&) const { y[r * ldy + k] = acc; }
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
 };
 
 template <typename T>
 struct EpiResidual {                    // r = b - A x                   GNNResidual.py:97-118
   const T* b; int64_t ldb; T* res; int64_t ldr;
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {
-    res[r * ldr + k] = b[r * ldb + k] - acc;
+  struct Pre { T b; };
+  __device__ __forceinline__ Pre load(int64_t r, int k) const { return Pre{b[r * ldb + k]}; }
+  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& p) const {
+    res[r * ldr + k] = p.b - acc;
   }
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
 };
 
 template <typename T>
 struct EpiJacobi {                      // x + (w*(b - A x))/A_ii        JacobiGNN.py:100-123 (:119)
   const T* diag; const T* b; int64_t ldb; const T* x; int64_t ldx; T* xo; int64_t ldxo; T w;
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {
-    const T xi = x[r * ldx + k];
-    xo[r * ldxo + k] = xi + (w * (b[r * ldb + k] - acc)) / diag[r];
+  struct Pre { T d, b, x; };
+  __device__ __forceinline__ Pre load(int64_t r, int k) const {
+    return Pre{diag[r], b[r * ldb + k], x[r * ldx + k]};
   }
+  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& p) const {
+    xo[r * ldxo + k] = p.x + (w * (p.b - acc)) / p.d;
+  }
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
 };
 
 template <typename T>
 struct EpiChebyFirst {                  // r = b - A x; p = r; x += alpha p    ChebyGNN.py:91-163
   const T* b; int64_t ldb; const T* x; int64_t ldx; T* res; int64_t ldr; T* p; int64_t ldp;
   T* xo; int64_t ldxo; T alpha;
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {
-    const T ri = b[r * ldb + k] - acc;
+  struct Pre { T b, x; };
+  __device__ __forceinline__ Pre load(int64_t r, int k) const { return Pre{b[r * ldb + k], x[r * ldx + k]}; }
+  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& q) const {
+    const T ri = q.b - acc;
     res[r * ldr + k] = ri;
     p[r * ldp + k] = ri;
-    xo[r * ldxo + k] = x[r * ldx + k] + alpha * ri;
+    xo[r * ldxo + k] = q.x + alpha * ri;
   }
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
 };
 
 template <typename T>
 struct EpiChebyNext {                   // r -= a_old*(A p); p = r + beta p; x += a_new p   ChebyGNN.py:186-243
   const T* p; int64_t ldp; T* po; int64_t ldpo; T* res; int64_t ldr; T* x; int64_t ldx;
   T a_old, a_new, beta;
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {
-    const T ri = res[r * ldr + k] - a_old * acc;
-    res[r * ldr + k] = ri;
-    const T pn = ri + beta * p[r * ldp + k];
-    po[r * ldpo + k] = pn;
-    x[r * ldx + k] = x[r * ldx + k] + a_new * pn;
+  struct Pre { T r, p, x; };
+  __device__ __forceinline__ Pre load(int64_t r, int k) const {
+    return Pre{res[r * ldr + k], p[r * ldp + k], x[r * ldx + k]};
   }
+  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& q) const {
+    const T ri = q.r - a_old * acc;
+    res[r * ldr + k] = ri;
+    const T pn = ri + beta * q.p;
+    po[r * ldpo + k] = pn;
+    x[r * ldx + k] = q.x + a_new * pn;
+  }
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
 };
 
 // ------------------------------------------------------------------------------------------------
 // K = 1: products staged in LDS
 // ------------------------------------------------------------------------------------------------
-constexpr int SPMV_UNROLL = 4;
+template <bool NT, typename U>
+__device__ __forceinline__ U ld_stream(const U* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
 
-template <typename T, class Epi>
+// NPT = nnz per thread issued back to back (memory-level parallelism); NT = non-temporal val/col loads
+template <typename T, class Epi, int NPT, bool NT>
 __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
     const T* __restrict__ x, TileMap tm, Epi epi) {
@@ -111,21 +139,21 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_kernel(
   const int len = rowptr[r1] - s;
   const int tid = threadIdx.x;
 
-  for (int base = 0; base < len; base += GLA_BLOCK * SPMV_UNROLL) {
-    T v[SPMV_UNROLL];
-    int c[SPMV_UNROLL];
+  for (int base = 0; base < len; base += GLA_BLOCK * NPT) {
+    T v[NPT];
+    int c[NPT];
 #pragma unroll
-    for (int u = 0; u < SPMV_UNROLL; ++u) {
+    for (int u = 0; u < NPT; ++u) {
       const int i = base + u * GLA_BLOCK + tid;
       const bool ok = i < len;
-      c[u] = ok ? col[s + i] : 0;
-      v[u] = ok ? val[s + i] : T(0);
+      c[u] = ok ? ld_stream<NT>(col + s + i) : 0;
+      v[u] = ok ? ld_stream<NT>(val + s + i) : T(0);
     }
-    T xv[SPMV_UNROLL];
+    T xv[NPT];
 #pragma unroll
-    for (int u = 0; u < SPMV_UNROLL; ++u) xv[u] = x[c[u]];
+    for (int u = 0; u < NPT; ++u) xv[u] = x[c[u]];
 #pragma unroll
-    for (int u = 0; u < SPMV_UNROLL; ++u) {
+    for (int u = 0; u < NPT; ++u) {
       const int i = base + u * GLA_BLOCK + tid;
       if (i < len) prod[i] = v[u] * xv[u];
     }
@@ -137,6 +165,89 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_kernel(
     T acc = T(0);
     for (int j = a; j < b; ++j) acc = acc + prod[j];
     epi((int64_t)r, 0, acc);
+  }
+}
+
+// Main K = 1 kernel: 16-byte val loads / 8-byte col loads -- each lane owns PAIRS of consecutive nnz; the tile's
+// nnz window is aligned down to an even index (the extra element is staged but never summed).
+// PF: the row lane's rowptr / dense operands are requested before the nnz stream so that the block runs through
+// three dependent memory round trips (tile record -> streams -> x gather) instead of five.
+template <typename T, class Epi, int PPT, bool NT, bool PF>
+__global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ x, TileMap tm, Epi epi) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* prod = reinterpret_cast<T*>(smem_raw);
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef int I2 __attribute__((ext_vector_type(2)));
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, e = ti.w;
+  if (r0 >= r1) return;
+  const int tid = threadIdx.x;
+  const int r = r0 + tid;
+  int ra = 0, rb = 0;
+  typename Epi::Pre pre;
+  if (PF && r < r1) {
+    ra = rowptr[r];
+    rb = rowptr[r + 1];
+    pre = epi.load((int64_t)r, 0);
+  }
+  const int sa = s & ~1;                       // even -> val+sa is 16-byte aligned, col+sa 8-byte aligned
+  const int npairs = (e - sa + 1) >> 1;
+  const T2* val2 = reinterpret_cast<const T2*>(val + sa);
+  const I2* col2 = reinterpret_cast<const I2*>(col + sa);
+  T2* prod2 = reinterpret_cast<T2*>(prod);
+
+  for (int base = 0; base < npairs; base += GLA_BLOCK * PPT) {
+    T2 v[PPT];
+    I2 c[PPT];
+    // Branch-free batch: indices are clamped into the tile, so every lane issues every load and every LDS
+    // write (lanes past the end recompute the tile's last pair and store the identical value again).  A
+    // predicated load or store makes hipcc sink the loads into exec-mask branches with a full s_waitcnt each,
+    // which serialises the batch and halves the bytes in flight.
+    int qc[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      qc[u] = min(base + u * GLA_BLOCK + tid, npairs - 1);
+      c[u] = ld_stream<NT>(col2 + qc[u]);
+      v[u] = ld_stream<NT>(val2 + qc[u]);
+    }
+    T2 xv[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) { xv[u].x = x[c[u].x]; xv[u].y = x[c[u].y]; }
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      T2 p;
+      p.x = v[u].x * xv[u].x;
+      p.y = v[u].y * xv[u].y;
+      prod2[qc[u]] = p;
+    }
+  }
+  __syncthreads();
+
+  if (r < r1) {
+    if (!PF) {
+      ra = rowptr[r];
+      rb = rowptr[r + 1];
+      pre = epi.load((int64_t)r, 0);
+    }
+    T acc = T(0);
+    int j = ra - sa;
+    const int jend = rb - sa;
+    for (; j + 4 <= jend; j += 4) {              // LDS reads issued together, added strictly in edge order
+      const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
+      acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+    }
+    for (; j < jend; ++j) acc = acc + prod[j];
+    epi.apply((int64_t)r, 0, acc, pre);
+  }
+  for (int r2 = r + GLA_BLOCK; r2 < r1; r2 += GLA_BLOCK) {       // tiles with more than 256 (short) rows
+    const int a = rowptr[r2] - sa, b = rowptr[r2 + 1] - sa;
+    T acc = T(0);
+    for (int j = a; j < b; ++j) acc = acc + prod[j];
+    epi((int64_t)r2, 0, acc);
   }
 }
 
@@ -222,6 +333,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   }
   TileMap tm;
   tm.tile_row = A->tile_row;
+  tm.tile_info = reinterpret_cast<const int4*>(A->tile_info);
   if (which == 0) { tm.tile_list = nullptr; tm.n_tiles = A->n_tiles; }
   else if (which == 1) { tm.tile_list = A->tile_lists; tm.n_tiles = A->n_interior; }
   else if (which == 2) { tm.tile_list = A->tile_lists + A->n_tiles; tm.n_tiles = A->n_boundary; }
@@ -231,8 +343,24 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   tm.tiles_per_xcd = (tm.n_tiles + GLA_XCDS - 1) / GLA_XCDS;
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   if (K == 1) {
-    const size_t lds = (size_t)A->lds_elems * sizeof(T);
-    hipLaunchKernelGGL((spmv_stream_kernel<T, Epi>), grid, block, lds, st, A->rowptr, A->col, val, X, tm, epi);
+    const size_t lds = (size_t)(A->lds_elems + 2) * sizeof(T);
+#define GLA_SPMV1(N_, NT_) \
+  hipLaunchKernelGGL((spmv_stream_kernel<T, Epi, N_, NT_>), grid, block, lds, st, A->rowptr, A->col, val, X, tm, epi)
+#define GLA_SPMV2(N_, NT_, PF_) \
+  hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
+                     X, tm, epi)
+    switch (g_tuning.spmv_variant) {
+      case 1: GLA_SPMV1(5, false); break;
+      case 2: GLA_SPMV1(4, false); break;
+      case 6: GLA_SPMV2(3, false, false); break;
+      case 7: GLA_SPMV2(2, false, false); break;
+      case 10: GLA_SPMV2(2, false, true); break;
+      case 11: GLA_SPMV2(4, false, true); break;
+      case 12: GLA_SPMV2(3, true, true); break;
+      default: GLA_SPMV2(3, false, true); break;
+    }
+#undef GLA_SPMV1
+#undef GLA_SPMV2
   } else {
     const size_t lds = (size_t)A->lds_elems * (sizeof(T) + sizeof(int32_t));
 #define GLA_SPMM_CASE(KP_)                                                                              \
@@ -459,6 +587,7 @@ inline unsigned grid_for(int64_t work, int per_block = GLA_BLOCK, int cap = 256 
 inline TileMap all_tiles(gla_csr* A) {
   TileMap tm;
   tm.tile_row = A->tile_row;
+  tm.tile_info = reinterpret_cast<const int4*>(A->tile_info);
   tm.tile_list = nullptr;
   tm.n_tiles = A->n_tiles;
   tm.tiles_per_xcd = (A->n_tiles + GLA_XCDS - 1) / GLA_XCDS;

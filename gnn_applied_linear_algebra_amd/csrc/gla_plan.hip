@@ -87,6 +87,15 @@ __global__ __launch_bounds__(GLA_BLOCK) void tile_rows_kernel(const int32_t* __r
   tile_row[k] = (int32_t)lo;
 }
 
+__global__ __launch_bounds__(GLA_BLOCK) void tile_info_kernel(const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ tile_row, int n_tiles,
+                                                              int4* __restrict__ info) {
+  const int t = blockIdx.x * GLA_BLOCK + threadIdx.x;
+  if (t >= n_tiles) return;
+  const int r0 = tile_row[t], r1 = tile_row[t + 1];
+  info[t] = make_int4(r0, r1, rowptr[r0], rowptr[r1]);
+}
+
 // a tile is "boundary" when any of its columns is >= col_limit (a halo column of a row-block partition)
 __global__ __launch_bounds__(GLA_BLOCK) void tile_flag_kernel(const int32_t* __restrict__ rowptr,
                                                               const int32_t* __restrict__ col,
@@ -258,9 +267,21 @@ done:
   return rc;
 }
 
+gla_tuning g_tuning;
+
 extern "C" {
 
 int gla_version(void) { return 100; }
+
+int gla_set_option(const char* name, int64_t value) {
+  if (!name) return GLA_ERR_INVALID_ARG;
+  if (!strcmp(name, "spmv_variant")) { g_tuning.spmv_variant = (int)value; return GLA_OK; }
+  if (!strcmp(name, "tile_nnz")) {
+    if (value != 0 && (value < 256 || value > GLA_LDS_ELEMS_MAX - 64)) return GLA_ERR_INVALID_ARG;
+    g_tuning.tile_nnz = (int)value; return GLA_OK;
+  }
+  return GLA_ERR_INVALID_ARG;
+}
 
 const char* gla_error_string(int code) {
   switch (code) {
@@ -284,6 +305,7 @@ int gla_csr_destroy(gla_csr_t p) {
   if (p->perm) (void)hipFree(p->perm);
   if (p->val) (void)hipFree(p->val);
   if (p->tile_row) (void)hipFree(p->tile_row);
+  if (p->tile_info) (void)hipFree(p->tile_info);
   if (p->tile_lists) (void)hipFree(p->tile_lists);
   delete p;
   return GLA_OK;
@@ -346,6 +368,7 @@ int gla_csr_create_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const i
     const double avg = n_rows > 0 ? (double)nnz / (double)n_rows : 0.0;
     int64_t target = (int64_t)(GLA_BLOCK * (avg < 1.0 ? 1.0 : avg) + 0.5);
     if (target < GLA_TILE_NNZ_MIN) target = GLA_TILE_NNZ_MIN;
+    if (g_tuning.tile_nnz > 0) target = g_tuning.tile_nnz;
     p->long_rows = (p->max_row_len > GLA_LDS_ELEMS_MAX - GLA_TILE_NNZ_MIN) ? 1 : 0;
     if (!p->long_rows && target > GLA_LDS_ELEMS_MAX - p->max_row_len) target = GLA_LDS_ELEMS_MAX - p->max_row_len;
     p->tile_nnz = (int32_t)target;
@@ -356,6 +379,10 @@ int gla_csr_create_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const i
     PLAN_CHECK(hipMalloc(&p->tile_row, (nt + 1) * sizeof(int32_t)));
     hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((nt + 1 + GLA_BLOCK - 1) / GLA_BLOCK)), dim3(GLA_BLOCK), 0,
                        st, p->rowptr, n_rows, p->n_tiles, p->tile_nnz, p->tile_row);
+    PLAN_CHECK(hipGetLastError());
+    PLAN_CHECK(hipMalloc(&p->tile_info, nt * 4 * sizeof(int32_t)));
+    hipLaunchKernelGGL(tile_info_kernel, dim3((unsigned)((nt + GLA_BLOCK - 1) / GLA_BLOCK)), dim3(GLA_BLOCK), 0, st,
+                       p->rowptr, p->tile_row, p->n_tiles, reinterpret_cast<int4*>(p->tile_info));
     PLAN_CHECK(hipGetLastError());
   }
   PLAN_CHECK(hipStreamSynchronize(st));

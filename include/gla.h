@@ -46,6 +46,9 @@ enum {
 };
 
 int gla_version(void);
+/* Tuning knobs (process-wide): "spmv_variant" (kernel flavour for K = 1), "tile_nnz" (target nnz per row
+ * tile for plans created afterwards; 0 = automatic). */
+int gla_set_option(const char* name, int64_t value);
 const char* gla_error_string(int code);
 
 /* ---- plan: COO edge list -> CSR (replaces nothing 1:1; it is the index side of every
