@@ -142,7 +142,7 @@ def main():
     value = world * total_sweeps / elapsed
     B = algorithmic_bytes_jacobi(n_local, nnz_local)
 
-    # roofline of the dominant kernel (spmv_stream_kernel<double, EpiJacobi>): HIP events on the launch stream
+    # roofline of the dominant kernel (spmv_stream_vec2_kernel<double, EpiJacobi>): HIP events on the launch stream
     roof = None
     if rank == 0:
         if kernel_only is not None:
@@ -170,7 +170,7 @@ def main():
                 traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "kernel": "spmv_stream_kernel<double,EpiJacobi>", "algorithmic_bytes_per_launch": B,
+                "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "algorithmic_bytes_per_launch": B,
                 "avg_launch_us": round(t_launch * 1e6, 2)}
 
     cpu = None

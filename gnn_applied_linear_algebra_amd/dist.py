@@ -1,0 +1,209 @@
+"""Row-block domain decomposition of the message-passing loop across the GPUs of one node (RCCL over xGMI).
+
+The reference has no distributed code; BASELINE.json defines this layer: the mesh is cut into
+contiguous ROW BLOCKS (whole grid lines of the 2-D Laplacian), one block per rank = one process per GPU, and the
+only data exchanged per sweep / SpMV are the HALO vertices: the x values of off-block columns.
+
+Layout per rank (rows [row_lo, row_hi) of the global matrix, n_local of them):
+
+    X buffer  [ n_local | P * S ] x K      local vertices, then the ALL-GATHERED send slots of every rank
+    columns   local column c        -> c - row_lo
+              column owned by rank q -> n_local + q * S + (position of c in q's send list)
+
+S = longest send list (a rank's send list = its rows that ANY other rank reads; for the 5-point grid: its first
+and last grid line).  One `all_gather_into_tensor` per sweep writes straight into the tail of the X buffer the
+kernels gather from, so there is no unpack pass.  The collective is asynchronous: interior row tiles (no halo
+column, classified once by gla_csr_classify_tiles) run while it is in flight, boundary tiles after it landed.
+
+`RowBlockPartition` is pure index logic + the exchange (works on CPU tensors with the gloo backend, which is how
+tests/test_dist_cpu.py covers it with world_size 2); `RowBlockJacobi` / `RowBlockOps` bind it to the HIP kernels.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class RowBlockPartition:
+    def __init__(self, edgeij_pair, n_global, row_lo, row_hi, group=None):
+        """edgeij_pair [2, nnz_local]: the edges whose ROW lies in [row_lo, row_hi), GLOBAL vertex ids."""
+        self.group = group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.n_global, self.row_lo, self.row_hi = int(n_global), int(row_lo), int(row_hi)
+        self.n_local = self.row_hi - self.row_lo
+        dev = edgeij_pair.device
+        row, col = edgeij_pair[0], edgeij_pair[1]
+        if row.numel() and (int(row.min()) < self.row_lo or int(row.max()) >= self.row_hi):
+            raise ValueError("edge rows outside this rank's row block")
+
+        # every rank's block + the halo columns it reads (setup-time object collectives, small)
+        off = (col < self.row_lo) | (col >= self.row_hi)
+        need = torch.unique(col[off]).cpu()                       # sorted global ids
+        if self.distributed:
+            blocks = [None] * self.world
+            needs = [None] * self.world
+            dist.all_gather_object(blocks, (self.row_lo, self.row_hi), group=group)
+            dist.all_gather_object(needs, need, group=group)
+        else:
+            blocks, needs = [(self.row_lo, self.row_hi)], [need]
+        los = torch.tensor([b[0] for b in blocks])
+        his = torch.tensor([b[1] for b in blocks])
+        if int(los[0]) != 0 or int(his[-1]) != self.n_global or bool((los[1:] != his[:-1]).any()):
+            raise ValueError(f"row blocks do not tile [0, {self.n_global}): {blocks}")
+        self.blocks = blocks
+        # send list of rank q = sorted union of q's rows that any rank needs
+        all_need = torch.unique(torch.cat(needs)) if self.world > 1 else need
+        send_lists = [all_need[(all_need >= lo) & (all_need < hi)] for lo, hi in blocks]
+        self.S = max([int(s.numel()) for s in send_lists] + [0])
+        self.halo_size = self.world * self.S
+        self.send_idx = (send_lists[self.rank] - self.row_lo).to(dev)          # local row ids, sorted
+        self.n_send = int(self.send_idx.numel())
+
+        # column renumbering: local | gathered slots
+        owner = torch.bucketize(need, his, right=True)                          # rank owning each halo column
+        slot = torch.empty_like(need)
+        for q in range(self.world):
+            m = owner == q
+            if bool(m.any()):
+                slot[m] = q * self.S + torch.searchsorted(send_lists[q], need[m])
+        need_d, slot_d = need.to(dev), slot.to(dev)
+        col_local = col - self.row_lo
+        if need_d.numel():
+            pos = torch.searchsorted(need_d, col[off])
+            col_local = col_local.clone()
+            col_local[off] = self.n_local + slot_d[pos]
+        self.edge_index_local = torch.stack([row - self.row_lo, col_local])
+        self.n_cols_local = self.n_local + self.halo_size
+
+    # ---- buffers / exchange -------------------------------------------------------------------------
+    def new_buffer(self, K, dtype, device):
+        return torch.zeros((self.n_cols_local, K), dtype=dtype, device=device)
+
+    def exchange(self, X, async_op=False):
+        """All-gather the send slots of every rank into X[n_local:].  X: [n_local + P*S, K]."""
+        if self.world == 1 or self.S == 0:
+            return None
+        K = X.shape[1]
+        send = torch.zeros((self.S, K), dtype=X.dtype, device=X.device)
+        if self.n_send:
+            send[:self.n_send] = X[:self.n_local].index_select(0, self.send_idx)
+        if X.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test-only route (2 ranks sharing one GPU, tests/test_gpu_dist.py): gloo moves host memory
+            send_h = send.cpu()
+            recv_h = torch.empty((self.halo_size, K), dtype=X.dtype)
+            dist.all_gather_into_tensor(recv_h, send_h, group=self.group)
+            X[self.n_local:] = recv_h.to(X.device)
+            return _Done() if async_op else None
+        return dist.all_gather_into_tensor(X[self.n_local:], send, group=self.group, async_op=async_op)
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class RowBlockOps:
+    """The partition bound to a libgla_hip CSR plan of the local block (rows local, columns local + halo)."""
+
+    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True):
+        from .plan import CsrPlan, ALL_TILES, INTERIOR_TILES, BOUNDARY_TILES
+        self.ALL, self.INTERIOR, self.BOUNDARY = ALL_TILES, INTERIOR_TILES, BOUNDARY_TILES
+        self.part = RowBlockPartition(edgeij_pair, n_global, row_lo, row_hi, group)
+        p = self.part
+        self.plan = CsrPlan(p.edge_index_local, p.n_local, p.n_cols_local)
+        self.plan.set_values(edge_attr)
+        self.overlap = bool(overlap) and p.world > 1 and p.S > 0
+        if self.overlap:
+            self.plan.classify_tiles(p.n_local)
+
+    def run(self, X, launch):
+        """Exchange X's halo and call launch(which_tiles) for all row tiles, overlapping when enabled."""
+        p = self.part
+        if p.world == 1 or p.S == 0:
+            launch(self.ALL)
+        elif self.overlap:
+            work = p.exchange(X, async_op=True)
+            launch(self.INTERIOR)
+            work.wait()
+            launch(self.BOUNDARY)
+        else:
+            p.exchange(X)
+            launch(self.ALL)
+
+
+class RowBlockJacobi(RowBlockOps):
+    """JacobiGNN.forward on a row block: same arguments as the module, local rows only (JacobiGNN.py:138-148)."""
+
+    def forward(self, n_iters, vertex_attr, g):
+        p = self.part
+        va = vertex_attr
+        K = 1 if va.dim() == 2 else va.shape[2]
+        diag = (va[:, 0] if va.dim() == 2 else va[:, 0, 0]).contiguous()
+        B = (va[:, 1].reshape(-1, 1) if va.dim() == 2 else va[:, 1, :]).contiguous()
+        w = float(g.reshape(-1)[0])
+        cur = p.new_buffer(K, va.dtype, va.device)
+        nxt = p.new_buffer(K, va.dtype, va.device)
+        cur[:p.n_local] = va[:, 2].reshape(-1, 1) if va.dim() == 2 else va[:, 2, :]
+        for _ in range(int(n_iters)):
+            out = nxt[:p.n_local]
+            self.run(cur, lambda which: self.plan.jacobi_sweep(diag, B, cur, out, w, which))
+            cur, nxt = nxt, cur
+        x = cur[:p.n_local]
+        return x.clone() if va.dim() == 2 else x.unsqueeze(1).clone()
+
+
+class RowBlockCheby(RowBlockOps):
+    """ChebyRelaxGNN(deg).forward on a row block (ChebyGNN.py:324-353); returns (x, r, p, g_out) local rows."""
+
+    def forward(self, deg, b, x0, g):
+        p = self.part
+        K = b.shape[1]
+        gh = g.detach().to("cpu")
+        c, d = gh[0], gh[1]
+        alpha = 1 / d
+        beta = None
+        xin = p.new_buffer(K, b.dtype, b.device)
+        xin[:p.n_local] = x0
+        r, x = torch.empty_like(b), torch.empty_like(b)
+        pc, pn = p.new_buffer(K, b.dtype, b.device), p.new_buffer(K, b.dtype, b.device)
+        if deg <= 0:
+            return x0, None, None, g
+        self.run(xin, lambda which: self.plan.cheby_first(b, xin, r, pc[:p.n_local], x, float(alpha), which))
+        for it in range(2, deg + 1):
+            beta = 0.5 * (c * alpha) ** 2 if it == 2 else ((c * alpha) / 2) ** 2
+            alpha_new = 1 / (d - beta / alpha)
+            a_old, a_new, bt = float(alpha), float(alpha_new), float(beta)
+            src, dst = pc, pn
+            self.run(src, lambda which: self.plan.cheby_next(src, dst[:p.n_local], r, x, a_old, a_new, bt, which))
+            pc, pn = pn, pc
+            alpha = alpha_new
+        g_out = torch.hstack([c, d, alpha] if beta is None else [c, d, alpha, beta]).to(g.device)
+        return x, r, pc[:p.n_local], g_out
+
+
+class RowBlockPower(RowBlockOps):
+    """PowerMethodGNN(num_iter).forward on a row block (PowerMethodGNN.py:296-334): halo exchange per SpMV plus
+    an all-reduce of the K (resp. 2K) partial sums per iteration."""
+
+    def forward(self, num_iter, b0):
+        from .plan import col_dot, col_scale_rsqrt
+        p = self.part
+        K = b0.shape[1]
+        buf = p.new_buffer(K, b0.dtype, b0.device)
+        buf[:p.n_local] = b0
+        y = torch.empty_like(b0)
+        nrm = torch.zeros(K, dtype=b0.dtype, device=b0.device)
+        for _ in range(int(num_iter)):
+            self.run(buf, lambda which: self.plan.spmm(buf, out=y, which=which))
+            ss = p.all_reduce_sum(col_dot(y, y))
+            buf[:p.n_local] = col_scale_rsqrt(y, ss)
+            nrm = torch.sqrt(ss)
+        self.run(buf, lambda which: self.plan.spmm(buf, out=y, which=which))
+        bl = buf[:p.n_local]
+        sums = p.all_reduce_sum(torch.stack([col_dot(bl, y), col_dot(bl, bl)]))
+        return bl.clone(), torch.stack([nrm, sums[0], sums[0] / sums[1]])

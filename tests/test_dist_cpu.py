@@ -1,0 +1,110 @@
+"""CPU, world_size 2, gloo: the row-block partition, column renumbering, send lists and the all-gather halo
+exchange of gnn_applied_linear_algebra_amd/dist.py.  The local arithmetic is supplied by the oracle
+(test infrastructure) so that the HOST LOGIC of the N > 1 path is what is under test; the HIP kernels behind the
+same partition are covered by tests/test_gpu_dist.py on the GPU box."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import reference_port as rp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_spmv(part, ev_local, X):
+    ei = part.edge_index_local
+    return rp.scatter_sum(ev_local * X[ei[1]], ei[0], part.n_local)
+
+
+def _worker(rank, world, port, kind, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnn_applied_linear_algebra_amd.dist import RowBlockPartition
+        gen = torch.Generator().manual_seed(7)
+        if kind == "laplacian":
+            Nx, Ny = 6, 9
+            ei, ev = rp.laplacianfun_torch(Nx, Ny)
+            n = Nx * Ny
+            cuts = [0, 4 * Nx, n]                         # uneven blocks: 4 and 5 grid lines
+        else:                                             # random sparse, ragged rows, far couplings
+            n = 57
+            ei = torch.randint(0, n, (2, 400), generator=gen)
+            ei = ei[:, torch.argsort(ei[0], stable=True)]
+            ev = torch.rand(400, 1, generator=gen, dtype=torch.float64) - 0.5
+            cuts = [0, 20, n]
+        K = 3
+        X = torch.rand(n, K, generator=gen, dtype=torch.float64)
+        B = torch.rand(n, K, generator=gen, dtype=torch.float64)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        m = (ei[0] >= lo) & (ei[0] < hi)
+        part = RowBlockPartition(ei[:, m], n, lo, hi)
+        ev_l = ev[m]
+        assert part.edge_index_local[0].min() >= 0 and part.edge_index_local[0].max() < part.n_local
+        assert part.edge_index_local[1].max() < part.n_cols_local
+        # y = A x through exchange + local SpMV == rows [lo, hi) of the single-process result
+        buf = part.new_buffer(K, torch.float64, "cpu")
+        buf[:part.n_local] = X[lo:hi]
+        part.exchange(buf)
+        y = _local_spmv(part, ev_l, buf)
+        y_ref = rp.scatter_sum(ev * X[ei[1]], ei[0], n)[lo:hi]
+        assert torch.equal(y, y_ref), (y - y_ref).abs().max()
+        # async exchange overlapping "interior" work, then 5 Jacobi sweeps with ping-pong buffers
+        diag = torch.full((n, 1), -4.0, dtype=torch.float64)
+        cur, nxt = part.new_buffer(K, torch.float64, "cpu"), part.new_buffer(K, torch.float64, "cpu")
+        cur[:part.n_local] = X[lo:hi]
+        xs = X.clone()
+        for _ in range(5):
+            work = part.exchange(cur, async_op=True)
+            if work is not None:
+                work.wait()
+            c = _local_spmv(part, ev_l, cur)
+            nxt[:part.n_local] = cur[:part.n_local] + 0.7 * (B[lo:hi] - c) / diag[lo:hi]
+            cur, nxt = nxt, cur
+            xs = xs + 0.7 * (B - rp.scatter_sum(ev * xs[ei[1]], ei[0], n)) / diag
+        assert torch.equal(cur[:part.n_local], xs[lo:hi])
+        # global reduction site (power method): all-reduce of partial column sums
+        s = part.all_reduce_sum((X[lo:hi] * X[lo:hi]).sum(0))
+        torch.testing.assert_close(s, (X * X).sum(0), rtol=1e-14, atol=0)
+        q.put((rank, "ok", part.S, part.n_send))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc(), 0, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["laplacian", "random"])
+def test_row_block_partition_world2(kind):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, S, n_send in sorted(res):
+        assert status == "ok", f"rank {rank}: {status}"
+    if kind == "laplacian":
+        assert all(r[2] == 6 and r[3] == 6 for r in res)          # one grid line of 6 vertices each way
+
+
+def test_single_process_partition_is_identity():
+    from gnn_applied_linear_algebra_amd.dist import RowBlockPartition
+    ei, ev = rp.laplacianfun_torch(5)
+    part = RowBlockPartition(ei, 25, 0, 25)
+    assert part.world == 1 and part.S == 0 and part.n_cols_local == 25
+    assert torch.equal(part.edge_index_local, ei)
