@@ -407,3 +407,28 @@ def test_full_size_jacobi():
     r0 = torch.linalg.norm(res(torch.cat([d(b), xs], 1), ei, ev))
     r20 = torch.linalg.norm(res(torch.cat([d(b), x20], 1), ei, ev))
     assert r20 < r0
+
+
+def test_full_size_20_sweeps_and_cheby_vs_c_oracle():
+    """BASELINE config 2 in full: 20 Jacobi sweeps and a degree-4 Chebyshev relaxation at 4096^2, bit-exact against
+    the single-threaded C restatement (oracle/gla_oracle.c, pinned by the golden vectors)."""
+    import c_oracle
+    N = 4096
+    n = N * N
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    gen = torch.Generator().manual_seed(24601)
+    b = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    x = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    A = c_oracle.Csr(ei.cpu().numpy(), ev.cpu().numpy(), n)
+    diag = torch.full((n, 1), -4.0, dtype=torch.float64)
+    ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+    got = gla.JacobiGNN.JacobiGNN()(20, d(torch.cat([diag, b, x], 1)), ei, ea, torch.tensor([0.7], dtype=torch.float64))
+    want = A.jacobi(diag.numpy(), b.numpy(), x.numpy(), 0.7, 20)
+    eq(got, want)
+    va, _, g = gla.ChebyGNN.ChebyRelaxGNN(4, return_edge_attr=False)(
+        d(torch.cat([b, x], 1)), ei, ev, torch.tensor([-3.4, -4.0], dtype=torch.float64))
+    xo, r, p, gw = A.cheby(b.numpy(), x.numpy(), -3.4, -4.0, 4)
+    eq(va[:, 1], xo)
+    eq(va[:, 2], r)
+    eq(va[:, 3], p)
+    eq(g, gw)

@@ -171,3 +171,36 @@ def test_fem_known_answer():
     A = torch.sparse_coo_tensor(ei, ev.flatten(), (36, 36)).to_dense()
     np.testing.assert_allclose(A[14, 14], 8 / 3, rtol=1e-14)      # alpha = 1 -> 8/3, -1/3 x 8
     np.testing.assert_allclose(A[14, [7, 8, 9, 13, 15, 19, 20, 21]], -1 / 3, rtol=1e-14)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the C restatement (oracle/gla_oracle.c) against the same golden vectors: bit-exact
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", GOLDEN_SIZES)
+def test_c_oracle_golden(golden, N):
+    import c_oracle
+    n = N * N
+    ei, ev = golden[f"lap{N}_ei"].astype(np.int64), golden[f"lap{N}_ev"]
+    perm = golden[f"N{N}_perm"].astype(np.int64)
+    b, x, X16 = golden[f"N{N}_b"], golden[f"N{N}_x"], golden[f"N{N}_X16"]
+    for e_i, e_v, tag in ((ei, ev, ""), (ei[:, perm], ev[perm], "perm_")):
+        A = c_oracle.Csr(e_i, e_v, n)
+        eq(A.spmm(x), golden[f"N{N}_matvec_{tag or 'k1_'}va"][:, 1:])
+    A = c_oracle.Csr(ei, ev, n)
+    eq(A.spmm(X16), golden[f"N{N}_matvec_k16_va"][:, 16:])
+    diag = -4 * np.ones(n)
+    for it in (1, 10, 20):
+        eq(A.jacobi(diag, b, x, 0.7, it), golden[f"N{N}_jacobi_w64_it{it}_x"])
+        eq(A.jacobi(diag, b, x, float(np.float32(0.7)), it), golden[f"N{N}_jacobi_w32_it{it}_x"])
+    c, d = golden[f"N{N}_cheby_g0"]
+    for deg in (1, 2, 3, 4, 8):
+        xo, r, p, g = A.cheby(b, x, c, d, deg)
+        va = golden[f"N{N}_cheby_deg{deg}_va"]
+        eq(xo, va[:, 1]); eq(r, va[:, 2]); eq(p, va[:, 3])
+        eq(g[:len(golden[f"N{N}_cheby_deg{deg}_g"])], golden[f"N{N}_cheby_deg{deg}_g"])
+    eio = golden[f"lap{N}_od_ei"].astype(np.int64)
+    Aod = c_oracle.Csr(eio, golden[f"N{N}_socr_ev"], n)
+    v, S = Aod.soc_classic(0.25)
+    eq(S, golden[f"N{N}_socr_S"])
+    w = Aod.direct_interp((S > 0).astype(np.float64), diag, golden[f"N{N}_split"].astype(np.float64))
+    eq(w, golden[f"N{N}_di_rnd_w"])
