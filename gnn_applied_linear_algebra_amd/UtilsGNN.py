@@ -64,6 +64,16 @@ def _ret(like, t):
 
 
 def coo_to_gnn_input(A):
-    """UtilsGNN.py:74-78: coalesced indices [2, nnz] and values [nnz, 1] of a torch sparse COO tensor."""
-    A = A.coalesce()
-    return A.indices(), A.values().reshape(-1, 1)
+    """UtilsGNN.py:74-78: coalesced indices [2, nnz] and values [nnz, 1] of a torch sparse COO tensor.
+    The pair is cached on the sparse tensor object so that repeated adapter calls (VCycle.py calls this on every
+    smoother / residual invocation, :63,77,96,141,157) reuse the same index tensor and hence its CSR plan."""
+    cached = getattr(A, "_gla_gnn_input", None)
+    if cached is not None:
+        return cached
+    Ac = A.coalesce()
+    out = (Ac.indices(), Ac.values().reshape(-1, 1))
+    try:
+        A._gla_gnn_input = out
+    except Exception:
+        pass
+    return out

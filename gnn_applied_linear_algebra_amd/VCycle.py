@@ -1,0 +1,233 @@
+"""Two-grid V-cycle glue -- mirror of /root/reference/pytorch/VCycle.py (functions :58-237, script body :239-277),
+plus the multi-level generalisation BASELINE config 5 asks for (`AMGHierarchy`).
+
+The reference is a whole-file script whose adapters read module-level globals (`N`, `SOCGNN`, `DIGNN`, `ResidualGNN`,
+`ChebyGNN`, `JacGNN`; VCycle.py:239-256).  The same names exist here as module attributes, created by `configure()`;
+the adapters keep the reference's names and argument lists.  Differences, all documented in SURVEY.md Appendix A:
+  * the C/F splitting is DATA (`configure(splitting=...)`, default every other vertex, matlab/test_vcycle.m:65-67)
+    instead of pyamg's randomised CLJP (VCycle.py:114);
+  * the true diagonal of A is used where the script hard-codes -4 (VCycle.py:117,165) -- identical on its matrix;
+  * P = (I + W)[:, C] is assembled sparse, without the dense n x n detour of VCycle.py:129-137.
+Smoothers, residual, strength of connection and interpolation weights run in libgla_hip kernels; restriction and
+prolongation are SpMVs on cached plans of P^T / P; the Galerkin product P^T (A P) (setup, VCycle.py:209) uses
+torch's device sparse-sparse product for now.
+"""
+import torch
+
+from ._common import compute_device, plan_for, to_dev
+from .ChebyGNN import ChebyRelaxGNN
+from .DirectInterpGNN import DirectInterpGNN
+from .GNNResidual import GNNResidual
+from .JacobiGNN import JacobiGNN
+from .SOCClassicGNN import SOCClassicGNN
+from .UtilsGNN import coo_to_gnn_input, remove_diag_entries
+
+# module-level state, as in the reference script (VCycle.py:239-256)
+N = None
+theta = 0.25
+cheb_deg = 4
+SOCGNN = DIGNN = ResidualGNN = ChebyGNN = JacGNN = None
+_splitting = None
+
+
+def default_splitting(n, device):
+    s = torch.zeros(n, dtype=torch.int64, device=device)
+    s[0::2] = 1
+    return s
+
+
+def configure(theta_=0.25, cheb_deg_=4, splitting=None, N_=None):
+    """Create the GNN modules (VCycle.py:251-256).  splitting: callable(S_matrix_coo, n) -> int vector, 1 = C point."""
+    global theta, cheb_deg, SOCGNN, DIGNN, ResidualGNN, ChebyGNN, JacGNN, _splitting, N
+    theta, cheb_deg, N = theta_, cheb_deg_, N_
+    SOCGNN = SOCClassicGNN(theta)
+    DIGNN = DirectInterpGNN()
+    ResidualGNN = GNNResidual()
+    ChebyGNN = ChebyRelaxGNN(cheb_deg, return_edge_attr=False)
+    JacGNN = JacobiGNN()
+    _splitting = splitting
+
+
+def _ready():
+    if SOCGNN is None:
+        configure()
+
+
+def _dev(A):
+    dev = compute_device(A)
+    return dev, (A if A.device == dev else A.to(dev))
+
+
+def _diag_of(edgeij_pair, edge_attr, n):
+    """True diagonal of A as [n, 1] (zero where the matrix stores none)."""
+    d = torch.zeros((n, 1), dtype=edge_attr.dtype, device=edge_attr.device)
+    m = edgeij_pair[0] == edgeij_pair[1]
+    d[edgeij_pair[0][m], 0] = edge_attr[m, 0]
+    return d
+
+
+def runResidual(A, b, x):
+    """VCycle.py:58-70: r = b - A x."""
+    _ready()
+    dev, A = _dev(A)
+    edgeij_pair, edge_attr = coo_to_gnn_input(A)
+    return ResidualGNN(torch.cat([to_dev(b, dev), to_dev(x, dev)], 1), edgeij_pair, edge_attr)
+
+
+def runSOC(A):
+    """VCycle.py:72-92: boolean strong-connection flags of the off-diagonal edges, [nnz_od, 1]."""
+    _ready()
+    dev, A = _dev(A)
+    edgeij_pair, edge_attr = remove_diag_entries(*coo_to_gnn_input(A))
+    vertex_attr = torch.zeros((A.shape[0], 1), dtype=edge_attr.dtype, device=dev)
+    return SOCGNN(vertex_attr, edgeij_pair, edge_attr).reshape(-1, 1) > 0
+
+
+def runDirectInterp(A, S, N=None, splitting=None):
+    """VCycle.py:94-137: prolongation operator P = (I + W)[:, C] as a sparse COO tensor [n, n_c]."""
+    _ready()
+    dev, A = _dev(A)
+    n = A.shape[0]
+    ei_all, ea_all = coo_to_gnn_input(A)
+    edgeij_pair, edge_attr = remove_diag_entries(ei_all, ea_all)
+    dt = edge_attr.dtype
+    if splitting is None:
+        if _splitting is not None:
+            S_matrix = torch.sparse_coo_tensor(edgeij_pair, to_dev(S, dev).flatten().to(dt), (n, n)).coalesce()
+            splitting = _splitting(S_matrix, n)
+        else:
+            splitting = default_splitting(n, dev)
+    splitting = torch.as_tensor(splitting).to(dev).reshape(-1)
+    vertex_attr = torch.hstack([_diag_of(ei_all, ea_all, n), splitting.reshape(-1, 1).to(dt)])
+    w_ij = DIGNN(vertex_attr, edgeij_pair, torch.hstack([edge_attr, to_dev(S, dev).to(dt)]), None)
+    # sparse (I + W)[:, C]: keep edges whose column is a C point, plus the identity entries of the C rows
+    is_c = splitting > 0
+    cmap = torch.cumsum(is_c.to(torch.int64), 0) - 1
+    keep = is_c[edgeij_pair[1]]
+    c_rows = torch.nonzero(is_c).reshape(-1)
+    rows = torch.cat([edgeij_pair[0][keep], c_rows])
+    cols = torch.cat([cmap[edgeij_pair[1][keep]], cmap[c_rows]])
+    vals = torch.cat([w_ij[keep], torch.ones(c_rows.numel(), dtype=dt, device=dev)])
+    return torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (n, int(is_c.sum()))).coalesce()
+
+
+def runCheby(A, b, x, c, d):
+    """VCycle.py:139-154: Chebyshev relaxation of degree cheb_deg with eigen-bounds (c, d)."""
+    _ready()
+    dev, A = _dev(A)
+    edgeij_pair, edge_attr = coo_to_gnn_input(A)
+    vertex_attr = torch.cat([to_dev(b, dev), to_dev(x, dev)], 1)
+    vertex_attr, _, _ = ChebyGNN(vertex_attr, edgeij_pair, edge_attr, torch.tensor([c, d]))
+    return vertex_attr[:, 1].reshape(-1, 1)
+
+
+def runJacobi(n_iters, w, A, b, x):
+    """VCycle.py:156-173: n_iters weighted-Jacobi sweeps."""
+    _ready()
+    dev, A = _dev(A)
+    edgeij_pair, edge_attr = coo_to_gnn_input(A)
+    diag_vals = _diag_of(edgeij_pair, edge_attr, A.shape[0])
+    edge_attr = torch.cat([edge_attr, torch.zeros_like(edge_attr)], 1)
+    vertex_attr = torch.cat([diag_vals, to_dev(b, dev), to_dev(x, dev)], 1)
+    return JacGNN(n_iters, vertex_attr, edgeij_pair, edge_attr, torch.tensor(w).reshape(-1))
+
+
+def _spmv(M, v):
+    """Sparse COO matrix times dense [n, K] on a cached libgla_hip plan (restriction / prolongation)."""
+    ei, ea = coo_to_gnn_input(M)
+    plan = plan_for(ei, M.shape[0], M.shape[1], edge_attr=ea)
+    return plan.spmm(v.contiguous())
+
+
+def runVCycle(A, b, x, n_presmooth, n_postsmooth, n_coarsesolve, use_jacobi=True):
+    """VCycle.py:175-237: one two-grid cycle (pre-smooth, SOC, DI, Galerkin, residual, restrict, Chebyshev coarse
+    'solve', prolong + correct, post-smooth).  n_coarsesolve is accepted and unused, as in the reference."""
+    _ready()
+    dev, A = _dev(A)
+    b, x = to_dev(b, dev), to_dev(x, dev)
+    if use_jacobi:
+        x = runJacobi(n_presmooth, 0.7, A, b, x)
+    else:
+        x = runCheby(A, b, x, -3.461, -4.0)
+    S = runSOC(A)
+    P = runDirectInterp(A, S, N)
+    Pt = P.t().coalesce()
+    Ac = torch.sparse.mm(Pt, torch.sparse.mm(A, P)).coalesce()           # VCycle.py:209
+    r = runResidual(A, b, x)
+    rc = _spmv(Pt, r)                                                    # :215
+    xc = runCheby(Ac, rc, torch.zeros_like(rc), -3.4, -4.0)              # :218-223
+    x = x + _spmv(P, xc)                                                 # :226
+    if use_jacobi:
+        x = runJacobi(n_postsmooth, 0.7, A, b, x)
+    else:
+        x = runCheby(A, b, x, -3.4, -4.0)
+    return x
+
+
+class AMGHierarchy:
+    """Multi-level generalisation (BASELINE config 5: 3 levels): the same five operators applied recursively, with
+    the setup (SOC -> splitting -> DI -> P -> Galerkin) done ONCE instead of every cycle.
+
+    cycle(): weighted Jacobi pre/post smoothing on every level but the coarsest, Chebyshev relaxation of degree
+    cheb_deg as the coarsest 'solve', eigen-bounds from a few power iterations of D^-1-free A (lambda_max) when not
+    supplied."""
+
+    def __init__(self, A, levels=3, theta_=0.25, cheb_deg_=4, splitting=None, w=0.7, n_pre=3, n_post=3,
+                 coarse_bounds=None):
+        dev, A = _dev(A)
+        self.w, self.n_pre, self.n_post = w, n_pre, n_post
+        self.soc, self.di = SOCClassicGNN(theta_), DirectInterpGNN()
+        self.res, self.jac = GNNResidual(), JacobiGNN()
+        self.cheby = ChebyRelaxGNN(cheb_deg_, return_edge_attr=False)
+        self.A, self.P, self.Pt, self.gnn = [A.coalesce()], [], [], []
+        for _ in range(levels - 1):
+            Al = self.A[-1]
+            n = Al.shape[0]
+            ei_all, ea_all = coo_to_gnn_input(Al)
+            ei, ea = remove_diag_entries(ei_all, ea_all)
+            S = self.soc(torch.zeros((n, 1), dtype=ea.dtype, device=dev), ei, ea).reshape(-1, 1) > 0
+            split = (splitting(Al, S, n) if splitting is not None else default_splitting(n, dev)).to(dev).reshape(-1)
+            va = torch.hstack([_diag_of(ei_all, ea_all, n), split.reshape(-1, 1).to(ea.dtype)])
+            w_ij = self.di(va, ei, torch.hstack([ea, S.to(ea.dtype)]), None)
+            is_c = split > 0
+            cmap = torch.cumsum(is_c.to(torch.int64), 0) - 1
+            keep = is_c[ei[1]] & ~is_c[ei[0]]                      # F rows interpolate from C columns
+            c_rows = torch.nonzero(is_c).reshape(-1)
+            rows = torch.cat([ei[0][keep], c_rows])
+            cols = torch.cat([cmap[ei[1][keep]], cmap[c_rows]])
+            vals = torch.cat([w_ij[keep], torch.ones(c_rows.numel(), dtype=ea.dtype, device=dev)])
+            P = torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (n, int(is_c.sum()))).coalesce()
+            Pt = P.t().coalesce()
+            self.P.append(P)
+            self.Pt.append(Pt)
+            self.A.append(torch.sparse.mm(Pt, torch.sparse.mm(Al, P)).coalesce())
+        # per-level GNN inputs, built once
+        for Al in self.A:
+            ei, ea = coo_to_gnn_input(Al)
+            self.gnn.append((ei, ea, torch.cat([ea, torch.zeros_like(ea)], 1), _diag_of(ei, ea, Al.shape[0])))
+        if coarse_bounds is None:
+            ei, ea, _, dg = self.gnn[-1]
+            lmax = float(dg.abs().max()) * 2.0                      # Gershgorin-style bound for these M-matrices
+            sign = -1.0 if float(dg.sum()) < 0 else 1.0
+            coarse_bounds = (sign * 0.45 * lmax, sign * 0.55 * lmax)    # (c, d): spectrum in d +- c
+        self.coarse_bounds = coarse_bounds
+
+    def residual(self, b, x, level=0):
+        ei, ea, _, _ = self.gnn[level]
+        return self.res(torch.cat([b, x], 1), ei, ea)
+
+    def _smooth(self, level, n_it, b, x):
+        ei, _, ea2, dg = self.gnn[level]
+        return self.jac(n_it, torch.cat([dg, b, x], 1), ei, ea2, torch.tensor([self.w], dtype=b.dtype))
+
+    def cycle(self, b, x, level=0):
+        if level == len(self.A) - 1:
+            ei, ea, _, _ = self.gnn[level]
+            va, _, _ = self.cheby(torch.cat([b, x], 1), ei, ea, torch.tensor(self.coarse_bounds, dtype=b.dtype))
+            return va[:, 1].reshape(-1, 1)
+        x = self._smooth(level, self.n_pre, b, x)
+        r = self.residual(b, x, level)
+        rc = _spmv(self.Pt[level], r)
+        xc = self.cycle(rc, torch.zeros_like(rc), level + 1)
+        x = x + _spmv(self.P[level], xc)
+        return self._smooth(level, self.n_post, b, x)

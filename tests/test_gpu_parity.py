@@ -432,3 +432,75 @@ def test_full_size_20_sweeps_and_cheby_vs_c_oracle():
     eq(va[:, 2], r)
     eq(va[:, 3], p)
     eq(g, gw)
+
+
+# ---------------------------------------------------------------------------------------------------
+# V-cycle glue
+# ---------------------------------------------------------------------------------------------------
+def test_vcycle_script_fp32(golden):
+    """The reference's fp32 two-grid script (VCycle.py:239-277, N=5, stand-in splitting), 5 cycles.  Everything
+    but the Galerkin product (torch's device sparse product, re-associated sums) is bit-faithful, so the iterates
+    agree to fp32 rounding."""
+    V = gla.VCycle
+    V.configure(0.25, 4, N_=5)
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(5, device=DEV)
+    A = torch.sparse_coo_tensor(ei, ev.flatten(), dtype=torch.float)
+    b, x = d(t(golden["vcycle_b"])), d(t(golden["vcycle_x0"]))
+    r0 = float(torch.norm(V.runResidual(A, b, x)))
+    for k in range(5):
+        x = V.runVCycle(A, b, x, 3, 3, 5, True)
+        np.testing.assert_allclose(x.cpu().numpy(), golden["vcycle_xs"][k], rtol=2e-4, atol=2e-6)
+    res = float(torch.norm(V.runResidual(A, b, x)))
+    assert res < 1e-5 * r0 * 10 and x.dtype == torch.float32
+    # the adapters on their own, bit-exact against the oracle (fp32)
+    A_c = torch.sparse_coo_tensor(ei.cpu(), ev.cpu().flatten(), dtype=torch.float)
+    b_c, x_c = t(golden["vcycle_b"]), t(golden["vcycle_x0"])
+    ei_c, ea_c = rp.coo_to_gnn_input(A_c)
+    diag = -4 * torch.ones((25, 1), dtype=torch.float)
+    eq(V.runJacobi(3, 0.7, A, d(b_c), d(x_c)),
+       rp.jacobi_forward(3, torch.cat([diag, b_c, x_c], 1), ei_c, torch.cat([ea_c, torch.zeros_like(ea_c)], 1),
+                         torch.tensor(0.7).reshape(-1)))
+    eq(V.runResidual(A, d(b_c), d(x_c)), rp.residual_forward(torch.cat([b_c, x_c], 1), ei_c, ea_c))
+    eq(V.runCheby(A, d(b_c), d(x_c), -3.4, -4.0),
+       rp.cheby_forward(4, torch.cat([b_c, x_c], 1), ei_c, ea_c, torch.tensor([-3.4, -4.0]))[0][:, 1:2])
+    S = V.runSOC(A)
+    eio, evo = rp.remove_diag_entries(ei_c, ea_c)
+    eq(S, rp.soc_classic_forward(0.25, torch.zeros((25, 1)), eio, evo).reshape(-1, 1) > 0)
+    split = torch.zeros(25, dtype=torch.int64)
+    split[0::2] = 1
+    P = V.runDirectInterp(A, S, 5)
+    P_w = rp.vcycle_interp_P(A_c, S.cpu(), split, diag)
+    eq(P.to_dense(), P_w.to_dense())
+
+
+def test_amg_hierarchy():
+    """Multi-level generalisation: (1) with 2 levels and the script's parameters it IS runVCycle; (2) BASELINE
+    config 5 shape (small): 3 levels on the Q1 FEM mesh -- finite, monotonically contracting residual (the coarsest
+    'solve' is a degree-4 Chebyshev relaxation as in the reference, so the rate is modest by construction)."""
+    V = gla.VCycle
+    V.configure(0.25, 4, N_=5)
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(5, device=DEV)
+    A = torch.sparse_coo_tensor(ei, ev.flatten(), dtype=torch.float)
+    gen = torch.Generator().manual_seed(4)
+    b, x = d(torch.rand(25, 1, generator=gen)), d(torch.rand(25, 1, generator=gen))
+    H = V.AMGHierarchy(A, levels=2, coarse_bounds=(-3.4, -4.0))
+    xa, xb = x, x
+    for _ in range(3):
+        xa = H.cycle(b, xa)
+        xb = V.runVCycle(A, b, xb, 3, 3, 5, True)
+        eq(xa, xb)
+    m = 96
+    ei, ev = rp.heateqnfem2dfun([m + 1, m + 1], [1.0, 1.0])
+    n = m * m
+    A = torch.sparse_coo_tensor(d(ei), d(-ev.flatten()), (n, n))     # negative-definite convention of the reference
+    H = V.AMGHierarchy(A, levels=3)
+    assert len(H.A) == 3 and H.A[1].shape[0] < n and H.A[2].shape[0] < H.A[1].shape[0]
+    b = d(torch.rand(n, 1, generator=gen, dtype=torch.float64))
+    x = torch.zeros_like(b)
+    norms = [float(torch.norm(H.residual(b, x)))]
+    for _ in range(6):
+        x = H.cycle(b, x)
+        norms.append(float(torch.norm(H.residual(b, x))))
+    assert all(np.isfinite(norms)) and all(b_ < a_ for a_, b_ in zip(norms, norms[1:])), norms
+    r_w = rp.residual_forward(torch.cat([b.cpu(), x.cpu()], 1), *rp.coo_to_gnn_input(A.cpu()))
+    eq(H.residual(b, x), r_w)
