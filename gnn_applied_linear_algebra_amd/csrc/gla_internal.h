@@ -36,6 +36,7 @@ struct gla_csr {
 struct gla_tuning {
   int spmv_variant = 0;     // experimental kernel selection for K = 1 (see launch_rows)
   int tile_nnz = 0;         // 0 = automatic (256 * average row length)
+  int spmm_variant = 0;     // 0 = paired-rhs 16-byte kernel when alignment allows, 1 = scalar lanes
 };
 extern gla_tuning g_tuning;
 

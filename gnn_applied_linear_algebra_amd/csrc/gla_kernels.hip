@@ -45,74 +45,110 @@ __device__ __forceinline__ int map_tile(const TileMap& m) {
 // ------------------------------------------------------------------------------------------------
 // fused vertex updates ("epilogues"): called once per (row, rhs) with the finished row sum
 // ------------------------------------------------------------------------------------------------
-// Each epilogue is split into load() -- the row's dense operands, issued EARLY so their latency overlaps the
-// nnz stream -- and apply() with the finished row sum.  operator() = both, for kernels that do not prefetch.
-struct NoPre {};
+// Each epilogue is split into load -- the row's dense operands, issued EARLY so their latency overlaps the
+// nnz stream -- and apply with the finished row sum.  Both are generic in the value type V: V = T for one
+// right-hand side per lane, V = T2 (16-byte accesses) for two adjacent right-hand sides per lane.
+// operator() = load + apply for kernels that do not prefetch.
+template <typename V, typename T>
+__device__ __forceinline__ V ldv(const T* p) { return *reinterpret_cast<const V*>(p); }
+template <typename V, typename T>
+__device__ __forceinline__ void stv(T* p, V v) { *reinterpret_cast<V*>(p) = v; }
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define GLA_EPI_SCALAR_API                                                                            \
+  typedef PreV<T> Pre;                                                                                \
+  __device__ __forceinline__ Pre load(int64_t r, int k) const { return loadv<T>(r, k); }              \
+  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& p) const {                \
+    applyv<T>(r, k, acc, p);                                                                          \
+  }                                                                                                   \
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {                         \
+    applyv<T>(r, k, acc, loadv<T>(r, k));                                                             \
+  }
 
 template <typename T>
 struct EpiStore {                       // y = A x                       MatVecGNN.py:95-114
   T* y; int64_t ldy;
-  typedef NoPre Pre;
-  __device__ __forceinline__ Pre load(int64_t, int) const { return Pre{}; }
-  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre&) const { y[r * ldy + k] = acc; }
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
+  template <typename V> struct PreV {};
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t, int) const { return PreV<V>{}; }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>&) const {
+    stv<V>(y + r * ldy + k, acc);
+  }
+  bool vec2_ok() const { return al16(y) && ldy % 2 == 0; }
+  GLA_EPI_SCALAR_API
 };
 
 template <typename T>
 struct EpiResidual {                    // r = b - A x                   GNNResidual.py:97-118
   const T* b; int64_t ldb; T* res; int64_t ldr;
-  struct Pre { T b; };
-  __device__ __forceinline__ Pre load(int64_t r, int k) const { return Pre{b[r * ldb + k]}; }
-  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& p) const {
-    res[r * ldr + k] = p.b - acc;
+  template <typename V> struct PreV { V b; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{ldv<V>(b + r * ldb + k)};
   }
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& p) const {
+    stv<V>(res + r * ldr + k, p.b - acc);
+  }
+  bool vec2_ok() const { return al16(b) && al16(res) && ldb % 2 == 0 && ldr % 2 == 0; }
+  GLA_EPI_SCALAR_API
 };
 
 template <typename T>
 struct EpiJacobi {                      // x + (w*(b - A x))/A_ii        JacobiGNN.py:100-123 (:119)
   const T* diag; const T* b; int64_t ldb; const T* x; int64_t ldx; T* xo; int64_t ldxo; T w;
-  struct Pre { T d, b, x; };
-  __device__ __forceinline__ Pre load(int64_t r, int k) const {
-    return Pre{diag[r], b[r * ldb + k], x[r * ldx + k]};
+  template <typename V> struct PreV { T d; V b, x; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{diag[r], ldv<V>(b + r * ldb + k), ldv<V>(x + r * ldx + k)};
   }
-  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& p) const {
-    xo[r * ldxo + k] = p.x + (w * (p.b - acc)) / p.d;
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& p) const {
+    stv<V>(xo + r * ldxo + k, p.x + (w * (p.b - acc)) / p.d);
   }
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
+  bool vec2_ok() const {
+    return al16(b) && al16(x) && al16(xo) && ldb % 2 == 0 && ldx % 2 == 0 && ldxo % 2 == 0;
+  }
+  GLA_EPI_SCALAR_API
 };
 
 template <typename T>
 struct EpiChebyFirst {                  // r = b - A x; p = r; x += alpha p    ChebyGNN.py:91-163
   const T* b; int64_t ldb; const T* x; int64_t ldx; T* res; int64_t ldr; T* p; int64_t ldp;
   T* xo; int64_t ldxo; T alpha;
-  struct Pre { T b, x; };
-  __device__ __forceinline__ Pre load(int64_t r, int k) const { return Pre{b[r * ldb + k], x[r * ldx + k]}; }
-  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& q) const {
-    const T ri = q.b - acc;
-    res[r * ldr + k] = ri;
-    p[r * ldp + k] = ri;
-    xo[r * ldxo + k] = q.x + alpha * ri;
+  template <typename V> struct PreV { V b, x; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{ldv<V>(b + r * ldb + k), ldv<V>(x + r * ldx + k)};
   }
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& q) const {
+    const V ri = q.b - acc;
+    stv<V>(res + r * ldr + k, ri);
+    stv<V>(p + r * ldp + k, ri);
+    stv<V>(xo + r * ldxo + k, q.x + alpha * ri);
+  }
+  bool vec2_ok() const {
+    return al16(b) && al16(x) && al16(res) && al16(p) && al16(xo) && ldb % 2 == 0 && ldx % 2 == 0 &&
+           ldr % 2 == 0 && ldp % 2 == 0 && ldxo % 2 == 0;
+  }
+  GLA_EPI_SCALAR_API
 };
 
 template <typename T>
 struct EpiChebyNext {                   // r -= a_old*(A p); p = r + beta p; x += a_new p   ChebyGNN.py:186-243
   const T* p; int64_t ldp; T* po; int64_t ldpo; T* res; int64_t ldr; T* x; int64_t ldx;
   T a_old, a_new, beta;
-  struct Pre { T r, p, x; };
-  __device__ __forceinline__ Pre load(int64_t r, int k) const {
-    return Pre{res[r * ldr + k], p[r * ldp + k], x[r * ldx + k]};
+  template <typename V> struct PreV { V r, p, x; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{ldv<V>(res + r * ldr + k), ldv<V>(p + r * ldp + k), ldv<V>(x + r * ldx + k)};
   }
-  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& q) const {
-    const T ri = q.r - a_old * acc;
-    res[r * ldr + k] = ri;
-    const T pn = ri + beta * q.p;
-    po[r * ldpo + k] = pn;
-    x[r * ldx + k] = q.x + a_new * pn;
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& q) const {
+    const V ri = q.r - a_old * acc;
+    stv<V>(res + r * ldr + k, ri);
+    const V pn = ri + beta * q.p;
+    stv<V>(po + r * ldpo + k, pn);
+    stv<V>(x + r * ldx + k, q.x + a_new * pn);
   }
-  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const { apply(r, k, acc, load(r, k)); }
+  bool vec2_ok() const {
+    return al16(p) && al16(po) && al16(res) && al16(x) && ldp % 2 == 0 && ldpo % 2 == 0 && ldr % 2 == 0 &&
+           ldx % 2 == 0;
+  }
+  GLA_EPI_SCALAR_API
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -122,50 +158,6 @@ template <bool NT, typename U>
 __device__ __forceinline__ U ld_stream(const U* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
   else return *p;
-}
-
-// NPT = nnz per thread issued back to back (memory-level parallelism); NT = non-temporal val/col loads
-template <typename T, class Epi, int NPT, bool NT>
-__global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
-    const T* __restrict__ x, TileMap tm, Epi epi) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* prod = reinterpret_cast<T*>(smem_raw);
-  const int t = map_tile(tm);
-  if (t < 0) return;
-  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
-  if (r0 >= r1) return;
-  const int s = rowptr[r0];
-  const int len = rowptr[r1] - s;
-  const int tid = threadIdx.x;
-
-  for (int base = 0; base < len; base += GLA_BLOCK * NPT) {
-    T v[NPT];
-    int c[NPT];
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) {
-      const int i = base + u * GLA_BLOCK + tid;
-      const bool ok = i < len;
-      c[u] = ok ? ld_stream<NT>(col + s + i) : 0;
-      v[u] = ok ? ld_stream<NT>(val + s + i) : T(0);
-    }
-    T xv[NPT];
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) xv[u] = x[c[u]];
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) {
-      const int i = base + u * GLA_BLOCK + tid;
-      if (i < len) prod[i] = v[u] * xv[u];
-    }
-  }
-  __syncthreads();
-
-  for (int r = r0 + tid; r < r1; r += GLA_BLOCK) {
-    const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
-    T acc = T(0);
-    for (int j = a; j < b; ++j) acc = acc + prod[j];
-    epi((int64_t)r, 0, acc);
-  }
 }
 
 // Main K = 1 kernel: 16-byte val loads / 8-byte col loads -- each lane owns PAIRS of consecutive nnz; the tile's
@@ -216,7 +208,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
     }
     T2 xv[PPT];
 #pragma unroll
-    for (int u = 0; u < PPT; ++u) { xv[u].x = x[c[u].x]; xv[u].y = x[c[u].y]; }
+    for (int u = 0; u < PPT; ++u) {
+      xv[u].x = x[c[u].x];
+      xv[u].y = x[c[u].y];
+    }
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       T2 p;
@@ -286,6 +281,83 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_kernel(
   }
 }
 
+// K even: lanes = (row, PAIR of adjacent rhs) with 16-byte X / epilogue accesses.  val, col AND the tile's row
+// offsets are staged in LDS, so phase 2 touches global memory only for the X gathers and the epilogue vectors.
+// A row's gathers are issued four at a time (independent 16-byte loads), its sum stays in edge order.
+// LPR = lanes per row (power of two >= K/2).  MODE 0: exact trip counts (4-batches + scalar tail);
+// MODE 1: branch-free clamped batches (surplus lanes re-read the last entry and are masked out of the sum).
+constexpr int SPMM_ROWCAP = 1024;               // row offsets staged per tile (more rows -> read rowptr directly)
+
+template <typename T, int LPR, int MODE, class Epi>
+__global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ X, int64_t ldx, int K, int lds_elems, TileMap tm, Epi epi) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  T* sval = reinterpret_cast<T*>(smem_raw);
+  int32_t* scol = reinterpret_cast<int32_t*>(sval + lds_elems);
+  int32_t* srow = scol + lds_elems;             // [SPMM_ROWCAP + 1] offsets relative to the tile's first nnz
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
+  if (r0 >= r1) return;
+  const int tid = threadIdx.x;
+  const int nrow_staged = min(r1 - r0, SPMM_ROWCAP);
+  for (int i = tid; i <= nrow_staged; i += GLA_BLOCK) srow[i] = rowptr[r0 + i] - s;
+  for (int i = tid; i < len; i += GLA_BLOCK) {
+    sval[i] = val[s + i];
+    scol[i] = col[s + i];
+  }
+  __syncthreads();
+  constexpr int RPP = GLA_BLOCK / LPR;          // rows per pass
+  const int k0 = (tid % LPR) * 2, rsub = tid / LPR;
+  for (int r = r0 + rsub; r < r1; r += RPP) {
+    int a, b;
+    if (r - r0 < SPMM_ROWCAP) { a = srow[r - r0]; b = srow[r - r0 + 1]; }
+    else { a = rowptr[r] - s; b = rowptr[r + 1] - s; }
+    for (int k = k0; k < K; k += 2 * LPR) {
+      const auto pre = epi.template loadv<T2>((int64_t)r, k);
+      T2 acc = {T(0), T(0)};
+      const T* Xk = X + k;
+      if constexpr (MODE == 0) {
+        int j = a;
+        for (; j + 4 <= b; j += 4) {
+          T2 xv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xv[u] = ldv<T2>(Xk + (int64_t)scol[j + u] * ldx);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = acc + sval[j + u] * xv[u];
+        }
+        if (j + 2 <= b) {
+          const T2 x0 = ldv<T2>(Xk + (int64_t)scol[j] * ldx), x1 = ldv<T2>(Xk + (int64_t)scol[j + 1] * ldx);
+          acc = acc + sval[j] * x0;
+          acc = acc + sval[j + 1] * x1;
+          j += 2;
+        }
+        if (j < b) acc = acc + sval[j] * ldv<T2>(Xk + (int64_t)scol[j] * ldx);
+      } else {
+        for (int j = a; j < b; j += 4) {
+          T v[4];
+          T2 xv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int jj = min(j + u, b - 1);
+            v[u] = sval[jj];
+            xv[u] = ldv<T2>(Xk + (int64_t)scol[jj] * ldx);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const T2 nxt = acc + v[u] * xv[u];
+            acc = (j + u < b) ? nxt : acc;
+          }
+        }
+      }
+      epi.template applyv<T2>((int64_t)r, k, acc, pre);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // fallback for plans with a row longer than the LDS tile: one wave per row, tree-ordered sum
 // ------------------------------------------------------------------------------------------------
@@ -344,35 +416,51 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   if (K == 1) {
     const size_t lds = (size_t)(A->lds_elems + 2) * sizeof(T);
-#define GLA_SPMV1(N_, NT_) \
-  hipLaunchKernelGGL((spmv_stream_kernel<T, Epi, N_, NT_>), grid, block, lds, st, A->rowptr, A->col, val, X, tm, epi)
 #define GLA_SPMV2(N_, NT_, PF_) \
   hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
                      X, tm, epi)
-    switch (g_tuning.spmv_variant) {
-      case 1: GLA_SPMV1(5, false); break;
-      case 2: GLA_SPMV1(4, false); break;
-      case 6: GLA_SPMV2(3, false, false); break;
-      case 7: GLA_SPMV2(2, false, false); break;
-      case 10: GLA_SPMV2(2, false, true); break;
-      case 11: GLA_SPMV2(4, false, true); break;
-      case 12: GLA_SPMV2(3, true, true); break;
+#define GLA_SPMV2(N_, NT_, PF_) \
+  hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
+                     X, tm, epi)
+    switch (g_tuning.spmv_variant) {          // A/B knobs (tools/ab_spmv.py); 0 is the tuned default
+      case 1: GLA_SPMV2(3, false, false); break;
+      case 2: GLA_SPMV2(2, false, true); break;
+      case 3: GLA_SPMV2(4, false, true); break;
+      case 4: GLA_SPMV2(3, true, true); break;
       default: GLA_SPMV2(3, false, true); break;
     }
-#undef GLA_SPMV1
 #undef GLA_SPMV2
   } else {
     const size_t lds = (size_t)A->lds_elems * (sizeof(T) + sizeof(int32_t));
+    const bool vec2 = (K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec2_ok() && g_tuning.spmm_variant != 1;
 #define GLA_SPMM_CASE(KP_)                                                                              \
   hipLaunchKernelGGL((spmm_stream_kernel<T, KP_, Epi>), grid, block, lds, st, A->rowptr, A->col, val, X, \
                      ldx, K, A->lds_elems, tm, epi)
-    if (K <= 2) GLA_SPMM_CASE(2);
+#define GLA_SPMM2_CASE(LPR_)                                                                                   \
+  do {                                                                                                         \
+    const size_t lds2 = lds + (SPMM_ROWCAP + 1) * sizeof(int32_t);                                             \
+    if (g_tuning.spmm_variant == 2)                                                                            \
+      hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, LPR_, 1, Epi>), grid, block, lds2, st, A->rowptr, A->col, \
+                         val, X, ldx, K, A->lds_elems, tm, epi);                                               \
+    else                                                                                                       \
+      hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, LPR_, 0, Epi>), grid, block, lds2, st, A->rowptr, A->col, \
+                         val, X, ldx, K, A->lds_elems, tm, epi);                                               \
+  } while (0)
+    if (vec2) {
+      if (K <= 2) GLA_SPMM2_CASE(1);
+      else if (K <= 4) GLA_SPMM2_CASE(2);
+      else if (K <= 8) GLA_SPMM2_CASE(4);
+      else if (K <= 16) GLA_SPMM2_CASE(8);
+      else if (K <= 32) GLA_SPMM2_CASE(16);
+      else GLA_SPMM2_CASE(32);
+    } else if (K <= 2) GLA_SPMM_CASE(2);
     else if (K <= 4) GLA_SPMM_CASE(4);
     else if (K <= 8) GLA_SPMM_CASE(8);
     else if (K <= 16) GLA_SPMM_CASE(16);
     else if (K <= 32) GLA_SPMM_CASE(32);
     else GLA_SPMM_CASE(64);
 #undef GLA_SPMM_CASE
+#undef GLA_SPMM2_CASE
   }
   GLA_LAUNCH_CHECK();
   return GLA_OK;

@@ -276,6 +276,7 @@ int gla_version(void) { return 100; }
 int gla_set_option(const char* name, int64_t value) {
   if (!name) return GLA_ERR_INVALID_ARG;
   if (!strcmp(name, "spmv_variant")) { g_tuning.spmv_variant = (int)value; return GLA_OK; }
+  if (!strcmp(name, "spmm_variant")) { g_tuning.spmm_variant = (int)value; return GLA_OK; }
   if (!strcmp(name, "tile_nnz")) {
     if (value != 0 && (value < 256 || value > GLA_LDS_ELEMS_MAX - 64)) return GLA_ERR_INVALID_ARG;
     g_tuning.tile_nnz = (int)value; return GLA_OK;
