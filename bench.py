@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- JacobiGNN sweeps/s on the 2-D Laplacian (BASELINE.json metric), 1..8 MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 4096] [--sweeps 20] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 4096] [--sweeps 20] [--no-cpu-baseline]
 
 A "step" is one `JacobiGNN.forward(n_iters=20, ...)` call (BASELINE config 2: 20 sweeps, 4096 x 4096
 Laplacian, fp64) through the drop-in nn.Module surface with all inputs resident in HBM: the per-call AoS
@@ -61,11 +61,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=4096, help="grid lines per rank and vertices per line")
+    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid lines per rank and vertices per line")
     ap.add_argument("--sweeps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sweeps", type=int, default=4)
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: exchange, then compute (no overlap)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: all ranks share cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,12 +78,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     import gnn_applied_linear_algebra_amd as gla
     from gnn_applied_linear_algebra_amd import UtilsGNN
@@ -133,7 +141,7 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

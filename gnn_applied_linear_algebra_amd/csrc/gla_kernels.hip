@@ -42,6 +42,19 @@ __device__ __forceinline__ int map_tile(const TileMap& m) {
   return m.tile_list ? m.tile_list[slot] : slot;
 }
 
+// Branch-free tile loop: every lane runs every iteration with its index clamped into [0, len) (lanes past the end
+// redo the last element and rewrite the identical value), so the loads of a batch are issued back to back instead
+// of one exec-masked load + wait at a time.  BODY_LOAD(u, i) fills per-slot registers, BODY_STORE(u, i) consumes.
+#define GLA_TILE_LOOP(len, tid, BODY_LOAD, BODY_STORE)                                  \
+  for (int base_ = 0; base_ < (len); base_ += 4 * GLA_BLOCK) {                          \
+    int ii_[4];                                                                         \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                     \
+      ii_[u] = min(base_ + u * GLA_BLOCK + (tid), (len)-1);                             \
+      BODY_LOAD(u, ii_[u]);                                                             \
+    }                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) { BODY_STORE(u, ii_[u]); }            \
+  }
+
 // ------------------------------------------------------------------------------------------------
 // fused vertex updates ("epilogues"): called once per (row, rhs) with the finished row sum
 // ------------------------------------------------------------------------------------------------
@@ -263,9 +276,14 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_kernel(
   const int s = rowptr[r0];
   const int len = rowptr[r1] - s;
   const int tid = threadIdx.x;
-  for (int i = tid; i < len; i += GLA_BLOCK) {
-    sval[i] = val[s + i];
-    scol[i] = col[s + i];
+  {
+    T v_[4];
+    int c_[4];
+#define MM_LD(u, i) { v_[u] = val[s + (i)]; c_[u] = col[s + (i)]; }
+#define MM_ST(u, i) { sval[i] = v_[u]; scol[i] = c_[u]; }
+    GLA_TILE_LOOP(len, tid, MM_LD, MM_ST)
+#undef MM_LD
+#undef MM_ST
   }
   __syncthreads();
   constexpr int RPP = GLA_BLOCK / KP;          // rows per pass
@@ -305,9 +323,14 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
   const int tid = threadIdx.x;
   const int nrow_staged = min(r1 - r0, SPMM_ROWCAP);
   for (int i = tid; i <= nrow_staged; i += GLA_BLOCK) srow[i] = rowptr[r0 + i] - s;
-  for (int i = tid; i < len; i += GLA_BLOCK) {
-    sval[i] = val[s + i];
-    scol[i] = col[s + i];
+  {
+    T v_[4];
+    int c_[4];
+#define MM_LD(u, i) { v_[u] = val[s + (i)]; c_[u] = col[s + (i)]; }
+#define MM_ST(u, i) { sval[i] = v_[u]; scol[i] = c_[u]; }
+    GLA_TILE_LOOP(len, tid, MM_LD, MM_ST)
+#undef MM_LD
+#undef MM_ST
   }
   __syncthreads();
   constexpr int RPP = GLA_BLOCK / LPR;          // rows per pass
@@ -475,17 +498,33 @@ inline int check_plan(gla_csr* A, int dtype, int K) {
 // ------------------------------------------------------------------------------------------------
 // edge-wise kernels (outputs in EDGE order)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int KC>          // KC > 0: compile-time K (division becomes a shift), 0: runtime K
 __global__ __launch_bounds__(GLA_BLOCK) void edge_products_kernel(
     const int32_t* __restrict__ col, const T* __restrict__ val, const int32_t* __restrict__ perm,
-    const T* __restrict__ X, int64_t ldx, T* __restrict__ C, int64_t ldc, int64_t nnz, int K) {
+    const T* __restrict__ X, int64_t ldx, T* __restrict__ C, int64_t ldc, int64_t nnz, int Krt) {
+  const int K = KC > 0 ? KC : Krt;
   const int64_t total = nnz * K;
-  for (int64_t idx = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * GLA_BLOCK) {
-    const int64_t p = idx / K;
-    const int k = (int)(idx - p * K);
-    const int64_t e = perm ? perm[p] : p;
-    C[e * ldc + k] = val[p] * X[(int64_t)col[p] * ldx + k];
+  // 4 independent (col -> X) chains per lane and iteration; indices clamped so the batch is branch-free
+  for (int64_t base = (int64_t)blockIdx.x * (GLA_BLOCK * 4) + threadIdx.x; base < total;
+       base += (int64_t)gridDim.x * (GLA_BLOCK * 4)) {
+    int64_t e[4];
+    int k[4];
+    T v[4];
+    int c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t idx = min(base + (int64_t)u * GLA_BLOCK, total - 1);
+      const int64_t p = idx / K;
+      k[u] = (int)(idx - p * K);
+      e[u] = perm ? (int64_t)perm[p] : p;
+      v[u] = val[p];
+      c[u] = col[p];
+    }
+    T xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = X[(int64_t)c[u] * ldx + k[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) C[e[u] * ldc + k[u]] = v[u] * xv[u];
   }
 }
 
@@ -501,12 +540,18 @@ __global__ __launch_bounds__(GLA_BLOCK) void soc_classic_kernel(
   T* sv = reinterpret_cast<T*>(smem_raw);
   const int t = map_tile(tm);
   if (t < 0) return;
-  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
   if (r0 >= r1) return;
-  const int s = rowptr[r0];
-  const int len = rowptr[r1] - s;
   const int tid = threadIdx.x;
-  for (int i = tid; i < len; i += GLA_BLOCK) sv[i] = val[s + i];
+  {
+    T v_[4];
+#define SOC_LD(u, i) v_[u] = val[s + (i)]
+#define SOC_ST(u, i) sv[i] = v_[u]
+    GLA_TILE_LOOP(len, tid, SOC_LD, SOC_ST)
+#undef SOC_LD
+#undef SOC_ST
+  }
   __syncthreads();
   for (int r = r0 + tid; r < r1; r += GLA_BLOCK) {
     const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
@@ -522,9 +567,13 @@ __global__ __launch_bounds__(GLA_BLOCK) void soc_classic_kernel(
     }
   }
   __syncthreads();
-  for (int i = tid; i < len; i += GLA_BLOCK) {
-    const int64_t e = perm ? perm[s + i] : (int64_t)(s + i);
-    S_out[e] = sv[i];
+  {
+    int64_t e_[4];
+#define SOC_LD(u, i) e_[u] = perm ? (int64_t)perm[s + (i)] : (int64_t)(s + (i))
+#define SOC_ST(u, i) S_out[e_[u]] = sv[i]
+    GLA_TILE_LOOP(len, tid, SOC_LD, SOC_ST)
+#undef SOC_LD
+#undef SOC_ST
   }
 }
 
@@ -539,16 +588,23 @@ __global__ __launch_bounds__(GLA_BLOCK) void direct_interp_kernel(
   T* sd = sa + lds_elems;                         // A_ik * S_ik * C_k
   const int t = map_tile(tm);
   if (t < 0) return;
-  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
   if (r0 >= r1) return;
-  const int s = rowptr[r0];
-  const int len = rowptr[r1] - s;
   const int tid = threadIdx.x;
-  for (int i = tid; i < len; i += GLA_BLOCK) {
-    const int64_t e = perm ? perm[s + i] : (int64_t)(s + i);
-    const T a = val[s + i];
-    sa[i] = a;
-    sd[i] = (a * S[e]) * cf[col[s + i]];
+  {
+    T a_[4], s_[4], c_[4];
+#define DI_LD(u, i)                                                                  \
+  {                                                                                  \
+    const int64_t e = perm ? (int64_t)perm[s + (i)] : (int64_t)(s + (i));            \
+    a_[u] = val[s + (i)];                                                            \
+    s_[u] = S[e];                                                                    \
+    c_[u] = cf[col[s + (i)]];                                                        \
+  }
+#define DI_ST(u, i) { sa[i] = a_[u]; sd[i] = (a_[u] * s_[u]) * c_[u]; }
+    GLA_TILE_LOOP(len, tid, DI_LD, DI_ST)
+#undef DI_LD
+#undef DI_ST
   }
   __syncthreads();
   for (int r = r0 + tid; r < r1; r += GLA_BLOCK) {
@@ -562,9 +618,13 @@ __global__ __launch_bounds__(GLA_BLOCK) void direct_interp_kernel(
     for (int j = a; j < b; ++j) sa[j] = omc * ((T(-1) * sa[j]) * alpha);
   }
   __syncthreads();
-  for (int i = tid; i < len; i += GLA_BLOCK) {
-    const int64_t e = perm ? perm[s + i] : (int64_t)(s + i);
-    w_out[e] = sa[i];
+  {
+    int64_t e_[4];
+#define DI_LD(u, i) e_[u] = perm ? (int64_t)perm[s + (i)] : (int64_t)(s + (i))
+#define DI_ST(u, i) w_out[e_[u]] = sa[i]
+    GLA_TILE_LOOP(len, tid, DI_LD, DI_ST)
+#undef DI_LD
+#undef DI_ST
   }
 }
 
@@ -580,15 +640,17 @@ __global__ __launch_bounds__(GLA_BLOCK) void soc_sa_kernel(
   T* sd = sa + lds_elems;                         // A_jj
   const int t = map_tile(tm);
   if (t < 0) return;
-  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
   if (r0 >= r1) return;
-  const int s = rowptr[r0];
-  const int len = rowptr[r1] - s;
   const int tid = threadIdx.x;
-  for (int i = tid; i < len; i += GLA_BLOCK) {
-    const T a = val[s + i];
-    sa[i] = a * a;
-    sd[i] = diag[col[s + i]];
+  {
+    T a_[4], d_[4];
+#define SA_LD(u, i) { a_[u] = val[s + (i)]; d_[u] = diag[col[s + (i)]]; }
+#define SA_ST(u, i) { sa[i] = a_[u] * a_[u]; sd[i] = d_[u]; }
+    GLA_TILE_LOOP(len, tid, SA_LD, SA_ST)
+#undef SA_LD
+#undef SA_ST
   }
   __syncthreads();
   for (int r = r0 + tid; r < r1; r += GLA_BLOCK) {
@@ -597,9 +659,13 @@ __global__ __launch_bounds__(GLA_BLOCK) void soc_sa_kernel(
     for (int j = a; j < b; ++j) sa[j] = sa[j] / (di * sd[j]);
   }
   __syncthreads();
-  for (int i = tid; i < len; i += GLA_BLOCK) {
-    const int64_t e = perm ? perm[s + i] : (int64_t)(s + i);
-    S_out[e] = sa[i];
+  {
+    int64_t e_[4];
+#define SA_LD(u, i) e_[u] = perm ? (int64_t)perm[s + (i)] : (int64_t)(s + (i))
+#define SA_ST(u, i) S_out[e_[u]] = sa[i]
+    GLA_TILE_LOOP(len, tid, SA_LD, SA_ST)
+#undef SA_LD
+#undef SA_ST
   }
 }
 
@@ -651,11 +717,12 @@ __global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage2(const T* __restrict_
   }
 }
 
-template <typename T>
+template <typename T, int KC>
 __global__ __launch_bounds__(GLA_BLOCK) void col_scale_rsqrt_kernel(const T* __restrict__ X, int64_t ldx,
                                                                     const T* __restrict__ sumsq,
                                                                     T* __restrict__ Y, int64_t ldy, int64_t n,
-                                                                    int K) {
+                                                                    int Krt) {
+  const int K = KC > 0 ? KC : Krt;
   const int64_t total = n * K;
   for (int64_t idx = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * GLA_BLOCK) {
@@ -703,6 +770,35 @@ int launch_col_dot(int64_t n, int K, const T* x, int64_t ldx, const T* y, int64_
 #undef GLA_DOT_CASE
   GLA_LAUNCH_CHECK();
   hipLaunchKernelGGL((col_dot_stage2<T>), dim3(1), dim3(GLA_BLOCK), 0, st, pw, (int)nb, K, out);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+#define GLA_K_SWITCH(K, ...)                      \
+  switch (K) {                                    \
+    case 1: { constexpr int KC = 1; __VA_ARGS__; } break;   \
+    case 2: { constexpr int KC = 2; __VA_ARGS__; } break;   \
+    case 4: { constexpr int KC = 4; __VA_ARGS__; } break;   \
+    case 8: { constexpr int KC = 8; __VA_ARGS__; } break;   \
+    case 16: { constexpr int KC = 16; __VA_ARGS__; } break; \
+    case 32: { constexpr int KC = 32; __VA_ARGS__; } break; \
+    default: { constexpr int KC = 0; __VA_ARGS__; } break;  \
+  }
+
+template <typename T>
+int launch_edge_products(gla_csr* A, int K, const T* X, int64_t ldx, T* C, int64_t ldc, hipStream_t st) {
+  const dim3 grid(grid_for(A->nnz * K, GLA_BLOCK * 4, 256 * 16));
+  GLA_K_SWITCH(K, hipLaunchKernelGGL((edge_products_kernel<T, KC>), grid, dim3(GLA_BLOCK), 0, st, A->col,
+                                     (const T*)A->val, A->perm, X, ldx, C, ldc, A->nnz, K))
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+template <typename T>
+int launch_col_scale(int64_t n, int K, const T* X, int64_t ldx, const T* sumsq, T* Y, int64_t ldy, hipStream_t st) {
+  const dim3 grid(grid_for(n * K, GLA_BLOCK * 4));
+  GLA_K_SWITCH(K, hipLaunchKernelGGL((col_scale_rsqrt_kernel<T, KC>), grid, dim3(GLA_BLOCK), 0, st, X, ldx, sumsq,
+                                     Y, ldy, n, K))
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }
@@ -821,10 +917,7 @@ int gla_col_scale_rsqrt(int dtype, int64_t n, int K, const void* X, int64_t ldx,
     return GLA_ERR_INVALID_ARG;
   if (n == 0) return GLA_OK;
   GLA_DISPATCH(dtype, {
-    hipLaunchKernelGGL((col_scale_rsqrt_kernel<T>), dim3(grid_for(n * K, GLA_BLOCK * 4)), dim3(GLA_BLOCK), 0,
-                       (hipStream_t)stream, (const T*)X, ldx, (const T*)sumsq, (T*)Y, ldy, n, K);
-    GLA_LAUNCH_CHECK();
-    return GLA_OK;
+    return launch_col_scale<T>(n, K, (const T*)X, ldx, (const T*)sumsq, (T*)Y, ldy, (hipStream_t)stream);
   })
 }
 
@@ -835,11 +928,7 @@ int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx,
   if (!X || (A->nnz > 0 && !C) || ldx < K || ldc < K) return GLA_ERR_INVALID_ARG;
   if (A->nnz == 0) return GLA_OK;
   GLA_DISPATCH(dtype, {
-    hipLaunchKernelGGL((edge_products_kernel<T>), dim3(grid_for(A->nnz * K, GLA_BLOCK * 4, 256 * 16)),
-                       dim3(GLA_BLOCK), 0, (hipStream_t)stream, A->col, (const T*)A->val, A->perm,
-                       (const T*)X, ldx, (T*)C, ldc, A->nnz, K);
-    GLA_LAUNCH_CHECK();
-    return GLA_OK;
+    return launch_edge_products<T>(A, K, (const T*)X, ldx, (T*)C, ldc, (hipStream_t)stream);
   })
 }
 

@@ -79,6 +79,7 @@ class RowBlockPartition:
             col_local[off] = self.n_local + slot_d[pos]
         self.edge_index_local = torch.stack([row - self.row_lo, col_local])
         self.n_cols_local = self.n_local + self.halo_size
+        self._send_bufs, self._send_flip = {}, 0
 
     # ---- buffers / exchange -------------------------------------------------------------------------
     def new_buffer(self, K, dtype, device):
@@ -89,9 +90,14 @@ class RowBlockPartition:
         if self.world == 1 or self.S == 0:
             return None
         K = X.shape[1]
-        send = torch.zeros((self.S, K), dtype=X.dtype, device=X.device)
+        key = (K, X.dtype, X.device)
+        send = self._send_bufs.get(key)
+        if send is None:                       # two buffers per shape: the previous collective may still read one
+            self._send_bufs[key] = send = [torch.zeros((self.S, K), dtype=X.dtype, device=X.device) for _ in (0, 1)]
+        self._send_flip ^= 1
+        send = send[self._send_flip]
         if self.n_send:
-            send[:self.n_send] = X[:self.n_local].index_select(0, self.send_idx)
+            torch.index_select(X[:self.n_local], 0, self.send_idx, out=send[:self.n_send])
         if X.is_cuda and dist.get_backend(self.group) == "gloo":
             # test-only route (2 ranks sharing one GPU, tests/test_gpu_dist.py): gloo moves host memory
             send_h = send.cpu()
