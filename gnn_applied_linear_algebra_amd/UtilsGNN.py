@@ -77,3 +77,45 @@ def coo_to_gnn_input(A):
     except Exception:
         pass
     return out
+
+
+def heateqnfem2dfun(num_cells, h_all, bcs=(2, 2), dtype=torch.float64, device=None):
+    """matlab/heateqnfem2dfun.m:52-172 (the only definition of the FEM mesh of BASELINE config 5): Q1 stiffness matrix
+    on a cx x cy cell grid with stretch alpha = hy/hx.  Every interior node sees all four of its elements, so the
+    assembled interior rows are the constant 9-point stencil of :105-110,
+        (1/6/alpha) * [4(2a^2+2) self, 2(-2a^2+1) x-neighbours, 2(a^2-2) y-neighbours, (-1-a^2) corners],
+    truncated at the (eliminated) boundary.  bcs = [2,2]: interior unknowns only (:164-168); bcs = [1,1]: all nodes,
+    identity rows/columns on the boundary (:143-161).  Returns (edge_index int64 [2,nnz], edge_val [nnz,1]) in
+    coalesced row-major order, generated on the device."""
+    _lib.require_gpu()
+    cx, cy = int(num_cells[0]), int(num_cells[1])
+    if tuple(bcs) not in ((1, 1), (2, 2)):
+        raise ValueError("bcs must be [1,1] or [2,2] (mixed modes are rejected by the reference)")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    alpha = float(h_all[1]) / float(h_all[0])
+    a2 = alpha ** 2
+    s = 1 / 6 / alpha
+    e_self, e_x, e_y, e_c = s * (2 * a2 + 2), s * (-2 * a2 + 1), s * (a2 - 2), s * (-1 - a2)
+    # assembled entries: the element contributions of one entry are equal, so their sum is an exact multiple
+    stencil = [(-1, -1, e_c), (0, -1, e_y + e_y), (1, -1, e_c),
+               (-1, 0, e_x + e_x), (0, 0, (e_self + e_self) + (e_self + e_self)), (1, 0, e_x + e_x),
+               (-1, 1, e_c), (0, 1, e_y + e_y), (1, 1, e_c)]
+    mx, my = cx - 1, cy - 1
+    k = torch.arange(mx * my, device=dev)
+    i, j = k % mx, k // mx
+    cand_c = torch.stack([(j + dy) * mx + (i + dx) for dx, dy, _ in stencil], 1)
+    valid = torch.stack([(i + dx >= 0) & (i + dx < mx) & (j + dy >= 0) & (j + dy < my) for dx, dy, _ in stencil], 1)
+    vals = torch.tensor([c for _, _, c in stencil], dtype=torch.float64, device=dev).expand(k.numel(), 9)
+    rows = k[:, None].expand(-1, 9)
+    r, c, v = rows[valid], cand_c[valid], vals[valid]
+    if tuple(bcs) == (1, 1):                     # embed the interior block, identity on the boundary nodes
+        nx = cx + 1
+        to_full = lambda q: (q // mx + 1) * nx + (q % mx + 1)
+        kk = torch.arange(nx * (cy + 1), device=dev)
+        bnd = kk[(kk % nx == 0) | (kk % nx == cx) | (kk // nx == 0) | (kk // nx == cy)]
+        r = torch.cat([to_full(r), bnd])
+        c = torch.cat([to_full(c), bnd])
+        v = torch.cat([v, torch.ones(bnd.numel(), dtype=torch.float64, device=dev)])
+        order = torch.argsort(r * (nx * (cy + 1)) + c)
+        r, c, v = r[order], c[order], v[order]
+    return torch.stack([r, c]), v.to(dtype).reshape(-1, 1)

@@ -101,8 +101,8 @@ def heateqnfem2dfun(num_cells, h_all, bcs=(2, 2)):
     coalesced (row-major) order for the (cx-1)*(cy-1) interior unknowns."""
     cx, cy = int(num_cells[0]), int(num_cells[1])
     alpha = float(h_all[1]) / float(h_all[0])
-    a2 = alpha * alpha
-    s = 1.0 / (6.0 * alpha)
+    a2 = alpha ** 2
+    s = 1 / 6 / alpha                                                          # (1/6/alpha), :94
     # element matrix entries (heateqnfem2dfun.m:71-100): self, x-neighbour, y-neighbour, corner
     e_self, e_x, e_y, e_c = s * (2 * a2 + 2), s * (-2 * a2 + 1), s * (a2 - 2), s * (-1 - a2)
     loc = np.array([[e_self, e_x, e_c, e_y],
@@ -116,17 +116,26 @@ def heateqnfem2dfun(num_cells, h_all, bcs=(2, 2)):
     rows = np.repeat(gidx, 4, axis=1).ravel()
     cols = np.tile(gidx, (1, 4)).ravel()
     vals = np.tile(loc.ravel(), gidx.shape[0])
-    if tuple(bcs) != (2, 2):
-        raise NotImplementedError("only bcs=[2,2] (interior unknowns) is restated")
     ix, iy = rows % nx, rows // nx
     jx, jy = cols % nx, cols // nx
-    keep = (ix > 0) & (ix < cx) & (iy > 0) & (iy < cy) & (jx > 0) & (jx < cx) & (jy > 0) & (jy < cy)
-    mx = cx - 1
-    r = (iy[keep] - 1) * mx + (ix[keep] - 1)
-    c = (jy[keep] - 1) * mx + (jx[keep] - 1)
-    n = mx * (cy - 1)
-    A = torch.sparse_coo_tensor(torch.tensor(np.array([r, c])), torch.tensor(vals[keep]), (n, n))
-    return coo_to_gnn_input(A)
+    interior = (ix > 0) & (ix < cx) & (iy > 0) & (iy < cy) & (jx > 0) & (jx < cx) & (jy > 0) & (jy < cy)
+    if tuple(bcs) == (2, 2):                                                   # :164-168 keep interior only
+        mx = cx - 1
+        r = (iy[interior] - 1) * mx + (ix[interior] - 1)
+        c = (jy[interior] - 1) * mx + (jx[interior] - 1)
+        n = mx * (cy - 1)
+        A = torch.sparse_coo_tensor(torch.tensor(np.array([r, c])), torch.tensor(vals[interior]), (n, n))
+        return coo_to_gnn_input(A)
+    if tuple(bcs) == (1, 1):                                                   # :143-161 zero rows/cols + identity
+        n = nx * ny
+        k = np.arange(n)
+        bnd = (k % nx == 0) | (k % nx == cx) | (k // nx == 0) | (k // nx == cy)
+        r = np.concatenate([rows[interior], k[bnd]])
+        c = np.concatenate([cols[interior], k[bnd]])
+        v = np.concatenate([vals[interior], np.ones(int(bnd.sum()))])
+        A = torch.sparse_coo_tensor(torch.tensor(np.array([r, c])), torch.tensor(v), (n, n))
+        return coo_to_gnn_input(A)
+    raise NotImplementedError("bcs must be [1,1] or [2,2] (mixed modes are rejected by the reference, :60-63)")
 
 
 # --------------------------------------------------------------------------------------

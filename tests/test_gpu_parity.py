@@ -88,6 +88,19 @@ def test_builders_edge_cases():
     assert o_i.shape == (2, 0)
 
 
+def test_fem_builder_vs_oracle():
+    """heateqnfem2dfun (matlab/heateqnfem2dfun.m restated): device builder == oracle assembly, bit-exact."""
+    for cells, h, bcs in (([7, 7], [1.0, 1.0], [2, 2]), ([6, 9], [1.0, 4.0], [2, 2]), ([5, 4], [0.5, 0.125], [2, 2]),
+                          ([6, 5], [1.0, 3.0], [1, 1]), ([2, 2], [1.0, 1.0], [2, 2])):
+        ei, ev = gla.UtilsGNN.heateqnfem2dfun(cells, h, bcs, device=DEV)
+        ei_c, ev_c = rp.heateqnfem2dfun(cells, h, bcs)
+        eq(ei, ei_c)
+        eq(ev, ev_c)
+    m = 64
+    ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 1.0], device=DEV)
+    assert ei.shape[1] == (3 * m - 2) ** 2                              # SURVEY 8: nnz of the m x m interior
+
+
 def test_remove_diag_large_random():
     gen = torch.Generator().manual_seed(5)
     nnz, n = 1_000_003, 5000

@@ -204,3 +204,17 @@ def test_c_oracle_golden(golden, N):
     eq(S, golden[f"N{N}_socr_S"])
     w = Aod.direct_interp((S > 0).astype(np.float64), diag, golden[f"N{N}_split"].astype(np.float64))
     eq(w, golden[f"N{N}_di_rnd_w"])
+
+
+def test_fem_bc1_structure():
+    """bcs=[1,1] (heateqnfem2dfun.m:143-161): boundary nodes are identity rows/columns, interior block = bcs [2,2]."""
+    m = 5
+    ei, ev = rp.heateqnfem2dfun([m + 1, m + 1], [1.0, 2.0], [1, 1])
+    nx = m + 2
+    A = torch.sparse_coo_tensor(ei, ev.flatten(), (nx * nx, nx * nx)).to_dense()
+    k = torch.arange(nx * nx)
+    bnd = (k % nx == 0) | (k % nx == m + 1) | (k // nx == 0) | (k // nx == m + 1)
+    assert torch.equal(A[bnd][:, bnd], torch.eye(int(bnd.sum()), dtype=torch.float64))
+    assert A[bnd][:, ~bnd].abs().sum() == 0 and A[~bnd][:, bnd].abs().sum() == 0
+    ei2, ev2 = rp.heateqnfem2dfun([m + 1, m + 1], [1.0, 2.0], [2, 2])
+    assert torch.equal(A[~bnd][:, ~bnd], torch.sparse_coo_tensor(ei2, ev2.flatten(), (m * m, m * m)).to_dense())
