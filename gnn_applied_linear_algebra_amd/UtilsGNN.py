@@ -70,8 +70,13 @@ def coo_to_gnn_input(A):
     cached = getattr(A, "_gla_gnn_input", None)
     if cached is not None:
         return cached
-    Ac = A.coalesce()
-    out = (Ac.indices(), Ac.values().reshape(-1, 1))
+    if A.is_cuda and not A.is_coalesced():
+        from .sparse_ops import coalesce           # libgla_hip sort + in-order duplicate sums
+        ei, ev = coalesce(A._indices(), A._values(), A.shape[0], A.shape[1])
+        out = (ei, ev.reshape(-1, 1))
+    else:
+        Ac = A.coalesce()
+        out = (Ac.indices(), Ac.values().reshape(-1, 1))
     try:
         A._gla_gnn_input = out
     except Exception:

@@ -9,12 +9,13 @@ the adapters keep the reference's names and argument lists.  Differences, all do
   * the true diagonal of A is used where the script hard-codes -4 (VCycle.py:117,165) -- identical on its matrix;
   * P = (I + W)[:, C] is assembled sparse, without the dense n x n detour of VCycle.py:129-137.
 Smoothers, residual, strength of connection and interpolation weights run in libgla_hip kernels; restriction and
-prolongation are SpMVs on cached plans of P^T / P; the Galerkin product P^T (A P) (setup, VCycle.py:209) uses
-torch's device sparse-sparse product for now.
+prolongation are SpMVs on plans of P^T / P; the Galerkin product P^T (A P) (setup, VCycle.py:209) and every
+coalesce run in libgla_hip's expand-sort-compress kernels (sparse_ops.py, csrc/gla_sparse.hip).
 """
 import torch
 
 from ._common import compute_device, plan_for, to_dev
+from . import sparse_ops
 from .ChebyGNN import ChebyRelaxGNN
 from .DirectInterpGNN import DirectInterpGNN
 from .GNNResidual import GNNResidual
@@ -108,7 +109,9 @@ def runDirectInterp(A, S, N=None, splitting=None):
     rows = torch.cat([edgeij_pair[0][keep], c_rows])
     cols = torch.cat([cmap[edgeij_pair[1][keep]], cmap[c_rows]])
     vals = torch.cat([w_ij[keep], torch.ones(c_rows.numel(), dtype=dt, device=dev)])
-    return torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (n, int(is_c.sum()))).coalesce()
+    n_c = int(is_c.sum())
+    P_ei, P_ev = sparse_ops.coalesce(torch.stack([rows, cols]), vals, n, n_c)
+    return _as_sparse(P_ei, P_ev, (n, n_c))
 
 
 def runCheby(A, b, x, c, d):
@@ -132,11 +135,20 @@ def runJacobi(n_iters, w, A, b, x):
     return JacGNN(n_iters, vertex_attr, edgeij_pair, edge_attr, torch.tensor(w).reshape(-1))
 
 
-def _spmv(M, v):
-    """Sparse COO matrix times dense [n, K] on a cached libgla_hip plan (restriction / prolongation)."""
-    ei, ea = coo_to_gnn_input(M)
-    plan = plan_for(ei, M.shape[0], M.shape[1], edge_attr=ea)
-    return plan.spmm(v.contiguous())
+def _as_sparse(ei, ev, shape):
+    """Coalesced (edge_index, values) -> torch sparse COO carrying its GNN-input cache (no re-coalesce later)."""
+    M = torch.sparse_coo_tensor(ei, ev.reshape(-1), shape, is_coalesced=True)
+    M._gla_gnn_input = (ei, ev.reshape(-1, 1))
+    return M
+
+
+def _galerkin(A, P):
+    """(Ac, plan(P), plan(P^T)) with Ac = P^T (A P) (VCycle.py:209) computed by libgla_hip's SpGEMM."""
+    A_ei, A_ev = coo_to_gnn_input(A)
+    P_ei, P_ev = coo_to_gnn_input(P)
+    Ac_ei, Ac_ev, Pp, Pt = sparse_ops.galerkin(A_ei, A_ev[:, 0].contiguous(), A.shape[0], P_ei,
+                                               P_ev[:, 0].contiguous(), P.shape[1])
+    return _as_sparse(Ac_ei, Ac_ev, (P.shape[1], P.shape[1])), Pp, Pt
 
 
 def runVCycle(A, b, x, n_presmooth, n_postsmooth, n_coarsesolve, use_jacobi=True):
@@ -151,12 +163,11 @@ def runVCycle(A, b, x, n_presmooth, n_postsmooth, n_coarsesolve, use_jacobi=True
         x = runCheby(A, b, x, -3.461, -4.0)
     S = runSOC(A)
     P = runDirectInterp(A, S, N)
-    Pt = P.t().coalesce()
-    Ac = torch.sparse.mm(Pt, torch.sparse.mm(A, P)).coalesce()           # VCycle.py:209
+    Ac, P_plan, Pt_plan = _galerkin(A, P)                                # VCycle.py:209
     r = runResidual(A, b, x)
-    rc = _spmv(Pt, r)                                                    # :215
+    rc = Pt_plan.spmm(r.contiguous())                                    # :215
     xc = runCheby(Ac, rc, torch.zeros_like(rc), -3.4, -4.0)              # :218-223
-    x = x + _spmv(P, xc)                                                 # :226
+    x = x + P_plan.spmm(xc.contiguous())                                 # :226
     if use_jacobi:
         x = runJacobi(n_postsmooth, 0.7, A, b, x)
     else:
@@ -179,7 +190,7 @@ class AMGHierarchy:
         self.soc, self.di = SOCClassicGNN(theta_), DirectInterpGNN()
         self.res, self.jac = GNNResidual(), JacobiGNN()
         self.cheby = ChebyRelaxGNN(cheb_deg_, return_edge_attr=False)
-        self.A, self.P, self.Pt, self.gnn = [A.coalesce()], [], [], []
+        self.A, self.P, self.Pt, self.gnn = [A], [], [], []
         for _ in range(levels - 1):
             Al = self.A[-1]
             n = Al.shape[0]
@@ -196,11 +207,12 @@ class AMGHierarchy:
             rows = torch.cat([ei[0][keep], c_rows])
             cols = torch.cat([cmap[ei[1][keep]], cmap[c_rows]])
             vals = torch.cat([w_ij[keep], torch.ones(c_rows.numel(), dtype=ea.dtype, device=dev)])
-            P = torch.sparse_coo_tensor(torch.stack([rows, cols]), vals, (n, int(is_c.sum()))).coalesce()
-            Pt = P.t().coalesce()
-            self.P.append(P)
-            self.Pt.append(Pt)
-            self.A.append(torch.sparse.mm(Pt, torch.sparse.mm(Al, P)).coalesce())
+            n_c = int(is_c.sum())
+            P_ei, P_ev = sparse_ops.coalesce(torch.stack([rows, cols]), vals, n, n_c)
+            Ac_ei, Ac_ev, P_plan, Pt_plan = sparse_ops.galerkin(ei_all, ea_all[:, 0].contiguous(), n, P_ei, P_ev, n_c)
+            self.P.append(P_plan)
+            self.Pt.append(Pt_plan)
+            self.A.append(_as_sparse(Ac_ei, Ac_ev, (n_c, n_c)))
         # per-level GNN inputs, built once
         for Al in self.A:
             ei, ea = coo_to_gnn_input(Al)
@@ -227,7 +239,7 @@ class AMGHierarchy:
             return va[:, 1].reshape(-1, 1)
         x = self._smooth(level, self.n_pre, b, x)
         r = self.residual(b, x, level)
-        rc = _spmv(self.Pt[level], r)
+        rc = self.Pt[level].spmm(r.contiguous())
         xc = self.cycle(rc, torch.zeros_like(rc), level + 1)
-        x = x + _spmv(self.P[level], xc)
+        x = x + self.P[level].spmm(xc.contiguous())
         return self._smooth(level, self.n_post, b, x)

@@ -8,6 +8,7 @@ runs in libgla_hip.so (csrc/, C ABI in include/gla.h); there is no CPU fallback.
 from . import _lib  # noqa: F401
 from .meta import MetaLayer  # noqa: F401
 from .plan import CsrPlan, plan_for, col_dot, col_scale_rsqrt  # noqa: F401
+from . import sparse_ops  # noqa: F401
 from . import (UtilsGNN, MatVecGNN, GNNResidual, JacobiGNN, ChebyGNN, PowerMethodGNN, SOCClassicGNN,  # noqa: F401
                DirectInterpGNN, SOCSAGNN, MatrixWeightedNorm, VCycle)
 

@@ -171,6 +171,23 @@ int gla_remove_diag_apply(int64_t nnz, const int64_t* row, const int64_t* col, c
                           int64_t val_stride, int dtype, const void* work,
                           int64_t* row_out, int64_t* col_out, void* val_out, gla_stream_t stream);
 
+/* ---- V-cycle setup (device-side sparse algebra) ----------------------------------------------------- */
+/* Coalesce a COO edge list: sort by (row, col), add duplicates in their original order.
+ * UtilsGNN.py:74-78 (coo_to_gnn_input -> A.coalesce()).  Outputs need room for nnz entries; the number of
+ * unique entries is returned through nnz_out_host (synchronises). */
+int gla_coo_coalesce(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* row, const int64_t* col,
+                     const void* val, int64_t val_stride, int dtype, int64_t* row_out, int64_t* col_out,
+                     void* val_out, int64_t* nnz_out_host, gla_stream_t stream);
+
+/* C = A * B for two plans holding values of `dtype`, as a coalesced COO list (row-major, ascending columns).
+ * VCycle.py:209 (Ac = P.t() @ (A @ P)), also R = P^T via a plan of the flipped edge list.
+ * Step 1 returns the number of scalar products (the size the output buffers need); step 2 fills
+ * row_out / col_out / val_out [n_products] and returns the number of entries of C.  Both synchronise.
+ * Duplicates are added in a defined order: A's CSR order, then B's. */
+int gla_spgemm_count(gla_csr_t A, gla_csr_t B, int64_t* n_products_host, gla_stream_t stream);
+int gla_spgemm(gla_csr_t A, gla_csr_t B, int dtype, int64_t n_products, int64_t* row_out, int64_t* col_out,
+               void* val_out, int64_t* nnz_out_host, gla_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -517,3 +517,54 @@ def test_amg_hierarchy():
     assert all(np.isfinite(norms)) and all(b_ < a_ for a_, b_ in zip(norms, norms[1:])), norms
     r_w = rp.residual_forward(torch.cat([b.cpu(), x.cpu()], 1), *rp.coo_to_gnn_input(A.cpu()))
     eq(H.residual(b, x), r_w)
+
+
+# ---------------------------------------------------------------------------------------------------
+# V-cycle setup: device coalesce / SpGEMM / Galerkin product
+# ---------------------------------------------------------------------------------------------------
+def test_sparse_ops():
+    from gnn_applied_linear_algebra_amd import sparse_ops as so
+    gen = torch.Generator().manual_seed(13)
+    # coalesce: duplicates, unsorted, empty rows; index side bit-exact, sums to rounding (2-3 addends)
+    n_r, n_c, nnz = 300, 211, 5000
+    ei = torch.stack([torch.randint(0, n_r, (nnz,), generator=gen), torch.randint(0, n_c, (nnz,), generator=gen)])
+    ev = torch.rand(nnz, generator=gen, dtype=torch.float64) - 0.5
+    want = torch.sparse_coo_tensor(ei, ev, (n_r, n_c)).coalesce()
+    got_i, got_v = so.coalesce(d(ei), d(ev), n_r, n_c)
+    eq(got_i, want.indices())
+    close(got_v, want.values(), rtol=1e-13)
+    e0, v0 = so.coalesce(d(ei[:, :0]), d(ev[:0]), n_r, n_c)
+    assert e0.shape == (2, 0) and v0.shape == (0,)
+    # coo_to_gnn_input on an uncoalesced device tensor takes the same route
+    gi, gv = gla.UtilsGNN.coo_to_gnn_input(torch.sparse_coo_tensor(d(ei), d(ev), (n_r, n_c)))
+    eq(gi, want.indices())
+    # SpGEMM against dense algebra (fp64 and fp32)
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 1e-5)):
+        A = (torch.rand(60, 45, generator=gen, dtype=torch.float64) < 0.15) * torch.rand(60, 45, generator=gen, dtype=torch.float64)
+        B = (torch.rand(45, 70, generator=gen, dtype=torch.float64) < 0.2) * torch.rand(45, 70, generator=gen, dtype=torch.float64)
+        A, B = A.to(dt), B.to(dt)
+        As, Bs = A.to_sparse().coalesce(), B.to_sparse().coalesce()
+        pa = so.plan_of(d(As.indices()), d(As.values()), 60, 45)
+        pb = so.plan_of(d(Bs.indices()), d(Bs.values()), 45, 70)
+        ci, cv = so.spgemm(pa, pb)
+        C = torch.sparse_coo_tensor(ci.cpu(), cv.cpu(), (60, 70)).to_dense()
+        np.testing.assert_allclose(C.numpy(), (A.double() @ B.double()).numpy(), rtol=tol, atol=tol)
+        flat = ci[0] * 70 + ci[1]
+        assert bool((flat[1:] > flat[:-1]).all())                    # coalesced: strictly increasing keys
+    # Galerkin product on the Laplacian with the checkerboard interpolation: symmetric, matches torch CPU
+    N = 12
+    n = N * N
+    ei, ev = rp.laplacianfun_torch(N)
+    A = torch.sparse_coo_tensor(ei, ev.flatten(), (n, n))
+    eio, evo = rp.remove_diag_entries(ei, ev)
+    S = rp.soc_classic_forward(0.25, torch.zeros(n, 1, dtype=torch.float64), eio, evo).reshape(-1, 1) > 0
+    split = torch.zeros(n, dtype=torch.int64)
+    split[0::2] = 1
+    P = rp.vcycle_interp_P(A.float(), S, split, -4 * torch.ones(n, 1)).double().coalesce()
+    P = torch.sparse_coo_tensor(P.indices(), torch.nan_to_num(P.values()), P.shape).coalesce()
+    Ac_w = (P.t() @ (A @ P)).to_dense()
+    Ac_i, Ac_v, Pp, Pt = so.galerkin(d(ei), d(ev.flatten()), n, d(P.indices()), d(P.values()), P.shape[1])
+    Ac = torch.sparse_coo_tensor(Ac_i.cpu(), Ac_v.cpu(), Ac_w.shape).to_dense()
+    np.testing.assert_allclose(Ac.numpy(), Ac_w.numpy(), rtol=1e-12, atol=1e-13)
+    r = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    np.testing.assert_allclose(Pt.spmm(d(r)).cpu().numpy(), (P.t() @ r).numpy(), rtol=1e-13)
