@@ -37,6 +37,65 @@ def default_splitting(n, device):
     return s
 
 
+def pmis_splitting(edgeij_pair_od, strong, n, max_rounds=64):
+    """Deterministic PMIS-style C/F splitting on the device (stands in for pyamg's randomised CLJP,
+    VCycle.py:114).  `strong[e]` says that vertex row(e) strongly depends on col(e).
+    weight_i = (number of vertices that strongly depend on i, fixed 32-bit hash of i, low bits of i) compared
+    lexicographically, so ties are practically impossible and the result is reproducible; a vertex becomes C when its weight beats every undecided strong neighbour (either
+    direction), then every undecided vertex that strongly depends on a new C point becomes F.  Vertices without
+    any strong connection become C (identity interpolation; the DI formula has no finite weight for them).
+    Returns an int64 vector, 1 = C point."""
+    dev = edgeij_pair_od.device
+    strong = strong.reshape(-1).to(torch.bool)
+    row, col = edgeij_pair_od[0][strong], edgeij_pair_od[1][strong]
+    lam = torch.bincount(col, minlength=n)
+    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    h = (idx + 1) & 0xFFFFFFFF                                       # murmur3 fmix32: a fixed pseudo-random order
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h = h ^ (h >> 16)
+    w = (lam << 52) | (h << 20) | (idx & 0xFFFFF)                    # integer weight: influence count, then hash
+    state = torch.zeros(n, dtype=torch.int64, device=dev)            # 0 undecided, 1 C, -1 F
+    touched = torch.zeros(n, dtype=torch.bool, device=dev)
+    touched[row] = True
+    touched[col] = True
+    state[~touched] = 1
+    a = torch.cat([row, col])                                        # symmetrised strong graph a -> b
+    b = torch.cat([col, row])
+    for _ in range(max_rounds):
+        und = state == 0
+        if not bool(und.any()):
+            break
+        live = und[a] & und[b]
+        m = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        m.scatter_reduce_(0, a[live], w[b[live]], "amax", include_self=True)
+        new_c = und & (w > m)
+        state[new_c] = 1
+        dep = (state[row] == 0) & (state[col] == 1)                  # undecided i strongly depends on a C point
+        state[row[dep]] = -1
+    state[state == 0] = 1
+    return (state == 1).to(torch.int64)
+
+
+class GridSplitting:
+    """Standard (full) coarsening of an nx x ny vertex grid numbered k = j*nx + i: C points at even i and even j.
+    Callable as splitting(A_level, S, n); it tracks the grid size from level to level."""
+
+    def __init__(self, nx, ny):
+        self.nx, self.ny = int(nx), int(ny)
+
+    def __call__(self, A, S, n):
+        if n != self.nx * self.ny:
+            raise ValueError(f"level has {n} vertices, expected a {self.nx} x {self.ny} grid")
+        dev = A.device
+        k = torch.arange(n, device=dev)
+        s = (((k % self.nx) % 2 == 0) & ((k // self.nx) % 2 == 0)).to(torch.int64)
+        self.nx, self.ny = (self.nx + 1) // 2, (self.ny + 1) // 2
+        return s
+
+
 def configure(theta_=0.25, cheb_deg_=4, splitting=None, N_=None):
     """Create the GNN modules (VCycle.py:251-256).  splitting: callable(S_matrix_coo, n) -> int vector, 1 = C point."""
     global theta, cheb_deg, SOCGNN, DIGNN, ResidualGNN, ChebyGNN, JacGNN, _splitting, N
@@ -179,30 +238,42 @@ class AMGHierarchy:
     """Multi-level generalisation (BASELINE config 5: 3 levels): the same five operators applied recursively, with
     the setup (SOC -> splitting -> DI -> P -> Galerkin) done ONCE instead of every cycle.
 
-    cycle(): weighted Jacobi pre/post smoothing on every level but the coarsest, Chebyshev relaxation of degree
-    cheb_deg as the coarsest 'solve', eigen-bounds from a few power iterations of D^-1-free A (lambda_max) when not
-    supplied."""
+    cycle(): weighted Jacobi pre/post smoothing on every level but the coarsest.  Coarsest 'solve': Chebyshev
+    relaxation (the reference's choice, VCycle.py:218-223) of degree coarse_deg over [lambda/kappa, 1.1 lambda] with
+    lambda from the power-method GNN, or coarse_solver="dense" (LU of the coarsest operator, for hierarchies deep
+    enough that it is small).  splitting: None (every other vertex), "pmis" (pmis_splitting) or a callable."""
 
     def __init__(self, A, levels=3, theta_=0.25, cheb_deg_=4, splitting=None, w=0.7, n_pre=3, n_post=3,
-                 coarse_bounds=None):
+                 coarse_bounds=None, coarse_sweeps=1, min_coarse=0, coarse_deg=None,
+                 coarse_kappa=100.0, coarse_solver="cheby"):
         dev, A = _dev(A)
-        self.w, self.n_pre, self.n_post = w, n_pre, n_post
+        self.w, self.n_pre, self.n_post, self.coarse_sweeps = w, n_pre, n_post, coarse_sweeps
         self.soc, self.di = SOCClassicGNN(theta_), DirectInterpGNN()
         self.res, self.jac = GNNResidual(), JacobiGNN()
-        self.cheby = ChebyRelaxGNN(cheb_deg_, return_edge_attr=False)
+        self.cheby = ChebyRelaxGNN(cheb_deg_ if coarse_deg is None else coarse_deg, return_edge_attr=False)
         self.A, self.P, self.Pt, self.gnn = [A], [], [], []
         for _ in range(levels - 1):
             Al = self.A[-1]
             n = Al.shape[0]
+            if n <= min_coarse:
+                break
             ei_all, ea_all = coo_to_gnn_input(Al)
             ei, ea = remove_diag_entries(ei_all, ea_all)
             S = self.soc(torch.zeros((n, 1), dtype=ea.dtype, device=dev), ei, ea).reshape(-1, 1) > 0
-            split = (splitting(Al, S, n) if splitting is not None else default_splitting(n, dev)).to(dev).reshape(-1)
+            if splitting == "pmis":
+                split = pmis_splitting(ei, S, n)
+            elif splitting is not None:
+                split = splitting(Al, S, n)
+            else:
+                split = default_splitting(n, dev)
+            split = split.to(dev).reshape(-1)
             va = torch.hstack([_diag_of(ei_all, ea_all, n), split.reshape(-1, 1).to(ea.dtype)])
             w_ij = self.di(va, ei, torch.hstack([ea, S.to(ea.dtype)]), None)
             is_c = split > 0
             cmap = torch.cumsum(is_c.to(torch.int64), 0) - 1
-            keep = is_c[ei[1]] & ~is_c[ei[0]]                      # F rows interpolate from C columns
+            # F rows interpolate from their STRONG C neighbours only (classical direct interpolation: the
+            # denominator of DirectInterpGNN.py:93 sums exactly those), C rows are identity rows
+            keep = is_c[ei[1]] & ~is_c[ei[0]] & S.reshape(-1)
             c_rows = torch.nonzero(is_c).reshape(-1)
             rows = torch.cat([ei[0][keep], c_rows])
             cols = torch.cat([cmap[ei[1][keep]], cmap[c_rows]])
@@ -217,11 +288,25 @@ class AMGHierarchy:
         for Al in self.A:
             ei, ea = coo_to_gnn_input(Al)
             self.gnn.append((ei, ea, torch.cat([ea, torch.zeros_like(ea)], 1), _diag_of(ei, ea, Al.shape[0])))
+        self.coarse_solver = coarse_solver
+        self._coarse_lu = None
+        if coarse_solver == "dense":
+            # classical AMG practice for a coarsest level of a few thousand unknowns: factor it once (torch.linalg)
+            self._coarse_lu = torch.linalg.lu_factor(self.A[-1].to_dense())
+            coarse_bounds = (0.0, 1.0)
         if coarse_bounds is None:
-            ei, ea, _, dg = self.gnn[-1]
-            lmax = float(dg.abs().max()) * 2.0                      # Gershgorin-style bound for these M-matrices
-            sign = -1.0 if float(dg.sum()) < 0 else 1.0
-            coarse_bounds = (sign * 0.45 * lmax, sign * 0.55 * lmax)    # (c, d): spectrum in d +- c
+            # dominant eigenvalue of the coarsest operator by the power-method GNN; the Chebyshev 'solve' then
+            # targets [lambda/kappa, 1.1 lambda] (c = half-width, d = centre, as in ChebyGNN.py:365-368)
+            from .PowerMethodGNN import PowerMethodGNN
+            ei, ea, ea2, dg = self.gnn[-1]
+            nc = dg.shape[0]
+            gen = torch.Generator().manual_seed(24601)
+            b0 = torch.rand(nc, 1, generator=gen, dtype=torch.float64).to(dg.dtype).to(dev)
+            _, _, gp = PowerMethodGNN(30, return_edge_attr=False)(
+                torch.cat([b0, torch.zeros_like(b0)], 1), ei, ea2, torch.zeros(3, dtype=dg.dtype), None)
+            lam = float(gp[2])
+            hi, lo = 1.1 * lam, lam / coarse_kappa
+            coarse_bounds = ((hi - lo) / 2, (hi + lo) / 2)
         self.coarse_bounds = coarse_bounds
 
     def residual(self, b, x, level=0):
@@ -234,9 +319,14 @@ class AMGHierarchy:
 
     def cycle(self, b, x, level=0):
         if level == len(self.A) - 1:
+            if self._coarse_lu is not None:
+                return torch.linalg.lu_solve(self._coarse_lu[0], self._coarse_lu[1], b)
             ei, ea, _, _ = self.gnn[level]
-            va, _, _ = self.cheby(torch.cat([b, x], 1), ei, ea, torch.tensor(self.coarse_bounds, dtype=b.dtype))
-            return va[:, 1].reshape(-1, 1)
+            g = torch.tensor(self.coarse_bounds, dtype=b.dtype)
+            for _ in range(self.coarse_sweeps):
+                va, _, _ = self.cheby(torch.cat([b, x], 1), ei, ea, g)
+                x = va[:, 1].reshape(-1, 1)
+            return x
         x = self._smooth(level, self.n_pre, b, x)
         r = self.residual(b, x, level)
         rc = self.Pt[level].spmm(r.contiguous())
