@@ -594,3 +594,64 @@ def test_sparse_ops():
     np.testing.assert_allclose(Ac.numpy(), Ac_w.numpy(), rtol=1e-12, atol=1e-13)
     r = torch.rand(n, 1, generator=gen, dtype=torch.float64)
     np.testing.assert_allclose(Pt.spmm(d(r)).cpu().numpy(), (P.t() @ r).numpy(), rtol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs 3 and 4 at full size
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_config3_k16():
+    """Config 3: ChebyGNN (deg 4) + PowerMethodGNN (10 its), 4096^2 Laplacian, 16 right-hand sides, fp64.
+    Chebyshev columns are bit-exact against the C oracle run on single columns; the power-method eigenvalue
+    estimates agree to 1e-12 (global sums are re-associated) and obey the spectrum bound |lambda| < 8."""
+    import c_oracle
+    N, K = 4096, 16
+    n = N * N
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    A = c_oracle.Csr(ei.cpu().numpy(), ev.cpu().numpy(), n)
+    gen = torch.Generator().manual_seed(24601)
+    B = torch.rand(n, K, generator=gen, dtype=torch.float64)
+    X = torch.rand(n, K, generator=gen, dtype=torch.float64)
+    gch = torch.tensor([-3.4, -4.0], dtype=torch.float64)
+    va, _, g = gla.ChebyGNN.ChebyRelaxGNN(4, return_edge_attr=False)(d(torch.stack([B, X], 1)), ei, ev, gch)
+    assert va.shape == (n, 4, K)
+    for k in (0, 11):
+        xo, r, p, gw = A.cheby(B[:, k].numpy(), X[:, k].numpy(), -3.4, -4.0, 4)
+        eq(va[:, 1, k], xo)
+        eq(va[:, 2, k], r)
+        eq(va[:, 3, k], p)
+    eq(g, gw)
+    del va
+    ea2 = torch.cat([ev, torch.zeros_like(ev)], 1)
+    vb, _, gp = gla.PowerMethodGNN.PowerMethodGNN(10, return_edge_attr=False)(
+        d(torch.stack([B, torch.zeros_like(B)], 1)), ei, ea2, torch.zeros(3, K, dtype=torch.float64), None)
+    lam = gp[2].cpu().numpy()
+    assert np.all(np.abs(lam) < 8.0) and np.all(lam < -7.0)
+    bk = B[:, 3:4].numpy().copy()                              # oracle power iteration on one column
+    for _ in range(10):
+        bk = A.spmm(bk)
+        bk = bk / np.sqrt(np.sum(bk * bk))
+    Ab = A.spmm(bk)
+    np.testing.assert_allclose(lam[3], np.sum(bk * Ab) / np.sum(bk * bk), rtol=1e-12)
+    np.testing.assert_allclose(vb[:, 0, 3].cpu().numpy(), bk[:, 0], rtol=1e-9, atol=1e-15)
+
+
+def test_full_size_config4_8192():
+    """Config 4 size on one GPU: 8192^2 Laplacian (335.5 M edges): CSR plan, 3 Jacobi sweeps bit-exact against the
+    C oracle, residual consistent."""
+    import c_oracle
+    N = 8192
+    n = N * N
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    assert ei.shape == (2, 5 * n - 4 * N)
+    gen = torch.Generator().manual_seed(7)
+    b = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    x = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    diag = torch.full((n, 1), -4.0, dtype=torch.float64)
+    ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+    got = gla.JacobiGNN.JacobiGNN()(3, d(torch.cat([diag, b, x], 1)), ei, ea, torch.tensor([0.7], dtype=torch.float64))
+    r = gla.GNNResidual.GNNResidual()(torch.cat([d(b), got], 1), ei, ev)
+    A = c_oracle.Csr(ei.cpu().numpy(), ev.cpu().numpy(), n)
+    del ei, ea
+    want = A.jacobi(diag.numpy(), b.numpy(), x.numpy(), 0.7, 3)
+    eq(got, want)
+    eq(r, b.numpy() - A.spmm(want))
