@@ -71,6 +71,7 @@ def main():
                     help="rehearsal only: all ranks share cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; before any HIP call
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,7 +85,6 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
