@@ -70,6 +70,15 @@ __device__ __forceinline__ void stv(T* p, V v) { *reinterpret_cast<V*>(p) = v; }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 #define GLA_EPI_SCALAR_API                                                                            \
+  static constexpr int NRED = 0; /* no block-level reduction */                                       \
+  template <typename V> struct GxV {};                                                                \
+  template <typename V> __device__ __forceinline__ GxV<V> gx_load(int) const { return GxV<V>{}; }     \
+  template <typename V> __device__ __forceinline__ V gx(V xv, const GxV<V>&) const { return xv; }     \
+  template <typename V> __device__ __forceinline__ V redv(V, const PreV<V>&) const { return V(); }    \
+  __device__ __forceinline__ T* partials_ptr() const { return nullptr; }                                                         \
+  GLA_EPI_SCALAR_CORE
+
+#define GLA_EPI_SCALAR_CORE                                                                           \
   typedef PreV<T> Pre;                                                                                \
   __device__ __forceinline__ Pre load(int64_t r, int k) const { return loadv<T>(r, k); }              \
   __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& p) const {                \
@@ -164,6 +173,49 @@ struct EpiChebyNext {                   // r -= a_old*(A p); p = r + beta p; x +
   GLA_EPI_SCALAR_API
 };
 
+// Fused power-method step (PowerMethodGNN.py:86-207, three MetaLayers): the gathered operand is normalised on
+// the fly (b_j = y_j / n, rounded like the reference's Layer 3), y_i = sum_j A_ij b_j is stored, and the workgroup
+// leaves sum_i y_i^2 of its tile in partials[tile * K + k] for the deterministic second-stage reduction.
+template <typename T>
+__device__ __forceinline__ T div_by(T a, T b, T rb) {
+  // a / b from the correctly rounded reciprocal rb = RN(1/b) with one Markstein correction step: q = RN(a*rb),
+  // r = a - q*b (exact in an FMA), q' = RN(q + r*rb) -- the correctly rounded quotient except for rare
+  // last-place cases, at 3 instructions instead of the ~30 of an IEEE fp64 division per gathered value.
+  const T q = a * rb;
+  const T r = __builtin_fma(-q, b, a);
+  return __builtin_fma(r, rb, q);
+}
+
+template <typename T>
+struct EpiPower {
+  T* y; int64_t ldy; const T* nrm; const T* rnrm; T* partials;
+  template <typename V> struct PreV {};
+  static constexpr int NRED = 1;
+  template <typename V> struct GxV { V n, rn; };                // this lane's divisor(s), loaded once per kernel
+  template <typename V> __device__ __forceinline__ GxV<V> gx_load(int k) const {
+    GxV<V> g;
+    if constexpr (sizeof(V) == sizeof(T)) { g.n = nrm ? nrm[k] : T(1); g.rn = nrm ? rnrm[k] : T(1); }
+    else {
+      g.n.x = nrm ? nrm[k] : T(1); g.n.y = nrm ? nrm[k + 1] : T(1);
+      g.rn.x = nrm ? rnrm[k] : T(1); g.rn.y = nrm ? rnrm[k + 1] : T(1);
+    }
+    return g;
+  }
+  template <typename V> __device__ __forceinline__ V gx(V xv, const GxV<V>& g) const {
+    if (!nrm) return xv;
+    if constexpr (sizeof(V) == sizeof(T)) return div_by(xv, g.n, g.rn);
+    else { V o; o.x = div_by(xv.x, g.n.x, g.rn.x); o.y = div_by(xv.y, g.n.y, g.rn.y); return o; }
+  }
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t, int) const { return PreV<V>{}; }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>&) const {
+    stv<V>(y + r * ldy + k, acc);
+  }
+  template <typename V> __device__ __forceinline__ V redv(V acc, const PreV<V>&) const { return acc * acc; }
+  __device__ __forceinline__ T* partials_ptr() const { return partials; }
+  bool vec2_ok() const { return al16(y) && ldy % 2 == 0; }
+  GLA_EPI_SCALAR_CORE
+};
+
 // ------------------------------------------------------------------------------------------------
 // K = 1: products staged in LDS
 // ------------------------------------------------------------------------------------------------
@@ -171,6 +223,13 @@ template <bool NT, typename U>
 __device__ __forceinline__ U ld_stream(const U* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
   else return *p;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = v + __shfl_down(v, off, 64);
+  return v;
 }
 
 // Main K = 1 kernel: 16-byte val loads / 8-byte col loads -- each lane owns PAIRS of consecutive nnz; the tile's
@@ -199,6 +258,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
     rb = rowptr[r + 1];
     pre = epi.load((int64_t)r, 0);
   }
+  const auto gxs = epi.template gx_load<T>(0);
   const int sa = s & ~1;                       // even -> val+sa is 16-byte aligned, col+sa 8-byte aligned
   const int npairs = (e - sa + 1) >> 1;
   const T2* val2 = reinterpret_cast<const T2*>(val + sa);
@@ -222,8 +282,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
     T2 xv[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
-      xv[u].x = x[c[u].x];
-      xv[u].y = x[c[u].y];
+      xv[u].x = epi.gx(x[c[u].x], gxs);
+      xv[u].y = epi.gx(x[c[u].y], gxs);
     }
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
@@ -235,6 +295,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
   }
   __syncthreads();
 
+  T red = T(0);
   if (r < r1) {
     if (!PF) {
       ra = rowptr[r];
@@ -250,12 +311,22 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
     }
     for (; j < jend; ++j) acc = acc + prod[j];
     epi.apply((int64_t)r, 0, acc, pre);
+    if constexpr (Epi::NRED > 0) red = epi.redv(acc, pre);
   }
   for (int r2 = r + GLA_BLOCK; r2 < r1; r2 += GLA_BLOCK) {       // tiles with more than 256 (short) rows
     const int a = rowptr[r2] - sa, b = rowptr[r2 + 1] - sa;
     T acc = T(0);
     for (int j = a; j < b; ++j) acc = acc + prod[j];
-    epi((int64_t)r2, 0, acc);
+    const auto pre2 = epi.load((int64_t)r2, 0);
+    epi.apply((int64_t)r2, 0, acc, pre2);
+    if constexpr (Epi::NRED > 0) red = red + epi.redv(acc, pre2);
+  }
+  if constexpr (Epi::NRED > 0) {                                  // fixed-order workgroup sum -> partials[tile]
+    __shared__ T wred[GLA_BLOCK / 64];
+    red = wave_sum(red);
+    if ((tid & 63) == 0) wred[tid >> 6] = red;
+    __syncthreads();
+    if (tid == 0) epi.partials_ptr()[t] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
   }
 }
 
@@ -335,12 +406,15 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
   __syncthreads();
   constexpr int RPP = GLA_BLOCK / LPR;          // rows per pass
   const int k0 = (tid % LPR) * 2, rsub = tid / LPR;
+  T2 red = {T(0), T(0)};
+  const auto gxs0 = epi.template gx_load<T2>(min(k0, max(K - 2, 0)));
   for (int r = r0 + rsub; r < r1; r += RPP) {
     int a, b;
     if (r - r0 < SPMM_ROWCAP) { a = srow[r - r0]; b = srow[r - r0 + 1]; }
     else { a = rowptr[r] - s; b = rowptr[r + 1] - s; }
     for (int k = k0; k < K; k += 2 * LPR) {
       const auto pre = epi.template loadv<T2>((int64_t)r, k);
+      const auto gxs = (k == k0) ? gxs0 : epi.template gx_load<T2>(k);
       T2 acc = {T(0), T(0)};
       const T* Xk = X + k;
       if constexpr (MODE == 0) {
@@ -348,17 +422,18 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
         for (; j + 4 <= b; j += 4) {
           T2 xv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xv[u] = ldv<T2>(Xk + (int64_t)scol[j + u] * ldx);
+          for (int u = 0; u < 4; ++u) xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + u] * ldx), gxs);
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc = acc + sval[j + u] * xv[u];
         }
         if (j + 2 <= b) {
-          const T2 x0 = ldv<T2>(Xk + (int64_t)scol[j] * ldx), x1 = ldv<T2>(Xk + (int64_t)scol[j + 1] * ldx);
+          const T2 x0 = epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
+          const T2 x1 = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + 1] * ldx), gxs);
           acc = acc + sval[j] * x0;
           acc = acc + sval[j + 1] * x1;
           j += 2;
         }
-        if (j < b) acc = acc + sval[j] * ldv<T2>(Xk + (int64_t)scol[j] * ldx);
+        if (j < b) acc = acc + sval[j] * epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
       } else {
         for (int j = a; j < b; j += 4) {
           T v[4];
@@ -367,7 +442,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
           for (int u = 0; u < 4; ++u) {
             const int jj = min(j + u, b - 1);
             v[u] = sval[jj];
-            xv[u] = ldv<T2>(Xk + (int64_t)scol[jj] * ldx);
+            xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[jj] * ldx), gxs);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -377,6 +452,21 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
         }
       }
       epi.template applyv<T2>((int64_t)r, k, acc, pre);
+      if constexpr (Epi::NRED > 0) red = red + epi.template redv<T2>(acc, pre);
+    }
+  }
+  if constexpr (Epi::NRED > 0) {       // lanes with the same rhs pair are LPR apart: fixed-order tree over the rows
+    __syncthreads();
+    T2* sred = reinterpret_cast<T2*>(smem_raw);
+    sred[tid] = red;
+    __syncthreads();
+    for (int st = GLA_BLOCK / 2; st >= LPR; st >>= 1) {
+      if (tid < st) sred[tid] = sred[tid] + sred[tid + st];
+      __syncthreads();
+    }
+    if (tid < LPR && k0 < K) {
+      epi.partials_ptr()[(int64_t)t * K + k0] = sred[tid].x;
+      if (k0 + 1 < K) epi.partials_ptr()[(int64_t)t * K + k0 + 1] = sred[tid].y;
     }
   }
 }
@@ -384,13 +474,6 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
 // ------------------------------------------------------------------------------------------------
 // fallback for plans with a row longer than the LDS tile: one wave per row, tree-ordered sum
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = v + __shfl_down(v, off, 64);
-  return v;
-}
-
 template <typename T, class Epi>
 __global__ __launch_bounds__(GLA_BLOCK) void spmm_vector_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
@@ -416,6 +499,8 @@ template <typename T, class Epi>
 int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int which, hipStream_t st) {
   if (A->n_rows == 0) return GLA_OK;
   const T* val = static_cast<const T*>(A->val);
+  if (Epi::NRED > 0 && (A->long_rows || (K > 1 && !((K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec2_ok()))))
+    return GLA_ERR_UNSUPPORTED;           // reducing epilogues exist for the K = 1 and paired-rhs kernels only
   if (A->long_rows) {
     if (which == 1) return GLA_OK;        // nothing is "interior" for the fallback: all rows run after the halo
     const int64_t waves_needed = A->n_rows;
@@ -455,7 +540,8 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
 #undef GLA_SPMV2
   } else {
     const size_t lds = (size_t)A->lds_elems * (sizeof(T) + sizeof(int32_t));
-    const bool vec2 = (K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec2_ok() && g_tuning.spmm_variant != 1;
+    const bool vec2 = (K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec2_ok() &&
+                      (g_tuning.spmm_variant != 1 || Epi::NRED > 0);
 #define GLA_SPMM_CASE(KP_)                                                                              \
   hipLaunchKernelGGL((spmm_stream_kernel<T, KP_, Epi>), grid, block, lds, st, A->rowptr, A->col, val, X, \
                      ldx, K, A->lds_elems, tm, epi)
@@ -686,7 +772,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage1(const T* __restrict_
     T acc = T(0);
     if (k < K)
       for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n; r += (int64_t)gridDim.x * RPP)
-        acc = acc + X[r * ldx + k] * Y[r * ldy + k];
+        acc = acc + (Y ? X[r * ldx + k] * Y[r * ldy + k] : X[r * ldx + k]);   // Y == nullptr: plain column sums
     red[tid] = acc;
     __syncthreads();
     for (int st = GLA_BLOCK / 2; st >= KP; st >>= 1) {
@@ -918,6 +1004,35 @@ int gla_col_scale_rsqrt(int dtype, int64_t n, int K, const void* X, int64_t ldx,
   if (n == 0) return GLA_OK;
   GLA_DISPATCH(dtype, {
     return launch_col_scale<T>(n, K, (const T*)X, ldx, (const T*)sumsq, (T*)Y, ldy, (hipStream_t)stream);
+  })
+}
+
+int64_t gla_power_work_bytes(gla_csr_t A, int K, int dtype) {
+  if (!A || K < 1) return -1;      // tile partials [n_tiles, K] + second-stage partials [DOT_BLOCKS_MAX, K]
+  return ((int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) + DOT_BLOCKS_MAX) * K * (dtype == GLA_F64 ? 8 : 4);
+}
+
+int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, const void* nrm_in,
+                   const void* rnrm_in, void* Y, int64_t ldy, void* sumsq_out, void* work, int which,
+                   gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!X || !Y || !work || ldx < K || ldy < K || ((nrm_in == nullptr) != (rnrm_in == nullptr)))
+    return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = dtype == GLA_F64 ? 8 : 4;
+  if (which != 2)          // boundary launches add to the partials the interior launch already zeroed
+    GLA_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)(A->n_tiles > 0 ? A->n_tiles : 1) * K * esz, st));
+  GLA_DISPATCH(dtype, {
+    EpiPower<T> epi{(T*)Y, ldy, (const T*)nrm_in, (const T*)rnrm_in, (T*)work};
+    rc = launch_rows<T>(A, K, (const T*)X, ldx, epi, which, st);
+    if (rc) return rc;
+    if (sumsq_out && which != 1) {     // column sums of the tile partials once every tile has contributed
+      T* tile_part = (T*)work;
+      return launch_col_dot<T>(A->n_tiles, K, tile_part, K, (const T*)nullptr, K, (T*)sumsq_out,
+                               tile_part + (int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) * K, st);
+    }
+    return GLA_OK;
   })
 }
 

@@ -217,11 +217,22 @@ class RowBlockPower(RowBlockOps):
         buf[:p.n_local] = b0
         y = torch.empty_like(b0)
         nrm = torch.zeros(K, dtype=b0.dtype, device=b0.device)
+        ss, work, nrm_in = torch.zeros(K, dtype=b0.dtype, device=b0.device), None, None
+        cur, nxt = buf, p.new_buffer(K, b0.dtype, b0.device)
         for _ in range(int(num_iter)):
-            self.run(buf, lambda which: self.plan.spmm(buf, out=y, which=which))
-            ss = p.all_reduce_sum(col_dot(y, y))
-            buf[:p.n_local] = col_scale_rsqrt(y, ss)
-            nrm = torch.sqrt(ss)
+            # fused step: gathers read cur (local + halo) ./ nrm_in, y lands in nxt's local part; the second-stage
+            # reduction of the tile partials runs with the boundary launch, the all-reduce makes it global
+            def launch(which, cur=cur, nxt=nxt):
+                nonlocal work
+                _, _, work = self.plan.power_step(cur, nrm=nrm_in, out=nxt[:p.n_local], which=which, work=work, sumsq=ss)
+            self.run(cur, launch)
+            p.all_reduce_sum(ss)
+            nrm_in = torch.sqrt(ss)
+            nrm = nrm_in.clone()
+            cur, nxt = nxt, cur
+        if int(num_iter) > 0:
+            buf = p.new_buffer(K, b0.dtype, b0.device)
+            buf[:p.n_local] = col_scale_rsqrt(cur[:p.n_local], ss)
         self.run(buf, lambda which: self.plan.spmm(buf, out=y, which=which))
         bl = buf[:p.n_local]
         sums = p.all_reduce_sum(torch.stack([col_dot(bl, y), col_dot(bl, bl)]))

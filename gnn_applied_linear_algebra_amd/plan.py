@@ -190,6 +190,26 @@ class CsrPlan:
                                    ptr(X), ldx, float(alpha_old), float(alpha_new), float(beta), which,
                                    stream_ptr(self.device)))
 
+    def power_step(self, X, nrm=None, out=None, which=ALL_TILES, work=None, sumsq=None):
+        """Fused power-method step: Y = A (X ./ nrm), sumsq[k] = sum_i Y[i,k]^2 (PowerMethodGNN.py:86-207).
+        Returns (Y, sumsq, work); raises GlaError(-5) when the plan / K has no fused kernel."""
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        self._need(X.dtype)
+        code = dtype_code(X.dtype)
+        Y = torch.empty((self.n_rows, K), dtype=X.dtype, device=self.device) if out is None else out
+        Y, Ky, ldy = _dense(Y, self.n_rows, "Y")
+        assert Ky == K and Y.dtype == X.dtype
+        if nrm is not None:
+            assert nrm.numel() == K and nrm.dtype == X.dtype and nrm.is_cuda and nrm.is_contiguous()
+        if work is None:
+            work = torch.empty(lib().gla_power_work_bytes(self._h, K, code), dtype=torch.uint8, device=self.device)
+        if sumsq is None:
+            sumsq = torch.empty(K, dtype=X.dtype, device=self.device)
+        rnrm = None if nrm is None else torch.reciprocal(nrm)
+        check(lib().gla_power_step(self._h, code, K, ptr(X), ldx, ptr(nrm), ptr(rnrm), ptr(Y), ldy, ptr(sumsq),
+                                   ptr(work), which, stream_ptr(self.device)))
+        return Y, sumsq, work
+
     def edge_products(self, X):
         """c_e = A_e * X[col_e] in EDGE order, [nnz, K]."""
         X, K, ldx = _dense(X, self.n_cols, "X")

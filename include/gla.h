@@ -134,6 +134,19 @@ int gla_col_dot(int dtype, int64_t n, int K, const void* X, int64_t ldx, const v
 int gla_col_scale_rsqrt(int dtype, int64_t n, int K, const void* X, int64_t ldx, const void* sumsq,
                         void* Y, int64_t ldy, gla_stream_t stream);
 
+/* One FUSED power-method step on K columns (PowerMethodGNN.py:86-207, the three MetaLayers of an iteration):
+ *   Y = A * (X ./ nrm_in)      (nrm_in [K] = sqrt of the previous sums and rnrm_in [K] = 1 ./ nrm_in, both NULL: X
+ *                               used as is; every gathered value is divided through the reciprocal with one
+ *                               correction step, i.e. the reference's b = b / n up to rare last-place cases)
+ *   sumsq_out[k] = sum_i Y[i,k]^2   (workgroup partials in `work`, then a fixed-order second stage)
+ * work: gla_power_work_bytes(A, K, dtype).  With which_tiles = 1 (interior) the second stage is deferred to the
+ * which_tiles = 2 (boundary) call.  Returns GLA_ERR_UNSUPPORTED for plans with long rows or odd K > 1 (use
+ * gla_spmm + gla_col_dot + gla_col_scale_rsqrt). */
+int64_t gla_power_work_bytes(gla_csr_t A, int K, int dtype);
+int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, const void* nrm_in,
+                   const void* rnrm_in, void* Y, int64_t ldy, void* sumsq_out, void* work, int which_tiles,
+                   gla_stream_t stream);
+
 /* Edge products in EDGE order: C[e,k] = A_e * X[col_e,k] -- the `c_ij`/`z_ij` column every EdgeUpdate
  * returns (e.g. JacobiGNN.py:83-88); materialised only when a caller asks for edge_attr. */
 int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,

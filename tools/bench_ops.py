@@ -55,6 +55,9 @@ for K in KS:
     report(f"jacobi_sweep K={K}", timeit(lambda: plan.jacobi_sweep(diag, B, X, Xo, 0.7)), base + 8 * n + 24 * n * K)
     report(f"cheby_first K={K}", timeit(lambda: plan.cheby_first(B, X, R, P, Xo, -0.25)), base + 40 * n * K)
     report(f"cheby_next K={K}", timeit(lambda: plan.cheby_next(P, P2, R, Xo, -0.25, -0.26, 0.1)), base + 48 * n * K)
+    nrm = torch.sqrt(col_dot(X, X))
+    _, _, wk = plan.power_step(X, nrm=nrm, out=Y)
+    report(f"power_step (fused) K={K}", timeit(lambda: plan.power_step(X, nrm=nrm, out=Y, work=wk)), base + 16 * n * K)
     report(f"col_dot K={K}", timeit(lambda: col_dot(X, B)), 16 * n * K)
     ss = col_dot(X, X)
     report(f"col_scale_rsqrt K={K}", timeit(lambda: col_scale_rsqrt(X, ss)), 16 * n * K)
