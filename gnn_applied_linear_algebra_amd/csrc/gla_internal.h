@@ -31,12 +31,18 @@ struct gla_csr {
   int32_t n_tiles = 0, n_interior = 0, n_boundary = 0;
   int32_t tile_nnz = 0, lds_elems = 0, max_row_len = 0;
   int32_t sorted_input = 1, long_rows = 0;
+  // optional packed stream for the K = 1 kernels (option "compress"): 3 bytes per nonzero instead of 12
+  int16_t* col16 = nullptr;      // [nnz + 16] column minus the first row of the nonzero's tile
+  uint8_t* vcode = nullptr;      // [nnz + 16] index into vdict
+  void* vdict = nullptr;         // [256] distinct values (bit patterns ascending), dtype = val_dtype
+  int32_t packed = 0, col16_state = 0;   // col16_state: 0 not tried, 1 built, -1 does not fit int16
 };
 
 struct gla_tuning {
   int spmv_variant = 0;     // experimental kernel selection for K = 1 (see launch_rows)
   int tile_nnz = 0;         // 0 = automatic (256 * average row length)
   int spmm_variant = 0;     // 0 = paired-rhs 16-byte kernel when alignment allows, 1 = scalar lanes
+  int compress = 0;         // 1: gla_csr_set_values also builds the packed stream when the matrix allows it
 };
 extern gla_tuning g_tuning;
 

@@ -330,6 +330,98 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
   }
 }
 
+// Packed-stream K = 1 kernel (option "compress"): the matrix is read as 1-byte value codes + 2-byte tile-relative
+// columns (3 B per nonzero instead of 12).  Each lane owns 8 consecutive nonzeros: one 8-byte code load and one
+// 16-byte delta load, 8 gathers in flight; values come from the <= 256-entry dictionary staged in LDS.  Products,
+// in-order row sums and the fused vertex update are exactly those of spmv_stream_vec2_kernel (bit-identical).
+template <typename T, class Epi>
+__global__ __launch_bounds__(GLA_BLOCK) void spmv_packed_kernel(
+    const int32_t* __restrict__ rowptr, const int16_t* __restrict__ col16, const uint8_t* __restrict__ vcode,
+    const T* __restrict__ vdict, const T* __restrict__ x, unsigned n_cols, TileMap tm, Epi epi) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sdict = reinterpret_cast<T*>(smem_raw);               // [256]
+  T* prod = sdict + 256;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, e = ti.w;
+  if (r0 >= r1) return;
+  const int tid = threadIdx.x;
+  const int r = r0 + tid;
+  int ra = 0, rb = 0;
+  typename Epi::Pre pre;
+  if (r < r1) {
+    ra = rowptr[r];
+    rb = rowptr[r + 1];
+    pre = epi.load((int64_t)r, 0);
+  }
+  const auto gxs = epi.template gx_load<T>(0);
+  const int sa = s & ~7;                       // multiple of 8 -> 8-byte aligned codes, 16-byte aligned deltas
+  const int ngrp = (e - sa + 7) >> 3;
+  const uint2* code8 = reinterpret_cast<const uint2*>(vcode + sa);
+  const int4* delta8 = reinterpret_cast<const int4*>(col16 + sa);
+  sdict[tid] = vdict[tid];
+  bool first = true;
+  for (int base = 0; base < ngrp; base += GLA_BLOCK) {
+    const int q = min(base + tid, ngrp - 1);   // branch-free: surplus lanes redo the last group
+    const uint2 cw = code8[q];
+    const int4 dw = delta8[q];
+    if (first) { __syncthreads(); first = false; }          // dictionary visible (loads above are in flight)
+    unsigned cc[8];
+    T v[8], xv[8];
+    const unsigned dd[4] = {(unsigned)dw.x, (unsigned)dw.y, (unsigned)dw.z, (unsigned)dw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lo = (int)(short)(dd[i] & 0xFFFFu), hi = (int)(short)(dd[i] >> 16);
+      cc[2 * i] = min((unsigned)(r0 + lo), n_cols - 1);      // elements of neighbouring tiles (alignment slack)
+      cc[2 * i + 1] = min((unsigned)(r0 + hi), n_cols - 1);  // may decode out of range: clamp, never summed
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xv[i] = epi.gx(x[cc[i]], gxs);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = sdict[((i < 4 ? cw.x : cw.y) >> (8 * (i & 3))) & 0xFFu];
+    T2* dst = reinterpret_cast<T2*>(prod + 8 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      T2 pp;
+      pp.x = v[2 * i] * xv[2 * i];
+      pp.y = v[2 * i + 1] * xv[2 * i + 1];
+      dst[i] = pp;
+    }
+  }
+  __syncthreads();
+
+  T red = T(0);
+  if (r < r1) {
+    T acc = T(0);
+    int j = ra - sa;
+    const int jend = rb - sa;
+    for (; j + 4 <= jend; j += 4) {
+      const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
+      acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+    }
+    for (; j < jend; ++j) acc = acc + prod[j];
+    epi.apply((int64_t)r, 0, acc, pre);
+    if constexpr (Epi::NRED > 0) red = epi.redv(acc, pre);
+  }
+  for (int r2 = r + GLA_BLOCK; r2 < r1; r2 += GLA_BLOCK) {
+    const int a = rowptr[r2] - sa, b = rowptr[r2 + 1] - sa;
+    T acc = T(0);
+    for (int j = a; j < b; ++j) acc = acc + prod[j];
+    const auto pre2 = epi.load((int64_t)r2, 0);
+    epi.apply((int64_t)r2, 0, acc, pre2);
+    if constexpr (Epi::NRED > 0) red = red + epi.redv(acc, pre2);
+  }
+  if constexpr (Epi::NRED > 0) {
+    __shared__ T wred[GLA_BLOCK / 64];
+    red = wave_sum(red);
+    if ((tid & 63) == 0) wred[tid >> 6] = red;
+    __syncthreads();
+    if (tid == 0) epi.partials_ptr()[t] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K > 1: val/col staged in LDS, lanes = (row, rhs)
 // ------------------------------------------------------------------------------------------------
@@ -522,6 +614,13 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   if (tm.n_tiles == 0) return GLA_OK;
   tm.tiles_per_xcd = (tm.n_tiles + GLA_XCDS - 1) / GLA_XCDS;
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
+  if (K == 1 && A->packed && g_tuning.compress && A->n_cols * (int64_t)sizeof(T) < ((int64_t)1 << 32)) {
+    const size_t ldsp = (size_t)(256 + A->lds_elems + 16) * sizeof(T);
+    hipLaunchKernelGGL((spmv_packed_kernel<T, Epi>), grid, block, ldsp, st, A->rowptr, A->col16, A->vcode,
+                       (const T*)A->vdict, X, (unsigned)A->n_cols, tm, epi);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  }
   if (K == 1) {
     const size_t lds = (size_t)(A->lds_elems + 2) * sizeof(T);
 #define GLA_SPMV2(N_, NT_, PF_) \

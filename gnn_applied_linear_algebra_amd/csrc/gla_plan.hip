@@ -8,6 +8,7 @@
 #include <cstring>
 #include "gla_internal.h"
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace {
 
@@ -229,6 +230,131 @@ __global__ __launch_bounds__(GLA_BLOCK) void compact_apply_kernel(const int64_t*
   }
 }
 
+
+// ---- packed stream (option "compress") ---------------------------------------------------------------------
+// col16[p] = col[p] - (first row of p's tile); flag set when a delta does not fit int16
+__global__ __launch_bounds__(GLA_BLOCK) void col16_kernel(const int32_t* __restrict__ col, const int4* __restrict__ tile_info,
+                                                          int n_tiles, int16_t* __restrict__ col16, int* fail) {
+  const int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  const int4 ti = tile_info[t];
+  int bad = 0;
+  for (int p = ti.z + threadIdx.x; p < ti.w; p += GLA_BLOCK) {
+    const int d = col[p] - ti.x;
+    if (d < -32768 || d > 32767) bad = 1;
+    col16[p] = (int16_t)d;
+  }
+  if (bad) atomicOr(fail, 1);
+}
+
+template <typename T, typename U>
+__global__ __launch_bounds__(GLA_BLOCK) void val_bits_kernel(const T* __restrict__ val, int64_t nnz, U* __restrict__ keys) {
+  for (int64_t p = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * GLA_BLOCK) {
+    U u;
+    memcpy(&u, &val[p], sizeof(U));
+    keys[p] = u;
+  }
+}
+
+template <typename U>
+__global__ __launch_bounds__(GLA_BLOCK) void uniq_flags_kernel(const U* __restrict__ keys, int64_t n, int64_t* __restrict__ flags) {
+  for (int64_t t = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; t < n; t += (int64_t)gridDim.x * GLA_BLOCK)
+    flags[t] = (t == 0 || keys[t] != keys[t - 1]) ? 1 : 0;
+}
+
+template <typename U>
+__global__ __launch_bounds__(GLA_BLOCK) void uniq_gather_kernel(const U* __restrict__ keys, int64_t n,
+                                                                const int64_t* __restrict__ pos, U* __restrict__ dict) {
+  for (int64_t t = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; t < n; t += (int64_t)gridDim.x * GLA_BLOCK)
+    if ((t == 0 || keys[t] != keys[t - 1]) && pos[t] < 256) dict[pos[t]] = keys[t];
+}
+
+template <typename T, typename U>
+__global__ __launch_bounds__(GLA_BLOCK) void val_code_kernel(const T* __restrict__ val, int64_t nnz, const U* __restrict__ dict,
+                                                             int n_dict, uint8_t* __restrict__ code) {
+  for (int64_t p = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; p < nnz + 16; p += (int64_t)gridDim.x * GLA_BLOCK) {
+    if (p >= nnz) { code[p] = 0; continue; }
+    U u;
+    memcpy(&u, &val[p], sizeof(U));
+    int lo = 0, hi = n_dict - 1;                       // dict is sorted by bit pattern; the value is present
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (dict[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    code[p] = (uint8_t)lo;
+  }
+}
+
+template <typename T, typename U>
+int build_packed(gla_csr* p, hipStream_t st) {
+  p->packed = 0;
+  if (p->nnz == 0 || p->long_rows) return GLA_OK;
+  hipError_t e;
+#define PK(expr) do { e = (expr); if (e != hipSuccess) return -(1000 + (int)e); } while (0)
+  int* d_fail = nullptr;
+  if (p->col16_state == 0) {
+    PK(hipMalloc(&p->col16, (p->nnz + 16) * sizeof(int16_t)));
+    PK(hipMemsetAsync(p->col16, 0, (p->nnz + 16) * sizeof(int16_t), st));
+    PK(hipMalloc(&d_fail, sizeof(int)));
+    PK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+    hipLaunchKernelGGL(col16_kernel, dim3(p->n_tiles), dim3(GLA_BLOCK), 0, st, p->col,
+                       reinterpret_cast<const int4*>(p->tile_info), p->n_tiles, p->col16, d_fail);
+    int h_fail = 0;
+    PK(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    PK(hipStreamSynchronize(st));
+    (void)hipFree(d_fail);
+    p->col16_state = h_fail ? -1 : 1;
+  }
+  if (p->col16_state < 0) return GLA_OK;
+  // value dictionary: sort the bit patterns, count the distinct ones
+  U *keys = nullptr, *keys2 = nullptr;
+  int64_t *flags = nullptr, *pos = nullptr;
+  void *tmp = nullptr, *tmp2 = nullptr;
+  int rc = GLA_OK;
+  size_t tb = 0, tb2 = 0;
+  int64_t last[2] = {0, 0};
+  const int64_t n = p->nnz;
+  unsigned gridn = (unsigned)((n + GLA_BLOCK - 1) / GLA_BLOCK > 4096 ? 4096 : (n + GLA_BLOCK - 1) / GLA_BLOCK);
+#define PKG(expr) do { e = (expr); if (e != hipSuccess) { rc = -(1000 + (int)e); goto done; } } while (0)
+  PKG(hipMalloc(&keys, n * sizeof(U)));
+  PKG(hipMalloc(&keys2, n * sizeof(U)));
+  hipLaunchKernelGGL((val_bits_kernel<T, U>), dim3(gridn), dim3(GLA_BLOCK), 0, st, (const T*)p->val, n, keys);
+  PKG(rocprim::radix_sort_keys(nullptr, tb, keys, keys2, (size_t)n, 0u, (unsigned)(8 * sizeof(U)), st));
+  PKG(hipMalloc(&tmp, tb ? tb : 16));
+  PKG(rocprim::radix_sort_keys(tmp, tb, keys, keys2, (size_t)n, 0u, (unsigned)(8 * sizeof(U)), st));
+  PKG(hipMalloc(&flags, n * sizeof(int64_t)));
+  PKG(hipMalloc(&pos, n * sizeof(int64_t)));
+  hipLaunchKernelGGL((uniq_flags_kernel<U>), dim3(gridn), dim3(GLA_BLOCK), 0, st, keys2, n, flags);
+  PKG(rocprim::exclusive_scan(nullptr, tb2, flags, pos, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), st));
+  PKG(hipMalloc(&tmp2, tb2 ? tb2 : 16));
+  PKG(rocprim::exclusive_scan(tmp2, tb2, flags, pos, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), st));
+  PKG(hipMemcpyAsync(&last[0], pos + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  PKG(hipMemcpyAsync(&last[1], flags + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  PKG(hipStreamSynchronize(st));
+  if (last[0] + last[1] <= 256) {
+    const int n_dict = (int)(last[0] + last[1]);
+    if (!p->vdict) PKG(hipMalloc(&p->vdict, 256 * sizeof(double)));
+    if (!p->vcode) PKG(hipMalloc(&p->vcode, (n + 16) * sizeof(uint8_t)));
+    PKG(hipMemsetAsync(p->vdict, 0, 256 * sizeof(double), st));
+    hipLaunchKernelGGL((uniq_gather_kernel<U>), dim3(gridn), dim3(GLA_BLOCK), 0, st, keys2, n, pos, (U*)p->vdict);
+    hipLaunchKernelGGL((val_code_kernel<T, U>), dim3(gridn), dim3(GLA_BLOCK), 0, st, (const T*)p->val, n,
+                       (const U*)p->vdict, n_dict, p->vcode);
+    PKG(hipGetLastError());
+    PKG(hipStreamSynchronize(st));
+    p->packed = 1;
+  }
+done:
+  if (keys) (void)hipFree(keys);
+  if (keys2) (void)hipFree(keys2);
+  if (flags) (void)hipFree(flags);
+  if (pos) (void)hipFree(pos);
+  if (tmp) (void)hipFree(tmp);
+  if (tmp2) (void)hipFree(tmp2);
+  return rc;
+#undef PK
+#undef PKG
+}
+
 inline unsigned grid_for(int64_t work, int64_t per_block = GLA_BLOCK, int64_t cap = 256 * 16) {
   int64_t b = (work + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -276,6 +402,7 @@ int gla_version(void) { return 100; }
 int gla_set_option(const char* name, int64_t value) {
   if (!name) return GLA_ERR_INVALID_ARG;
   if (!strcmp(name, "spmv_variant")) { g_tuning.spmv_variant = (int)value; return GLA_OK; }
+  if (!strcmp(name, "compress")) { g_tuning.compress = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "spmm_variant")) { g_tuning.spmm_variant = (int)value; return GLA_OK; }
   if (!strcmp(name, "tile_nnz")) {
     if (value != 0 && (value < 256 || value > GLA_LDS_ELEMS_MAX - 64)) return GLA_ERR_INVALID_ARG;
@@ -308,6 +435,9 @@ int gla_csr_destroy(gla_csr_t p) {
   if (p->tile_row) (void)hipFree(p->tile_row);
   if (p->tile_info) (void)hipFree(p->tile_info);
   if (p->tile_lists) (void)hipFree(p->tile_lists);
+  if (p->col16) (void)hipFree(p->col16);
+  if (p->vcode) (void)hipFree(p->vcode);
+  if (p->vdict) (void)hipFree(p->vdict);
   delete p;
   return GLA_OK;
 }
@@ -369,6 +499,8 @@ int gla_csr_create_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const i
     const double avg = n_rows > 0 ? (double)nnz / (double)n_rows : 0.0;
     int64_t target = (int64_t)(GLA_BLOCK * (avg < 1.0 ? 1.0 : avg) + 0.5);
     if (target < GLA_TILE_NNZ_MIN) target = GLA_TILE_NNZ_MIN;
+    // packed stream: one batch of 8 nonzeros per lane covers 2048 entries (incl. alignment slack and the last row)
+    if (g_tuning.compress && p->max_row_len <= 1000) target = 2040 - p->max_row_len;
     if (g_tuning.tile_nnz > 0) target = g_tuning.tile_nnz;
     p->long_rows = (p->max_row_len > GLA_LDS_ELEMS_MAX - GLA_TILE_NNZ_MIN) ? 1 : 0;
     if (!p->long_rows && target > GLA_LDS_ELEMS_MAX - p->max_row_len) target = GLA_LDS_ELEMS_MAX - p->max_row_len;
@@ -411,6 +543,9 @@ int gla_csr_set_values(gla_csr_t p, const void* edge_val, int64_t stride, int dt
                        (const float*)edge_val, stride, p->perm, p->nnz, (float*)p->val);
   GLA_LAUNCH_CHECK();
   p->val_dtype = dtype;
+  p->packed = 0;
+  if (g_tuning.compress)
+    return dtype == GLA_F64 ? build_packed<double, uint64_t>(p, st) : build_packed<float, uint32_t>(p, st);
   return GLA_OK;
 }
 
@@ -419,7 +554,7 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->n_rows = p->n_rows; info->n_cols = p->n_cols; info->nnz = p->nnz;
   info->sorted_input = p->sorted_input; info->max_row_len = p->max_row_len;
   info->n_tiles = p->n_tiles; info->tile_nnz = p->tile_nnz; info->lds_elems = p->lds_elems;
-  info->long_rows = p->long_rows; info->val_dtype = p->val_dtype;
+  info->long_rows = p->long_rows; info->val_dtype = p->val_dtype; info->packed = p->packed;
   return GLA_OK;
 }
 

@@ -83,6 +83,7 @@ class CsrPlan:
         check(lib().gla_csr_set_values(self._h, ptr(edge_val), max(int(stride), 1), dtype_code(edge_val.dtype),
                                        stream_ptr(self.device)))
         self.val_dtype = edge_val.dtype
+        check(lib().gla_csr_info(self._h, ctypes.byref(self.info)))          # `packed` may have changed
 
     def set_values_cached(self, edge_attr):
         """Refresh the CSR-ordered values unless `edge_attr` is the very tensor object they were gathered from

@@ -655,3 +655,52 @@ def test_full_size_config4_8192():
     want = A.jacobi(diag.numpy(), b.numpy(), x.numpy(), 0.7, 3)
     eq(got, want)
     eq(r, b.numpy() - A.spmm(want))
+
+
+# ---------------------------------------------------------------------------------------------------
+# opt-in packed matrix stream (option "compress"): bit-identical results, falls back when not applicable
+# ---------------------------------------------------------------------------------------------------
+def test_packed_stream_bit_identical():
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+    gen = torch.Generator().manual_seed(31)
+
+    def run_all(ei, ev, n, dtype):
+        ei_d, ev_d = d(ei), d(ev.to(dtype))
+        b = d(torch.rand(n, 1, generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(dtype))
+        x = d(torch.rand(n, 1, generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(dtype))
+        diag = torch.full((n, 1), -4.0, dtype=dtype, device=DEV)
+        plan = gla.CsrPlan(ei_d, n)
+        plan.set_values(ev_d)
+        outs = [plan.spmm(x), plan.residual(b, x), plan.jacobi_sweeps(diag.reshape(-1), b, x, 0.7, 5)]
+        r, p, xo, p2 = (torch.empty_like(x) for _ in range(4))
+        plan.cheby_first(b, x, r, p, xo, -0.25)
+        plan.cheby_next(p, p2, r, xo, -0.25, -0.26, 0.1)
+        y, ss, _ = plan.power_step(x, nrm=torch.tensor([1.7], dtype=dtype, device=DEV))
+        return plan, outs + [r, p2, xo, y, ss]
+
+    cases = []
+    ei, ev = rp.laplacianfun_torch(130)
+    cases.append(("laplacian", ei, ev, 130 * 130, True))
+    ei, ev = rp.heateqnfem2dfun([71, 59], [1.0, 4.0])
+    cases.append(("fem", ei, ev, 70 * 58, True))
+    ei, ev = rp.laplacianfun_torch(40)
+    cases.append(("random values (> 256 distinct)", ei, torch.rand(ei.shape[1], 1, generator=gen, dtype=torch.float64), 1600, False))
+    n = 70000                                    # couplings further than 32767 columns away: int16 deltas do not fit
+    k = torch.arange(n)
+    ei = torch.stack([torch.cat([k, k]), torch.cat([k, (k + 40000) % n])])
+    ei = ei[:, torch.argsort(ei[0], stable=True)]
+    cases.append(("wide band", ei, torch.ones(2 * n, 1, dtype=torch.float64), n, False))
+    for name, ei, ev, n, want_packed in cases:
+        for dtype in (torch.float64, torch.float32):
+            check(lib().gla_set_option(b"compress", 0))
+            _, ref_out = run_all(ei, ev, n, dtype)
+            try:
+                check(lib().gla_set_option(b"compress", 1))
+                plan, out = run_all(ei, ev, n, dtype)
+            finally:
+                check(lib().gla_set_option(b"compress", 0))
+            assert bool(plan.info.packed) == want_packed, (name, dtype)
+            for a, b_ in zip(out[:-1], ref_out[:-1]):
+                eq(a, b_)
+            # the sum of squares is grouped by row tile, and packed plans use other tiles: equal to rounding only
+            close(out[-1], ref_out[-1], rtol=1e-12 if dtype == torch.float64 else 1e-5)

@@ -33,6 +33,19 @@ def main():
         p = gla.CsrPlan(ei, n)
         p.set_values(ev)
         plans[tnz] = p
+    if "--compress" in sys.argv:                       # packed-stream plan (3 B/nnz), timed as tile key -1
+        ptiles = [0]
+        for a in sys.argv[1:]:
+            if a.startswith("--ptiles="):
+                ptiles = [int(v) for v in a.split("=")[1].split(",")]
+        check(lib().gla_set_option(b"compress", 1))
+        for i, pt in enumerate(ptiles):
+            check(lib().gla_set_option(b"tile_nnz", pt))
+            pc = gla.CsrPlan(ei, n)
+            pc.set_values(ev)
+            print("packed plan:", bool(pc.info.packed), pc.info.tile_nnz)
+            plans[-1 - i] = pc
+            tiles = tiles + [-1 - i]
     sweeps, rounds = 10, 7
     ref = None
     res = {}
@@ -40,6 +53,7 @@ def main():
         for tnz in tiles:
             for v in variants:
                 check(lib().gla_set_option(b"spmv_variant", v))
+                check(lib().gla_set_option(b"compress", 1 if tnz < 0 else 0))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 out = plans[tnz].jacobi_sweeps(diag, b, x, 0.7, sweeps)
@@ -69,7 +83,7 @@ def main():
         ts = sorted(ts)
         med, mn = ts[len(ts) // 2], ts[0]
         info = plans[tnz].info
-        print(f"tile_nnz={info.tile_nnz:5d} lds={info.lds_elems:5d} variant={v}: median {med:7.1f} us  min {mn:7.1f} us  "
+        print(f"tile_nnz={info.tile_nnz:5d} lds={info.lds_elems:5d} {'PACKED ' if tnz < 0 else ''}variant={v}: median {med:7.1f} us  min {mn:7.1f} us  "
               f"-> {B / med / 1e3:7.1f} GB/s ({B / med / 8e6 * 100:5.1f}% of 8 TB/s)")
 
 
