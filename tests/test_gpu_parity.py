@@ -704,3 +704,15 @@ def test_packed_stream_bit_identical():
                 eq(a, b_)
             # the sum of squares is grouped by row tile, and packed plans use other tiles: equal to rounding only
             close(out[-1], ref_out[-1], rtol=1e-12 if dtype == torch.float64 else 1e-5)
+
+
+def test_reference_demo_self_checks():
+    """examples/reference_demos.py = the reference's own `__main__` self-checks with the imports
+    switched to this package; every printed diagnostic must be within the value the reference itself reports."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "reference_demos.py")], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
