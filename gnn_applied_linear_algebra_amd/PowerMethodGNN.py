@@ -2,7 +2,7 @@
 
 Per iteration the reference runs three MetaLayers (b <- A b; n = sqrt(sum b^2); b <- b / n); here an iteration is
 ONE fused kernel (gla_power_step): the normalisation b = y / n of the previous iteration is applied to the gathered
-operand (same rounding as the reference's division), y = A b is stored once and the workgroups leave their partial
+operand (reciprocal + one correction step: the reference's quotient except for rare last-place cases), y = A b is stored once and the workgroups leave their partial
 sums of y^2 for a fixed-order second stage -- 16 n bytes of vector traffic per iteration instead of 40 n.  Plans /
 K without a fused kernel (long rows, odd K > 1) use gla_spmm + gla_col_dot + gla_col_scale_rsqrt.  The Rayleigh
 block is an SpMV plus two reductions.

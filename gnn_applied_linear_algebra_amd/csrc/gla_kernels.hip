@@ -1003,6 +1003,7 @@ int gla_spmm(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* Y,
              gla_stream_t stream) {
   int rc = check_plan(A, dtype, K);
   if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
   if (!X || !Y || ldx < K || ldy < K) return GLA_ERR_INVALID_ARG;
   GLA_DISPATCH(dtype, {
     EpiStore<T> epi{(T*)Y, ldy};
@@ -1014,6 +1015,7 @@ int gla_residual(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, cons
                  int64_t ldr, int which, gla_stream_t stream) {
   int rc = check_plan(A, dtype, K);
   if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
   if (!B || !X || !R || ldb < K || ldx < K || ldr < K) return GLA_ERR_INVALID_ARG;
   GLA_DISPATCH(dtype, {
     EpiResidual<T> epi{(const T*)B, ldb, (T*)R, ldr};
@@ -1025,6 +1027,7 @@ int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void
                      int64_t ldx, void* Xout, int64_t ldxo, double w, int which, gla_stream_t stream) {
   int rc = check_plan(A, dtype, K);
   if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
   if (!diag || !B || !X || !Xout || X == Xout || ldb < K || ldx < K || ldxo < K) return GLA_ERR_INVALID_ARG;
   GLA_DISPATCH(dtype, {
     EpiJacobi<T> epi{(const T*)diag, (const T*)B, ldb, (const T*)X, ldx, (T*)Xout, ldxo, (T)w};
@@ -1056,6 +1059,7 @@ int gla_cheby_first(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, c
                     gla_stream_t stream) {
   int rc = check_plan(A, dtype, K);
   if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
   if (!B || !X || !R || !P || !Xout || X == Xout || ldb < K || ldx < K || ldr < K || ldp < K || ldxo < K)
     return GLA_ERR_INVALID_ARG;
   GLA_DISPATCH(dtype, {
@@ -1069,6 +1073,7 @@ int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, vo
                    gla_stream_t stream) {
   int rc = check_plan(A, dtype, K);
   if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
   if (!P || !Pout || !R || !X || P == Pout || ldp < K || ldpo < K || ldr < K || ldx < K)
     return GLA_ERR_INVALID_ARG;
   GLA_DISPATCH(dtype, {
@@ -1116,6 +1121,7 @@ int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, co
                    gla_stream_t stream) {
   int rc = check_plan(A, dtype, K);
   if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
   if (!X || !Y || !work || ldx < K || ldy < K || ((nrm_in == nullptr) != (rnrm_in == nullptr)))
     return GLA_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -1139,6 +1145,7 @@ int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx,
                       gla_stream_t stream) {
   int rc = check_plan(A, dtype, K);
   if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
   if (!X || (A->nnz > 0 && !C) || ldx < K || ldc < K) return GLA_ERR_INVALID_ARG;
   if (A->nnz == 0) return GLA_OK;
   GLA_DISPATCH(dtype, {

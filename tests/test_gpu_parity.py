@@ -716,3 +716,28 @@ def test_reference_demo_self_checks():
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "reference_demos.py")], capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_degenerate_sizes():
+    """n = 0, n = 1, a graph with vertices but no edges: every entry point returns the empty / trivial result."""
+    e0 = torch.zeros((2, 0), dtype=torch.long, device=DEV)
+    for n in (0, 1, 5):
+        plan = gla.CsrPlan(e0, n)
+        plan.set_values(torch.zeros((0, 1), dtype=torch.float64, device=DEV))
+        x = torch.ones(n, 2, dtype=torch.float64, device=DEV)
+        eq(plan.spmm(x), np.zeros((n, 2)))
+        eq(plan.residual(x, x), np.ones((n, 2)))
+        if n:
+            diag = torch.full((n,), 2.0, dtype=torch.float64, device=DEV)
+            eq(plan.jacobi_sweeps(diag, x, x, 0.5, 3), np.full((n, 2), 1.0 + 3 * 0.25))   # x += w*b/d, 3 times
+    # one vertex with a self loop: x <- x + w (b - a x) / a
+    ei = torch.zeros((2, 1), dtype=torch.long, device=DEV)
+    va = torch.tensor([[2.0, 3.0, 1.0]], dtype=torch.float64, device=DEV)
+    ea = torch.tensor([[2.0, 0.0]], dtype=torch.float64, device=DEV)
+    x1 = gla.JacobiGNN.JacobiGNN()(1, va, ei, ea, torch.tensor([0.5], dtype=torch.float64))
+    eq(x1, [[1.0 + 0.5 * (3.0 - 2.0) / 2.0]])
+    v, S = gla.CsrPlan(e0, 3), None
+    v.set_values(torch.zeros((0, 1), dtype=torch.float64, device=DEV))
+    vv, SS = v.soc_classic(0.25, torch.float64)
+    eq(vv, np.zeros((3, 1)))
+    assert SS.shape == (0,)
