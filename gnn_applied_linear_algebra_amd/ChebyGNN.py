@@ -11,6 +11,28 @@ import torch
 from ._common import back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
 
 
+def chebyshev_relax(plan, b, x0, g, deg):
+    """Core of ChebyRelaxGNN on SoA operands: b, x0 [n, K] contiguous, g = [c, d] (any device).  Runs `deg` fused
+    steps on `plan` and returns (x, r, p, gathered, g_out) where `gathered` is the vector the last SpMV read
+    (x0 for deg 1, the previous p otherwise -- the z_ij = A_ij * gathered_j of the returned edge attributes)."""
+    gh = g.detach().to("cpu")
+    c, d = gh[0], gh[1]
+    alpha = 1 / d                                                    # ChebyGNN.py:137
+    beta = None
+    r, p, x = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
+    plan.cheby_first(b, x0, r, p, x, float(alpha))
+    gathered = x0
+    p_next = torch.empty_like(p) if deg > 1 else None
+    for it in range(2, deg + 1):
+        beta = 0.5 * (c * alpha) ** 2 if it == 2 else ((c * alpha) / 2) ** 2      # :262 / :282
+        alpha_new = 1 / (d - beta / alpha)                                          # :263 / :283
+        plan.cheby_next(p, p_next, r, x, float(alpha), float(alpha_new), float(beta))
+        gathered, p, p_next = p, p_next, p
+        alpha = alpha_new
+    g_out = torch.hstack([c, d, alpha] if beta is None else [c, d, alpha, beta]).to(g.device)
+    return x, r, p, gathered, g_out
+
+
 class ChebyRelaxGNN(torch.nn.Module):
     def __init__(self, deg=3, return_edge_attr=True):
         super().__init__()
@@ -29,20 +51,6 @@ class ChebyRelaxGNN(torch.nn.Module):
             raise ValueError("vertex_attr must be [n, 2] = [b, x]")
         plan = plan_for(ei, va.shape[0], edge_attr=ea)
         b, x0 = cols(va, 0), cols(va, 1)
-        gh = g.detach().to("cpu")
-        c, d = gh[0], gh[1]
-        alpha = 1 / d                                                    # ChebyGNN.py:137
-        beta = None
-        r, p, x = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
-        plan.cheby_first(b, x0, r, p, x, float(alpha))
-        gathered = x0
-        p_next = torch.empty_like(p) if self.deg > 1 else None
-        for it in range(2, self.deg + 1):
-            beta = 0.5 * (c * alpha) ** 2 if it == 2 else ((c * alpha) / 2) ** 2      # :262 / :282
-            alpha_new = 1 / (d - beta / alpha)                                          # :263 / :283
-            plan.cheby_next(p, p_next, r, x, float(alpha), float(alpha_new), float(beta))
-            gathered, p, p_next = p, p_next, p
-            alpha = alpha_new
-        g_out = torch.hstack([c, d, alpha] if beta is None else [c, d, alpha, beta]).to(g.device)
+        x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg)
         ea_out = edge_cols(ea, plan.edge_products(gathered)) if self.return_edge_attr else None
         return back(stack_cols([b, x, r, p], va), vertex_attr), back(ea_out, edge_attr), g_out

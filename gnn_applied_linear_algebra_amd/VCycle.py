@@ -16,7 +16,7 @@ import torch
 
 from ._common import compute_device, plan_for, to_dev
 from . import sparse_ops
-from .ChebyGNN import ChebyRelaxGNN
+from .ChebyGNN import ChebyRelaxGNN, chebyshev_relax
 from .DirectInterpGNN import DirectInterpGNN
 from .GNNResidual import GNNResidual
 from .JacobiGNN import JacobiGNN
@@ -285,9 +285,13 @@ class AMGHierarchy:
             self.Pt.append(Pt_plan)
             self.A.append(_as_sparse(Ac_ei, Ac_ev, (n_c, n_c)))
         # per-level GNN inputs, built once
+        self.plans, self.diags = [], []
         for Al in self.A:
             ei, ea = coo_to_gnn_input(Al)
-            self.gnn.append((ei, ea, torch.cat([ea, torch.zeros_like(ea)], 1), _diag_of(ei, ea, Al.shape[0])))
+            dg = _diag_of(ei, ea, Al.shape[0])
+            self.gnn.append((ei, ea, torch.cat([ea, torch.zeros_like(ea)], 1), dg))
+            self.plans.append(sparse_ops.plan_of(ei, ea, Al.shape[0], Al.shape[1]))      # values gathered once
+            self.diags.append(dg.reshape(-1).contiguous())
         self.coarse_solver = coarse_solver
         self._coarse_lu = None
         if coarse_solver == "dense":
@@ -310,26 +314,25 @@ class AMGHierarchy:
         self.coarse_bounds = coarse_bounds
 
     def residual(self, b, x, level=0):
-        ei, ea, _, _ = self.gnn[level]
-        return self.res(torch.cat([b, x], 1), ei, ea)
+        """r = b - A_level x (GNNResidual on the level's plan)."""
+        return self.plans[level].residual(b.contiguous(), x.contiguous())
 
     def _smooth(self, level, n_it, b, x):
-        ei, _, ea2, dg = self.gnn[level]
-        return self.jac(n_it, torch.cat([dg, b, x], 1), ei, ea2, torch.tensor([self.w], dtype=b.dtype))
+        """n_it weighted-Jacobi sweeps (JacobiGNN on the level's plan; w is cast to the operand dtype like g[0])."""
+        w = float(torch.tensor(self.w, dtype=b.dtype))
+        return self.plans[level].jacobi_sweeps(self.diags[level], b.contiguous(), x.contiguous(), w, n_it)
 
     def cycle(self, b, x, level=0):
         if level == len(self.A) - 1:
             if self._coarse_lu is not None:
                 return torch.linalg.lu_solve(self._coarse_lu[0], self._coarse_lu[1], b)
-            ei, ea, _, _ = self.gnn[level]
             g = torch.tensor(self.coarse_bounds, dtype=b.dtype)
             for _ in range(self.coarse_sweeps):
-                va, _, _ = self.cheby(torch.cat([b, x], 1), ei, ea, g)
-                x = va[:, 1].reshape(-1, 1)
+                x = chebyshev_relax(self.plans[level], b.contiguous(), x.contiguous(), g, self.cheby.deg)[0]
             return x
         x = self._smooth(level, self.n_pre, b, x)
         r = self.residual(b, x, level)
-        rc = self.Pt[level].spmm(r.contiguous())
+        rc = self.Pt[level].spmm(r)
         xc = self.cycle(rc, torch.zeros_like(rc), level + 1)
         x = x + self.P[level].spmm(xc.contiguous())
         return self._smooth(level, self.n_post, b, x)
