@@ -64,6 +64,7 @@ SIGNATURES = {
     "gla_remove_diag_count": (_I, [_I64, _P, _P, _P, ctypes.POINTER(_I64), _P]),
     "gla_remove_diag_apply": (_I, [_I64, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P]),
     "gla_coo_coalesce": (_I, [_I64, _I64, _I64, _P, _P, _P, _I64, _I, _P, _P, _P, ctypes.POINTER(_I64), _P]),
+    "gla_release_scratch": (_I, []),
     "gla_spgemm_count": (_I, [_P, _P, ctypes.POINTER(_I64), _P]),
     "gla_spgemm": (_I, [_P, _P, _I, _I64, _P, _P, _P, ctypes.POINTER(_I64), _P]),
 }

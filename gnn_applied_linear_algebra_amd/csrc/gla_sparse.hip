@@ -94,18 +94,65 @@ __global__ __launch_bounds__(GLA_BLOCK) void compress_kernel(const uint64_t* __r
   }
 }
 
-struct Scratch {                       // frees everything it handed out
-  void* ptrs[8];
-  int n = 0;
-  ~Scratch() { for (int i = 0; i < n; ++i) (void)hipFree(ptrs[i]); }
-  template <typename U> hipError_t get(U** p, size_t count) {
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(U));
-    if (e == hipSuccess) ptrs[n++] = q;
-    *p = static_cast<U*>(q);
-    return e;
-  }
-};
+// Setup scratch comes from one grow-only device pool (gla_release_scratch frees it): a hipMalloc / hipFree pair of
+// several GB per call costs up to seconds of page mapping, far more than the kernels.  Every setup entry point sizes
+// its scratch up front, reserves the pool once and bump-allocates from it; the entry points synchronise before they
+// return, so the pool is free again at every call boundary.  They are NOT re-entrant (one setup call at a time).
+struct Pool {
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+} g_pool;
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int pool_reserve(size_t bytes) {
+  g_pool.used = 0;
+  if (bytes <= g_pool.cap) return GLA_OK;
+  if (g_pool.base) (void)hipFree(g_pool.base);
+  g_pool.base = nullptr;
+  g_pool.cap = 0;
+  const size_t want = bytes + bytes / 8 + (1 << 20);
+  GLA_HIP_CHECK(hipMalloc((void**)&g_pool.base, want));
+  g_pool.cap = want;
+  return GLA_OK;
+}
+
+template <typename U>
+U* pool_get(size_t count) {
+  const size_t bytes = al256((count ? count : 1) * sizeof(U));
+  if (g_pool.used + bytes > g_pool.cap) return nullptr;          // sizing bug: callers check
+  U* p = reinterpret_cast<U*>(g_pool.base + g_pool.used);
+  g_pool.used += bytes;
+  return p;
+}
+
+unsigned key_bits(int64_t n_rows, int64_t n_cols) {
+  unsigned end_bit = 1;
+  const double span = (double)n_rows * (double)n_cols;
+  while (end_bit < 64 && (double)((uint64_t)1 << end_bit) < span) ++end_bit;
+  return end_bit;
+}
+
+template <typename T>
+size_t sort_tmp_bytes(int64_t n, unsigned end_bit) {
+  size_t b = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (T*)nullptr, (T*)nullptr,
+                                  (size_t)n, 0u, end_bit, (hipStream_t)0);
+  return b;
+}
+
+size_t scan_tmp_bytes(int64_t n) {
+  size_t b = 0;
+  (void)rocprim::exclusive_scan(nullptr, b, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)n,
+                                rocprim::plus<int64_t>(), (hipStream_t)0);
+  return b;
+}
+
+template <typename T>
+size_t compress_need(int64_t n, unsigned end_bit) {      // scratch of sort_and_compress
+  return al256(n * 8) + al256(n * sizeof(T)) + 2 * al256(n * 8) + al256(sort_tmp_bytes<T>(n, end_bit)) +
+         al256(scan_tmp_bytes(n)) + 4096;
+}
 
 // sort (keys, vals) and compress runs into (row_out, col_out, val_out); returns the number of unique keys
 template <typename T>
@@ -113,28 +160,18 @@ int sort_and_compress(uint64_t* keys, T* vals, int64_t n, int64_t n_rows, int64_
                       int64_t* col_out, T* val_out, int64_t* nnz_out, hipStream_t st) {
   *nnz_out = 0;
   if (n == 0) return GLA_OK;
-  Scratch sc;
-  uint64_t* keys2 = nullptr;
-  T* vals2 = nullptr;
-  int64_t *flags = nullptr, *pos = nullptr;
-  void* tmp = nullptr;
-  GLA_HIP_CHECK(sc.get(&keys2, n));
-  GLA_HIP_CHECK(sc.get(&vals2, n));
-  unsigned end_bit = 1;
-  const double span = (double)n_rows * (double)n_cols;
-  while (end_bit < 64 && (double)((uint64_t)1 << end_bit) < span) ++end_bit;
-  size_t tmp_bytes = 0;
-  GLA_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0u, end_bit, st));
-  GLA_HIP_CHECK(sc.get((char**)&tmp, tmp_bytes));
+  const unsigned end_bit = key_bits(n_rows, n_cols);
+  size_t tmp_bytes = sort_tmp_bytes<T>(n, end_bit), tmp2_bytes = scan_tmp_bytes(n);
+  uint64_t* keys2 = pool_get<uint64_t>(n);
+  T* vals2 = pool_get<T>(n);
+  int64_t* flags = pool_get<int64_t>(n);
+  int64_t* pos = pool_get<int64_t>(n);
+  char* tmp = pool_get<char>(tmp_bytes);
+  char* tmp2 = pool_get<char>(tmp2_bytes);
+  if (!keys2 || !vals2 || !flags || !pos || !tmp || !tmp2) return GLA_ERR_INVALID_ARG;
   GLA_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (size_t)n, 0u, end_bit, st));
-  GLA_HIP_CHECK(sc.get(&flags, n));
-  GLA_HIP_CHECK(sc.get(&pos, n));
   hipLaunchKernelGGL(head_flags_kernel, dim3(grid_for(n)), dim3(GLA_BLOCK), 0, st, keys2, n, flags);
   GLA_LAUNCH_CHECK();
-  size_t tmp2_bytes = 0;
-  void* tmp2 = nullptr;
-  GLA_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp2_bytes, flags, pos, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), st));
-  GLA_HIP_CHECK(sc.get((char**)&tmp2, tmp2_bytes));
   GLA_HIP_CHECK(rocprim::exclusive_scan(tmp2, tmp2_bytes, flags, pos, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), st));
   int64_t last[2] = {0, 0};
   GLA_HIP_CHECK(hipMemcpyAsync(&last[0], pos + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -152,25 +189,23 @@ int spgemm_impl(gla_csr* A, gla_csr* B, int64_t n_products, int64_t* row_out, in
                 int64_t* nnz_out, hipStream_t st) {
   *nnz_out = 0;
   if (n_products == 0 || A->nnz == 0) return GLA_OK;
-  Scratch sc;
-  int64_t *cnt = nullptr, *offs = nullptr;
-  int32_t* rowsA = nullptr;
-  uint64_t* keys = nullptr;
-  T* vals = nullptr;
-  void* tmp = nullptr;
-  GLA_HIP_CHECK(sc.get(&cnt, A->nnz));
-  GLA_HIP_CHECK(sc.get(&offs, A->nnz));
-  GLA_HIP_CHECK(sc.get(&rowsA, A->nnz));
+  const unsigned end_bit = key_bits(A->n_rows, B->n_cols);
+  size_t tmp_bytes = scan_tmp_bytes(A->nnz);
+  int rc = pool_reserve(2 * al256(A->nnz * 8) + al256(A->nnz * 4) + al256(tmp_bytes) + al256(n_products * 8) +
+                        al256(n_products * sizeof(T)) + compress_need<T>(n_products, end_bit));
+  if (rc) return rc;
+  int64_t* cnt = pool_get<int64_t>(A->nnz);
+  int64_t* offs = pool_get<int64_t>(A->nnz);
+  int32_t* rowsA = pool_get<int32_t>(A->nnz);
+  char* tmp = pool_get<char>(tmp_bytes);
+  uint64_t* keys = pool_get<uint64_t>(n_products);
+  T* vals = pool_get<T>(n_products);
+  if (!cnt || !offs || !rowsA || !tmp || !keys || !vals) return GLA_ERR_INVALID_ARG;
   hipLaunchKernelGGL(spgemm_count_kernel, dim3(grid_for(A->nnz)), dim3(GLA_BLOCK), 0, st, A->col, A->nnz, B->rowptr, cnt);
   GLA_LAUNCH_CHECK();
-  size_t tmp_bytes = 0;
-  GLA_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, offs, (int64_t)0, (size_t)A->nnz, rocprim::plus<int64_t>(), st));
-  GLA_HIP_CHECK(sc.get((char**)&tmp, tmp_bytes));
   GLA_HIP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, cnt, offs, (int64_t)0, (size_t)A->nnz, rocprim::plus<int64_t>(), st));
   hipLaunchKernelGGL(csr_rows_kernel, dim3(grid_for(A->n_rows)), dim3(GLA_BLOCK), 0, st, A->rowptr, A->n_rows, rowsA);
   GLA_LAUNCH_CHECK();
-  GLA_HIP_CHECK(sc.get(&keys, n_products));
-  GLA_HIP_CHECK(sc.get(&vals, n_products));
   hipLaunchKernelGGL((spgemm_expand_kernel<T>), dim3(grid_for(A->nnz)), dim3(GLA_BLOCK), 0, st, rowsA, A->col,
                      (const T*)A->val, A->nnz, B->rowptr, B->col, (const T*)B->val, B->n_cols, offs, keys, vals);
   GLA_LAUNCH_CHECK();
@@ -182,11 +217,11 @@ int coalesce_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* ro
                   int64_t stride, int64_t* row_out, int64_t* col_out, T* val_out, int64_t* nnz_out, hipStream_t st) {
   *nnz_out = 0;
   if (nnz == 0) return GLA_OK;
-  Scratch sc;
-  uint64_t* keys = nullptr;
-  T* vals = nullptr;
-  GLA_HIP_CHECK(sc.get(&keys, nnz));
-  GLA_HIP_CHECK(sc.get(&vals, nnz));
+  int rc = pool_reserve(al256(nnz * 8) + al256(nnz * sizeof(T)) + compress_need<T>(nnz, key_bits(n_rows, n_cols)));
+  if (rc) return rc;
+  uint64_t* keys = pool_get<uint64_t>(nnz);
+  T* vals = pool_get<T>(nnz);
+  if (!keys || !vals) return GLA_ERR_INVALID_ARG;
   hipLaunchKernelGGL((coo_keys_kernel<T>), dim3(grid_for(nnz)), dim3(GLA_BLOCK), 0, st, row, col, val, stride, nnz,
                      n_cols, keys, vals);
   GLA_LAUNCH_CHECK();
@@ -197,21 +232,29 @@ int coalesce_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* ro
 
 extern "C" {
 
+int gla_release_scratch(void) {
+  if (g_pool.base) (void)hipFree(g_pool.base);
+  g_pool.base = nullptr;
+  g_pool.cap = g_pool.used = 0;
+  return GLA_OK;
+}
+
 int gla_spgemm_count(gla_csr_t A, gla_csr_t B, int64_t* n_products_host, gla_stream_t stream) {
   if (!A || !B || !n_products_host || A->n_cols != B->n_rows) return GLA_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   *n_products_host = 0;
   if (A->nnz == 0) return GLA_OK;
-  Scratch sc;
-  int64_t *cnt = nullptr, *offs = nullptr;
-  void* tmp = nullptr;
-  GLA_HIP_CHECK(sc.get(&cnt, A->nnz));
-  GLA_HIP_CHECK(sc.get(&offs, A->nnz));
+  size_t tmp_bytes = 0;
+  GLA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (size_t)A->nnz,
+                                        rocprim::plus<int64_t>(), st));
+  int rc = pool_reserve(2 * al256(A->nnz * 8) + al256(tmp_bytes) + 4096);
+  if (rc) return rc;
+  int64_t* cnt = pool_get<int64_t>(A->nnz);
+  int64_t* offs = pool_get<int64_t>(A->nnz);
+  char* tmp = pool_get<char>(tmp_bytes);
+  if (!cnt || !offs || !tmp) return GLA_ERR_INVALID_ARG;
   hipLaunchKernelGGL(spgemm_count_kernel, dim3(grid_for(A->nnz)), dim3(GLA_BLOCK), 0, st, A->col, A->nnz, B->rowptr, cnt);
   GLA_LAUNCH_CHECK();
-  size_t tmp_bytes = 0;
-  GLA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, cnt, offs, (size_t)A->nnz, rocprim::plus<int64_t>(), st));
-  GLA_HIP_CHECK(sc.get((char**)&tmp, tmp_bytes));
   GLA_HIP_CHECK(rocprim::inclusive_scan(tmp, tmp_bytes, cnt, offs, (size_t)A->nnz, rocprim::plus<int64_t>(), st));
   GLA_HIP_CHECK(hipMemcpyAsync(n_products_host, offs + (A->nnz - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));
   GLA_HIP_CHECK(hipStreamSynchronize(st));

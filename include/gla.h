@@ -201,6 +201,9 @@ int gla_coo_coalesce(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t*
  * row_out / col_out / val_out [n_products] and returns the number of entries of C.  Both synchronise.
  * Duplicates are added in a defined order: A's CSR order, then B's. */
 int gla_spgemm_count(gla_csr_t A, gla_csr_t B, int64_t* n_products_host, gla_stream_t stream);
+/* gla_coo_coalesce / gla_spgemm* keep their scratch in one grow-only device pool (one setup call at a time, not
+ * re-entrant); this frees it. */
+int gla_release_scratch(void);
 int gla_spgemm(gla_csr_t A, gla_csr_t B, int dtype, int64_t n_products, int64_t* row_out, int64_t* col_out,
                void* val_out, int64_t* nnz_out_host, gla_stream_t stream);
 
