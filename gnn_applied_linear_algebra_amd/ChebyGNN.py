@@ -8,7 +8,7 @@ operation order, so alpha/beta are bit-identical.
 """
 import torch
 
-from ._common import back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
+from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
 
 
 def chebyshev_relax(plan, b, x0, g, deg):
@@ -54,3 +54,102 @@ class ChebyRelaxGNN(torch.nn.Module):
         x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg)
         ea_out = edge_cols(ea, plan.edge_products(gathered)) if self.return_edge_attr else None
         return back(stack_cols([b, x, r, p], va), vertex_attr), back(ea_out, edge_attr), g_out
+
+
+# ---- the reference's per-layer update modules (ChebyGNN.py:49-285), usable in a MetaLayer like the originals --------
+# Vertex attributes are [b, x, r, p] (columns appear as the layers add them), edge attributes [A_ij, z_ij],
+# globals [c, d, alpha, beta].  ChebyRelaxGNN above runs the same sequence as fused kernels.
+def _col(t, k):
+    return t[:, k:k + 1]
+
+
+def AllIters_EdgeToVertexAggregation(edgeij_pair, edge_attr, n_vertices):
+    """ChebyGNN.py:73-89: zbar_i = sum_j z_ij (1-D)."""
+    return aggregate(edgeij_pair, edge_attr[:, 1], n_vertices, "sum")
+
+
+class Iter1_Layer1_EdgeUpdate(torch.nn.Module):
+    """:49-70  z_ij = A_ij * x_j."""
+    def forward(self, vattr_i, vattr_j, edge_attr, g, batch):
+        return torch.cat([edge_attr, edge_attr * _col(vattr_j, 1)], 1)
+
+
+class _AggVertexUpdate(torch.nn.Module):
+    def __init__(self, EdgeToVertexAggregation):
+        super().__init__()
+        self.EdgeToVertexAggregation = EdgeToVertexAggregation
+
+    def _zbar(self, vertex_attr, edgeij_pair, edge_attr):
+        return self.EdgeToVertexAggregation(edgeij_pair, edge_attr, vertex_attr.shape[0]).view(-1, 1)
+
+
+class Iter1_Layer1_VertexUpdate(_AggVertexUpdate):
+    """:91-121  r_i = b_i - zbar_i  ->  [b, x, r]."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        b, x = _col(vertex_attr, 0), _col(vertex_attr, 1)
+        return torch.cat([b, x, b - self._zbar(vertex_attr, edgeij_pair, edge_attr)], 1)
+
+
+class Iter1_Layer1_GlobalUpdate(torch.nn.Module):
+    """:123-139  alpha = 1/d  ->  [c, d, alpha]."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        return torch.hstack([g[0], g[1], 1 / g[1]])
+
+
+class Iter1_Layer2_VertexUpdate(torch.nn.Module):
+    """:141-163  p = r; x += alpha p  ->  [b, x, r, p]."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        b, x, r = (_col(vertex_attr, k) for k in range(3))
+        return torch.cat([b, x + g[2] * r, r, r], 1)
+
+
+class IterGreaterThan1_Layer1_EdgeUpdate(torch.nn.Module):
+    """:166-183  z_ij = A_ij * p_j."""
+    def forward(self, vattr_i, vattr_j, edge_attr, g, batch):
+        A = _col(edge_attr, 0)
+        return torch.cat([A, A * _col(vattr_j, 3)], 1)
+
+
+class IterGreaterThan1_Layer1_VertexUpdate(_AggVertexUpdate):
+    """:186-216  r -= alpha * zbar (alpha is still the previous one: the global update runs after)."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        b, x, r, p = (_col(vertex_attr, k) for k in range(4))
+        return torch.cat([b, x, r - g[2] * self._zbar(vertex_attr, edgeij_pair, edge_attr), p], 1)
+
+
+class IterGreaterThan1_Layer2_VertexUpdate(torch.nn.Module):
+    """:219-243  p = r + beta p; x += alpha p."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        b, x, r, p = (_col(vertex_attr, k) for k in range(4))
+        p = r + g[3] * p
+        return torch.cat([b, x + g[2] * p, r, p], 1)
+
+
+class Iter2_Layer1_GlobalUpdate(torch.nn.Module):
+    """:246-265  beta = 0.5 (c alpha)^2; alpha = 1/(d - beta/alpha)."""
+    def forward(self, vertex_attr, edge_index, edge_attr, g, batch):
+        beta = 0.5 * (g[0] * g[2]) ** 2
+        return torch.hstack([g[0], g[1], 1 / (g[1] - beta / g[2]), beta])
+
+
+class IterGreaterThan2_Layer1_GlobalUpdate(torch.nn.Module):
+    """:269-285  beta = ((c alpha)/2)^2; alpha = 1/(d - beta/alpha)."""
+    def forward(self, vertex_attr, edge_index, edge_attr, g, batch):
+        beta = ((g[0] * g[2]) / 2) ** 2
+        return torch.hstack([g[0], g[1], 1 / (g[1] - beta / g[2]), beta])
+
+
+def unfused_layers(deg):
+    """The reference's layer list for degree `deg` (ChebyGNN.py:291-321) built from the modules above and this
+    package's MetaLayer -- the unfused formulation, kept for callers that want to interleave their own layers."""
+    from .meta import MetaLayer
+    agg = AllIters_EdgeToVertexAggregation
+    first = [MetaLayer(Iter1_Layer1_EdgeUpdate(), Iter1_Layer1_VertexUpdate(agg), Iter1_Layer1_GlobalUpdate()),
+             MetaLayer(None, Iter1_Layer2_VertexUpdate(), None)]
+    second = [MetaLayer(IterGreaterThan1_Layer1_EdgeUpdate(), IterGreaterThan1_Layer1_VertexUpdate(agg),
+                        Iter2_Layer1_GlobalUpdate()),
+              MetaLayer(None, IterGreaterThan1_Layer2_VertexUpdate(), None)]
+    later = [MetaLayer(IterGreaterThan1_Layer1_EdgeUpdate(), IterGreaterThan1_Layer1_VertexUpdate(agg),
+                       IterGreaterThan2_Layer1_GlobalUpdate()),
+             MetaLayer(None, IterGreaterThan1_Layer2_VertexUpdate(), None)]
+    return (first if deg > 0 else []) + (second if deg > 1 else []) + later * max(deg - 2, 0)

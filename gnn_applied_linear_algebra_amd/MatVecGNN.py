@@ -9,25 +9,13 @@ SpMV/SpMM kernel (gla_spmm) plus one edge-product pass (gla_edge_products) for t
 import torch
 
 from . import meta
-from ._common import back, compute_device, float_dtype, plan_for, to_dev
+from ._common import aggregate, back, compute_device, float_dtype, plan_for, to_dev
 from .meta import MetaLayer  # noqa: F401  (re-exported: the reference imports it from torch_geometric.nn)
 
 
 def edge_to_vertex_aggregation(edgeij_pair, c_ij, n_vertices):
-    """MatVecGNN.py:43-62: cbar_i = sum_j c_ij (edge-order row sums) via the CSR plan of edgeij_pair.
-    Standalone form: a segment sum of arbitrary per-edge values = SpMM with X = ones and values c_ij."""
-    dev = compute_device(c_ij, edgeij_pair)
-    ei, c = to_dev(edgeij_pair, dev), to_dev(c_ij, dev)
-    c2 = c.reshape(c.shape[0], -1)
-    plan = plan_for(ei, n_vertices)
-    ones = torch.ones((n_vertices, 1), dtype=c2.dtype, device=dev)
-    outs = []
-    for k in range(c2.shape[1]):                       # one plan-value refresh per attribute column
-        plan.set_values(c2[:, k].contiguous())
-        plan._val_key = plan._val_ref = None
-        outs.append(plan.spmm(ones))
-    out = torch.cat(outs, 1)
-    return back(out if c.dim() > 1 else out.reshape(-1), c_ij)
+    """MatVecGNN.py:43-62: cbar_i = sum_j c_ij (edge-order row sums) for every attribute column of c_ij."""
+    return aggregate(edgeij_pair, c_ij, n_vertices, "sum")
 
 
 class EdgeUpdate(torch.nn.Module):
@@ -69,9 +57,7 @@ def _fused_matvec(layer, x, edgeij_pair, edge_attr, u, batch):
 def _dispatch(layer, x, ei, ea, u, batch):
     out = _fused_matvec(layer, x, ei, ea, u, batch)
     if out is None:                                   # user-supplied aggregation: generic PyG sequence
-        row, col = ei[0], ei[1]
-        ea = layer.edge_model(x[row], x[col], ea, u, batch if batch is None else batch[row])
-        return layer.node_model(x, ei, ea, u, batch), ea, u
+        return meta.generic_forward(layer, x, ei, ea, u, batch)
     return out
 
 

@@ -10,7 +10,7 @@ block is an SpMV plus two reductions.
 import torch
 
 from . import _lib
-from ._common import back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
+from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
 from .plan import col_dot, col_scale_rsqrt
 
 
@@ -56,3 +56,96 @@ class PowerMethodGNN(torch.nn.Module):
         g_out = g_out.reshape(3) if g.dim() == 1 else g_out
         ea_out = edge_cols(ea, plan.edge_products(b)) if self.return_edge_attr else None
         return (back(stack_cols([b, b * b], va), vertex_attr), back(ea_out, edge_attr), back(g_out, g))
+
+
+# ---- the reference's per-layer update modules (PowerMethodGNN.py:50-294) -------------------------------------------
+# vertex attributes [b, y], edge attributes [A_ij, c_ij], globals [n, n_A, lambda].
+def vertex_to_global_aggregation(vertex_attr):
+    """:50-61  ybar = sum_i y_i (deterministic two-stage column sum on the device)."""
+    y = vertex_attr[:, 1:2]
+    if not y.is_cuda:
+        return torch.sum(vertex_attr[:, 1])
+    y = y.contiguous()
+    return col_dot(y, torch.ones_like(y))[0]
+
+
+def edge_to_vertex_aggregation(edgeij_pair, edge_attr, n_vertices):
+    """:64-83  cbar_i = sum_j c_ij, [n, 1]."""
+    return aggregate(edgeij_pair, edge_attr[:, 1], n_vertices, "sum").reshape((-1, 1))
+
+
+class Layer_1_EdgeUpdate(torch.nn.Module):
+    """:86-106  c_ij = A_ij * b_j."""
+    def forward(self, vattr_i, vattr_j, edge_attr, g, batch):
+        A = edge_attr[:, 0:1]
+        return torch.cat([A, A * vattr_j[:, 0:1]], 1)
+
+
+class Layer_2_VertexUpdate(torch.nn.Module):
+    """:109-126  y_i = b_i^2."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        b = vertex_attr[:, 0:1]
+        return torch.cat([b, b * b], 1)
+
+
+class _EdgeAgg(torch.nn.Module):
+    def __init__(self, edge_aggregation_function):
+        super().__init__()
+        self.edge_aggregation_function = edge_aggregation_function
+
+
+class _GlobalAgg(torch.nn.Module):
+    def __init__(self, vertex_to_global_aggregation_function):
+        super().__init__()
+        self.vertex_to_global_aggregation_function = vertex_to_global_aggregation_function
+
+
+class Iterative_Layer_1_VertexUpdate(_EdgeAgg):
+    """:129-158  b_i <- cbar_i."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        return torch.cat([self.edge_aggregation_function(edgeij_pair, edge_attr, vertex_attr.shape[0]),
+                          vertex_attr[:, 1:2]], 1)
+
+
+class Iterative_Layer_2_GlobalUpdate(_GlobalAgg):
+    """:160-185  n = sqrt(ybar)."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        return torch.stack([torch.sqrt(self.vertex_to_global_aggregation_function(vertex_attr)).to(g.device),
+                            g[1], g[2]])
+
+
+class Iterative_Layer_3_VertexUpdate(torch.nn.Module):
+    """:187-207  b_i <- b_i / n."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        return torch.cat([vertex_attr[:, 0:1] / g[0].to(vertex_attr.device), vertex_attr[:, 1:2]], 1)
+
+
+class Rayleigh_Layer_1_VertexUpdate(_EdgeAgg):
+    """:209-237  y_i = b_i * cbar_i."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        b = vertex_attr[:, 0:1]
+        return torch.cat([b, b * self.edge_aggregation_function(edgeij_pair, edge_attr, vertex_attr.shape[0])], 1)
+
+
+class Rayleigh_Layer_1_GlobalUpdate(_GlobalAgg):
+    """:239-266  n_A = ybar."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        return torch.stack([g[0], self.vertex_to_global_aggregation_function(vertex_attr).to(g.device), g[2]])
+
+
+class Rayleigh_Layer_2_GlobalUpdate(_GlobalAgg):
+    """:268-294  lambda = n_A / ybar."""
+    def forward(self, vertex_attr, edgeij_pair, edge_attr, g, batch):
+        return torch.stack([g[0], g[1], g[1] / self.vertex_to_global_aggregation_function(vertex_attr).to(g.device)])
+
+
+def unfused_layers(num_iter):
+    """The reference's layer list (PowerMethodGNN.py:303-329) from the modules above and this package's MetaLayer."""
+    from .meta import MetaLayer
+    e2v, v2g = edge_to_vertex_aggregation, vertex_to_global_aggregation
+    block = [MetaLayer(Layer_1_EdgeUpdate(), Iterative_Layer_1_VertexUpdate(e2v), None),
+             MetaLayer(None, Layer_2_VertexUpdate(), Iterative_Layer_2_GlobalUpdate(v2g)),
+             MetaLayer(None, Iterative_Layer_3_VertexUpdate(), None)]
+    rayleigh = [MetaLayer(Layer_1_EdgeUpdate(), Rayleigh_Layer_1_VertexUpdate(e2v), Rayleigh_Layer_1_GlobalUpdate(v2g)),
+                MetaLayer(None, Layer_2_VertexUpdate(), Rayleigh_Layer_2_GlobalUpdate(v2g))]
+    return block * num_iter + rayleigh

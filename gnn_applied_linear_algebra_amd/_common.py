@@ -69,4 +69,13 @@ def edge_cols(edge_attr, c):
     return torch.cat([A, c], 1)
 
 
-__all__ = ["compute_device", "to_dev", "back", "float_dtype", "cols", "stack_cols", "edge_cols", "plan_for"]
+def aggregate(edgeij_pair, src, n_vertices, reduce="sum"):
+    """The reference's aggregation primitive, torch_scatter.scatter(src, edgeij_pair[0], dim=0, dim_size=n,
+    reduce=...), on the cached CSR plan of `edgeij_pair` (libgla_hip gla_segment_reduce: rows visited in edge order,
+    so sums equal the sequential CPU scatter-add; rows without edges give 0).  src: [nnz] or [nnz, k]."""
+    dev = compute_device(src, edgeij_pair)
+    plan = plan_for(to_dev(edgeij_pair, dev), n_vertices)
+    return back(plan.segment_reduce(to_dev(src, dev), reduce), src)
+
+
+__all__ = ["aggregate", "compute_device", "to_dev", "back", "float_dtype", "cols", "stack_cols", "edge_cols", "plan_for"]

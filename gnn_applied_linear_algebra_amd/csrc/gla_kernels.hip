@@ -855,6 +855,36 @@ __global__ __launch_bounds__(GLA_BLOCK) void soc_sa_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// generic edge -> vertex aggregation: the torch_scatter.scatter(src, edgeij_pair[0], dim=0, dim_size=n, reduce=...)
+// primitive itself, for callers that keep their own EdgeUpdate / VertexUpdate modules.  Lanes are
+// (row, column) pairs; a row's entries are visited in EDGE order, so `sum` equals the reference's sequential
+// scatter-add bit for bit.  Empty rows give 0 for every op (torch_scatter semantics); max / min propagate NaN.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KP>
+__global__ __launch_bounds__(GLA_BLOCK) void segment_reduce_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm, const T* __restrict__ src, int64_t lds_,
+    int K, int op, int64_t n_rows, T* __restrict__ out, int64_t ldo) {
+  constexpr int RPP = GLA_BLOCK / KP;
+  const int k0 = threadIdx.x % KP, rsub = threadIdx.x / KP;
+  for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n_rows; r += (int64_t)gridDim.x * RPP) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    for (int k = k0; k < K; k += KP) {
+      T acc = T(0);
+      for (int p = a; p < b; ++p) {
+        const int64_t e = perm ? (int64_t)perm[p] : (int64_t)p;
+        const T v = src[e * lds_ + k];
+        if (op == 0 || op == 3) acc = acc + v;
+        else if (p == a) acc = v;
+        else if (op == 1) acc = (v > acc || v != v) ? v : acc;
+        else acc = (v < acc || v != v) ? v : acc;
+      }
+      if (op == 3 && b > a) acc = acc / T(b - a);
+      out[r * ldo + k] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // column dots / scaling (global aggregations of the power method)
 // ------------------------------------------------------------------------------------------------
 constexpr int DOT_BLOCKS_MAX = 1024;
@@ -984,6 +1014,29 @@ int launch_col_scale(int64_t n, int K, const T* X, int64_t ldx, const T* sumsq, 
   const dim3 grid(grid_for(n * K, GLA_BLOCK * 4));
   GLA_K_SWITCH(K, hipLaunchKernelGGL((col_scale_rsqrt_kernel<T, KC>), grid, dim3(GLA_BLOCK), 0, st, X, ldx, sumsq,
                                      Y, ldy, n, K))
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+template <typename T>
+int launch_segment_reduce(gla_csr* A, int K, const T* src, int64_t ld_src, int op, T* out, int64_t ld_out,
+                          hipStream_t st) {
+  int kp = 1;
+  while (kp < K && kp < 64) kp <<= 1;
+  const unsigned grid = grid_for(A->n_rows, GLA_BLOCK / kp, 256 * 16);
+#define GLA_SEG(KP_)                                                                                            \
+  hipLaunchKernelGGL((segment_reduce_kernel<T, KP_>), dim3(grid), dim3(GLA_BLOCK), 0, st, A->rowptr, A->perm,  \
+                     src, ld_src, K, op, A->n_rows, out, ld_out)
+  switch (kp) {
+    case 1: GLA_SEG(1); break;
+    case 2: GLA_SEG(2); break;
+    case 4: GLA_SEG(4); break;
+    case 8: GLA_SEG(8); break;
+    case 16: GLA_SEG(16); break;
+    case 32: GLA_SEG(32); break;
+    default: GLA_SEG(64); break;
+  }
+#undef GLA_SEG
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }
@@ -1139,6 +1192,17 @@ int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, co
     }
     return GLA_OK;
   })
+}
+
+int gla_segment_reduce(gla_csr_t A, int dtype, int K, const void* src, int64_t ld_src, int op, void* out,
+                       int64_t ld_out, gla_stream_t stream) {
+  if (!A || K < 1 || op < 0 || op > 3 || (dtype != GLA_F32 && dtype != GLA_F64) || ld_src < K || ld_out < K)
+    return GLA_ERR_INVALID_ARG;
+  if (A->n_rows == 0) return GLA_OK;
+  if (!out || (A->nnz > 0 && !src)) return GLA_ERR_INVALID_ARG;
+  if (dtype == GLA_F64)
+    return launch_segment_reduce<double>(A, K, (const double*)src, ld_src, op, (double*)out, ld_out, (hipStream_t)stream);
+  return launch_segment_reduce<float>(A, K, (const float*)src, ld_src, op, (float*)out, ld_out, (hipStream_t)stream);
 }
 
 int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,

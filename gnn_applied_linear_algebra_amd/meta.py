@@ -25,14 +25,22 @@ class MetaLayer(torch.nn.Module):
         fused = self._fused()
         if fused is not None:
             return fused(self, x, edge_index, edge_attr, u, batch)
-        row, col = edge_index[0], edge_index[1]
-        if self.edge_model is not None:
-            edge_attr = self.edge_model(x[row], x[col], edge_attr, u, batch if batch is None else batch[row])
-        if self.node_model is not None:
-            x = self.node_model(x, edge_index, edge_attr, u, batch)
-        if self.global_model is not None:
-            u = self.global_model(x, edge_index, edge_attr, u, batch)
-        return x, edge_attr, u
+        return generic_forward(self, x, edge_index, edge_attr, u, batch)
+
+
+def generic_forward(layer, x, edge_index, edge_attr=None, u=None, batch=None):
+    """PyG MetaLayer semantics: gather x[row], x[col] (and batch[row]), then edge -> node -> global callbacks."""
+    row, col = edge_index[0], edge_index[1]
+    if row.device != x.device:
+        row, col = row.to(x.device), col.to(x.device)
+    if layer.edge_model is not None:
+        edge_attr = layer.edge_model(x[row], x[col], edge_attr, u,
+                                     batch if batch is None else batch.to(x.device)[row])
+    if layer.node_model is not None:
+        x = layer.node_model(x, edge_index, edge_attr, u, batch)
+    if layer.global_model is not None:
+        u = layer.global_model(x, edge_index, edge_attr, u, batch)
+    return x, edge_attr, u
 
 
 _FUSED = {}

@@ -211,6 +211,21 @@ class CsrPlan:
                                    ptr(work), which, stream_ptr(self.device)))
         return Y, sumsq, work
 
+    def segment_reduce(self, src, reduce="sum"):
+        """torch_scatter.scatter(src, row, dim=0, dim_size=n_rows, reduce=...) on the plan's row structure; src is in
+        EDGE order, [nnz] or [nnz, K]; returns [n_rows] resp. [n_rows, K]."""
+        op = {"sum": 0, "add": 0, "max": 1, "min": 2, "mean": 3}[reduce]
+        one_d = src.dim() == 1
+        s2 = src.reshape(self.nnz, -1)
+        if s2.shape[1] > 1 and s2.stride(1) != 1 or not s2.is_cuda:
+            s2 = s2.contiguous().to(self.device)
+        K = s2.shape[1]
+        ld = s2.stride(0) if self.nnz > 1 else K
+        out = torch.empty((self.n_rows, K), dtype=s2.dtype, device=self.device)
+        check(lib().gla_segment_reduce(self._h, dtype_code(s2.dtype), K, ptr(s2), max(ld, K), op, ptr(out), K,
+                                       stream_ptr(self.device)))
+        return out.reshape(-1) if one_d else out
+
     def edge_products(self, X):
         """c_e = A_e * X[col_e] in EDGE order, [nnz, K]."""
         X, K, ldx = _dense(X, self.n_cols, "X")

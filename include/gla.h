@@ -150,6 +150,13 @@ int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, co
                    const void* rnrm_in, void* Y, int64_t ldy, void* sumsq_out, void* work, int which_tiles,
                    gla_stream_t stream);
 
+/* The aggregation primitive on its own: out[i,k] = reduce over the edges e with row(e) = i of src[e,k], src in EDGE
+ * order [nnz, K].  op: 0 sum (edge order, = the reference's sequential scatter-add), 1 max, 2 min, 3 mean; rows
+ * without edges give 0.  torch_scatter.scatter(src, edgeij_pair[0], dim=0, dim_size=n, reduce=...), e.g.
+ * JacobiGNN.py:66, SOCClassicGNN.py:69, DirectInterpGNN.py:89-92.  Only the plan's index side is used. */
+int gla_segment_reduce(gla_csr_t A, int dtype, int K, const void* src, int64_t ld_src, int op, void* out,
+                       int64_t ld_out, gla_stream_t stream);
+
 /* Edge products in EDGE order: C[e,k] = A_e * X[col_e,k] -- the `c_ij`/`z_ij` column every EdgeUpdate
  * returns (e.g. JacobiGNN.py:83-88); materialised only when a caller asks for edge_attr. */
 int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,

@@ -741,3 +741,86 @@ def test_degenerate_sizes():
     vv, SS = v.soc_classic(0.25, torch.float64)
     eq(vv, np.zeros((3, 1)))
     assert SS.shape == (0,)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's per-layer (L3) modules + the aggregation primitive, wired through MetaLayer (unfused path)
+# ---------------------------------------------------------------------------------------------------
+def test_segment_reduce_primitive():
+    """gla_segment_reduce == torch_scatter.scatter semantics (sum in edge order, max/min/mean, empty rows -> 0)."""
+    from gnn_applied_linear_algebra_amd._common import aggregate
+    gen = torch.Generator().manual_seed(17)
+    n, nnz = 500, 4000
+    ei = torch.stack([torch.randint(0, n, (nnz,), generator=gen), torch.randint(0, n, (nnz,), generator=gen)])
+    ei[0][ei[0] % 7 == 3] = 5                                       # some empty rows, one crowded row
+    for K in (1, 3, 16):
+        src = torch.rand(nnz, K, generator=gen, dtype=torch.float64) - 0.5
+        idx = ei[0].view(-1, 1).expand_as(src)
+        want_sum = torch.zeros(n, K, dtype=torch.float64).scatter_add_(0, idx, src)
+        eq(aggregate(d(ei), d(src), n, "sum"), want_sum)
+        for op, red in (("max", "amax"), ("min", "amin")):
+            want = torch.zeros(n, K, dtype=torch.float64).scatter_reduce_(0, idx, src, red, include_self=False)
+            eq(aggregate(d(ei), d(src), n, op), want)
+        cnt = torch.bincount(ei[0], minlength=n).clamp(min=1).view(-1, 1)
+        close(aggregate(d(ei), d(src), n, "mean"), want_sum / cnt, rtol=1e-14)
+    v = aggregate(d(ei), d(src[:, 0].contiguous()), n, "sum")
+    assert v.shape == (n,)
+    eq(aggregate(ei, src[:, 0].contiguous(), n, "sum"), want_sum[:, 0])      # CPU in -> CPU out
+
+
+@pytest.mark.parametrize("N", (5, 16))
+def test_unfused_l3_modules_golden(golden, N):
+    """The reference's own layer wiring, built from this package's EdgeUpdate / VertexUpdate / GlobalUpdate classes and
+    MetaLayer, reproduces the golden vectors: bit-exact wherever the fused modules are."""
+    ei, ev = lap(golden, N)
+    n = N * N
+    b, x = t(golden[f"N{N}_b"]), t(golden[f"N{N}_x"])
+    ei_d = d(ei)
+    J = gla.JacobiGNN
+    va0 = d(torch.cat([-4 * torch.ones((n, 1), dtype=torch.float64), b, x], 1))
+    ea0 = d(torch.cat([ev, torch.zeros_like(ev)], 1))
+    g = torch.tensor([0.7], dtype=torch.float64)
+    fused = gla.MetaLayer(J.EdgeUpdate(), J.VertexUpdate(J.edge_to_vertex_aggregation))
+    unfused = gla.MetaLayer(J.EdgeUpdate(), J.VertexUpdate(lambda *a: J.edge_to_vertex_aggregation(*a)))
+    for layer in (fused, unfused):
+        va, ea, _ = layer(va0, ei_d, ea0, g, batch=None)
+        eq(va, golden[f"N{N}_jacobi_iterate_va"])
+        eq(ea, golden[f"N{N}_jacobi_iterate_ea"])
+    va = va0
+    for _ in range(10):
+        va, ea, _ = unfused(va, ei_d, ea0 if _ == 0 else ea, g, batch=None)
+    eq(va[:, 2:3], golden[f"N{N}_jacobi_w64_it10_x"])
+    R = gla.GNNResidual
+    for layer in (gla.MetaLayer(R.EdgeUpdate(), R.VertexUpdate(R.edge_to_vertex_aggregation)),
+                  gla.MetaLayer(R.EdgeUpdate(), R.VertexUpdate(lambda *a: R.edge_to_vertex_aggregation(*a)))):
+        va, _, _ = layer(d(torch.cat([b, x], 1)), ei_d, d(ev), None, batch=None)
+        eq(va[:, 2:3], golden[f"N{N}_residual_r"])
+    for deg in (1, 2, 4):
+        va, ea, gg = d(torch.cat([b, x], 1)), d(ev), t(golden[f"N{N}_cheby_g0"])
+        for layer in gla.ChebyGNN.unfused_layers(deg):
+            va, ea, gg = layer(va, ei_d, ea, gg, None)
+        eq(va, golden[f"N{N}_cheby_deg{deg}_va"])
+        eq(ea, golden[f"N{N}_cheby_deg{deg}_ea"])
+        eq(gg, golden[f"N{N}_cheby_deg{deg}_g"])
+    va, ea, gg = d(torch.cat([b, torch.zeros_like(b)], 1)), d(torch.cat([ev, torch.zeros_like(ev)], 1)), torch.zeros(3, dtype=torch.float64)
+    for layer in gla.PowerMethodGNN.unfused_layers(10):
+        va, ea, gg = layer(va, ei_d, ea, gg, None)
+    close(gg, golden[f"N{N}_power_it10_g"])
+    close(va, golden[f"N{N}_power_it10_va"])
+    eio, evo = lap(golden, N, od=True)
+    evr = t(golden[f"N{N}_socr_ev"])
+    S_ = gla.SOCClassicGNN
+    l1 = gla.MetaLayer(None, S_.VertexUpdate(S_.edge_to_vertex_aggregation))
+    l2 = gla.MetaLayer(S_.EdgeUpdate(0.25))
+    va, ea, gg = l1(d(torch.zeros((n, 1), dtype=torch.float64)), d(eio), d(evr), None, batch=None)
+    va, ea, gg = l2(va, d(eio), ea, gg, batch=None)
+    eq(ea[:, 1], golden[f"N{N}_socr_S"])
+    D_ = gla.DirectInterpGNN
+    diag = -4 * torch.ones((n, 1), dtype=torch.float64)
+    split = t(golden[f"N{N}_split"]).reshape(-1, 1).to(torch.float64)
+    Sflag = (t(golden[f"N{N}_socr_S"]).reshape(-1, 1) > 0).to(torch.float64)
+    la = gla.MetaLayer(D_.Layer1_EdgeUpdate(), D_.Layer1_VertexUpdate(D_.EdgeToVertexAggregation))
+    lb = gla.MetaLayer(D_.Layer2_EdgeUpdate())
+    va, ea, _ = la(d(torch.hstack([diag, split])), d(eio), d(torch.hstack([evr, Sflag])), None, batch=None)
+    va, ea, _ = lb(va, d(eio), ea, None, batch=None)
+    eq(ea[:, 2], golden[f"N{N}_di_rnd_w"])
