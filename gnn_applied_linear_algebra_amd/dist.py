@@ -28,8 +28,10 @@ class _Done:
 
 
 class RowBlockPartition:
-    def __init__(self, edgeij_pair, n_global, row_lo, row_hi, group=None):
-        """edgeij_pair [2, nnz_local]: the edges whose ROW lies in [row_lo, row_hi), GLOBAL vertex ids."""
+    def __init__(self, edgeij_pair, n_global, row_lo, row_hi, group=None, col_blocks=None):
+        """edgeij_pair [2, nnz_local]: the edges whose ROW lies in [row_lo, row_hi), GLOBAL vertex ids.
+        Square operators (default): the input vector is partitioned like the rows.  Rectangular operators
+        (restriction P^T, prolongation P): `col_blocks` = [(lo, hi)] * world, the partition of the INPUT vector."""
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
@@ -40,45 +42,58 @@ class RowBlockPartition:
         row, col = edgeij_pair[0], edgeij_pair[1]
         if row.numel() and (int(row.min()) < self.row_lo or int(row.max()) >= self.row_hi):
             raise ValueError("edge rows outside this rank's row block")
-
-        # every rank's block + the halo columns it reads (setup-time object collectives, small)
-        off = (col < self.row_lo) | (col >= self.row_hi)
-        need = torch.unique(col[off]).cpu()                       # sorted global ids
         if self.distributed:
             blocks = [None] * self.world
-            needs = [None] * self.world
             dist.all_gather_object(blocks, (self.row_lo, self.row_hi), group=group)
-            dist.all_gather_object(needs, need, group=group)
         else:
-            blocks, needs = [(self.row_lo, self.row_hi)], [need]
+            blocks = [(self.row_lo, self.row_hi)]
         los = torch.tensor([b[0] for b in blocks])
         his = torch.tensor([b[1] for b in blocks])
         if int(los[0]) != 0 or int(his[-1]) != self.n_global or bool((los[1:] != his[:-1]).any()):
             raise ValueError(f"row blocks do not tile [0, {self.n_global}): {blocks}")
         self.blocks = blocks
-        # send list of rank q = sorted union of q's rows that any rank needs
+        in_blocks = blocks if col_blocks is None else [(int(lo), int(hi)) for lo, hi in col_blocks]
+        if len(in_blocks) != self.world or in_blocks[0][0] != 0 or \
+                any(in_blocks[q][1] != in_blocks[q + 1][0] for q in range(self.world - 1)):
+            raise ValueError(f"input-vector blocks do not tile their range: {in_blocks}")
+        self.in_blocks = in_blocks
+        self.in_lo, self.in_hi = in_blocks[self.rank]
+        self.n_in = self.in_hi - self.in_lo                       # entries of the input vector this rank owns
+        in_his = torch.tensor([b[1] for b in in_blocks])
+        if col.numel() and (int(col.min()) < 0 or int(col.max()) >= in_blocks[-1][1]):
+            raise ValueError("edge columns outside the input vector")
+
+        # the off-block input entries this rank reads (setup-time object collective, small)
+        off = (col < self.in_lo) | (col >= self.in_hi)
+        need = torch.unique(col[off]).cpu()                       # sorted global ids
+        if self.distributed:
+            needs = [None] * self.world
+            dist.all_gather_object(needs, need, group=group)
+        else:
+            needs = [need]
+        # send list of rank q = sorted union of q's input entries that any rank needs
         all_need = torch.unique(torch.cat(needs)) if self.world > 1 else need
-        send_lists = [all_need[(all_need >= lo) & (all_need < hi)] for lo, hi in blocks]
+        send_lists = [all_need[(all_need >= lo) & (all_need < hi)] for lo, hi in in_blocks]
         self.S = max([int(s.numel()) for s in send_lists] + [0])
         self.halo_size = self.world * self.S
-        self.send_idx = (send_lists[self.rank] - self.row_lo).to(dev)          # local row ids, sorted
+        self.send_idx = (send_lists[self.rank] - self.in_lo).to(dev)           # local input ids, sorted
         self.n_send = int(self.send_idx.numel())
 
-        # column renumbering: local | gathered slots
-        owner = torch.bucketize(need, his, right=True)                          # rank owning each halo column
+        # column renumbering: local input entries | gathered slots
+        owner = torch.bucketize(need, in_his, right=True)                       # rank owning each halo column
         slot = torch.empty_like(need)
         for q in range(self.world):
             m = owner == q
             if bool(m.any()):
                 slot[m] = q * self.S + torch.searchsorted(send_lists[q], need[m])
         need_d, slot_d = need.to(dev), slot.to(dev)
-        col_local = col - self.row_lo
+        col_local = col - self.in_lo
         if need_d.numel():
             pos = torch.searchsorted(need_d, col[off])
             col_local = col_local.clone()
-            col_local[off] = self.n_local + slot_d[pos]
+            col_local[off] = self.n_in + slot_d[pos]
         self.edge_index_local = torch.stack([row - self.row_lo, col_local])
-        self.n_cols_local = self.n_local + self.halo_size
+        self.n_cols_local = self.n_in + self.halo_size
         self._send_bufs, self._send_flip = {}, 0
 
     # ---- buffers / exchange -------------------------------------------------------------------------
@@ -86,7 +101,7 @@ class RowBlockPartition:
         return torch.zeros((self.n_cols_local, K), dtype=dtype, device=device)
 
     def exchange(self, X, async_op=False):
-        """All-gather the send slots of every rank into X[n_local:].  X: [n_local + P*S, K]."""
+        """All-gather the send slots of every rank into X[n_in:].  X: [n_in + P*S, K] (n_in = n_local when square)."""
         if self.world == 1 or self.S == 0:
             return None
         K = X.shape[1]
@@ -97,15 +112,15 @@ class RowBlockPartition:
         self._send_flip ^= 1
         send = send[self._send_flip]
         if self.n_send:
-            torch.index_select(X[:self.n_local], 0, self.send_idx, out=send[:self.n_send])
+            torch.index_select(X[:self.n_in], 0, self.send_idx, out=send[:self.n_send])
         if X.is_cuda and dist.get_backend(self.group) == "gloo":
             # test-only route (2 ranks sharing one GPU, tests/test_gpu_dist.py): gloo moves host memory
             send_h = send.cpu()
             recv_h = torch.empty((self.halo_size, K), dtype=X.dtype)
             dist.all_gather_into_tensor(recv_h, send_h, group=self.group)
-            X[self.n_local:] = recv_h.to(X.device)
+            X[self.n_in:] = recv_h.to(X.device)
             return _Done() if async_op else None
-        return dist.all_gather_into_tensor(X[self.n_local:], send, group=self.group, async_op=async_op)
+        return dist.all_gather_into_tensor(X[self.n_in:], send, group=self.group, async_op=async_op)
 
     def all_reduce_sum(self, t):
         if self.world > 1:
@@ -116,16 +131,16 @@ class RowBlockPartition:
 class RowBlockOps:
     """The partition bound to a libgla_hip CSR plan of the local block (rows local, columns local + halo)."""
 
-    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True):
+    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None):
         from .plan import CsrPlan, ALL_TILES, INTERIOR_TILES, BOUNDARY_TILES
         self.ALL, self.INTERIOR, self.BOUNDARY = ALL_TILES, INTERIOR_TILES, BOUNDARY_TILES
-        self.part = RowBlockPartition(edgeij_pair, n_global, row_lo, row_hi, group)
+        self.part = RowBlockPartition(edgeij_pair, n_global, row_lo, row_hi, group, col_blocks)
         p = self.part
         self.plan = CsrPlan(p.edge_index_local, p.n_local, p.n_cols_local)
         self.plan.set_values(edge_attr)
         self.overlap = bool(overlap) and p.world > 1 and p.S > 0
         if self.overlap:
-            self.plan.classify_tiles(p.n_local)
+            self.plan.classify_tiles(p.n_in)
 
     def run(self, X, launch):
         """Exchange X's halo and call launch(which_tiles) for all row tiles, overlapping when enabled."""

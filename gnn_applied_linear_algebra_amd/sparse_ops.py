@@ -65,4 +65,5 @@ def galerkin(A_ei, A_val, n, P_ei, P_val, n_c):
     AP_ei, AP_val = spgemm(A, P)
     AP = plan_of(AP_ei, AP_val, n, n_c)
     Ac_ei, Ac_val = spgemm(Pt, AP)
+    P.coo, Pt.coo = (P_ei, P_val), (Pt_ei, Pt_val)        # kept for row-block slicing (dist_amg.py)
     return Ac_ei, Ac_val, P, Pt

@@ -73,6 +73,22 @@ def _worker(rank, world, port, kind, q):
             cur, nxt = nxt, cur
             xs = xs + 0.7 * (B - rp.scatter_sum(ev * xs[ei[1]], ei[0], n)) / diag
         assert torch.equal(cur[:part.n_local], xs[lo:hi])
+        # rectangular operator (prolongation-like, 57 x 23): rows by `cuts`, input vector by its own partition
+        if kind == "random":
+            nc = 23
+            ccuts = [0, 9, nc]
+            ei_r = torch.stack([torch.randint(0, n, (300,), generator=gen), torch.randint(0, nc, (300,), generator=gen)])
+            ei_r = ei_r[:, torch.argsort(ei_r[0], stable=True)]
+            ev_r = torch.rand(300, 1, generator=gen, dtype=torch.float64)
+            Xc = torch.rand(nc, K, generator=gen, dtype=torch.float64)
+            mr = (ei_r[0] >= lo) & (ei_r[0] < hi)
+            pr = RowBlockPartition(ei_r[:, mr], n, lo, hi, col_blocks=[(ccuts[q], ccuts[q + 1]) for q in range(world)])
+            assert pr.n_in == ccuts[rank + 1] - ccuts[rank] and pr.n_local == hi - lo
+            bufr = pr.new_buffer(K, torch.float64, "cpu")
+            bufr[:pr.n_in] = Xc[ccuts[rank]:ccuts[rank + 1]]
+            pr.exchange(bufr)
+            yr = _local_spmv(pr, ev_r[mr], bufr)
+            assert torch.equal(yr, rp.scatter_sum(ev_r * Xc[ei_r[1]], ei_r[0], n)[lo:hi])
         # global reduction site (power method): all-reduce of partial column sums
         s = part.all_reduce_sum((X[lo:hi] * X[lo:hi]).sum(0))
         torch.testing.assert_close(s, (X * X).sum(0), rtol=1e-14, atol=0)
