@@ -348,13 +348,18 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_packed_kernel(
   const int r0 = ti.x, r1 = ti.y, s = ti.z, e = ti.w;
   if (r0 >= r1) return;
   const int tid = threadIdx.x;
-  const int r = r0 + tid;
-  int ra = 0, rb = 0;
-  typename Epi::Pre pre;
-  if (r < r1) {
-    ra = rowptr[r];
-    rb = rowptr[r + 1];
-    pre = epi.load((int64_t)r, 0);
+  // packed tiles hold ~2040 nonzeros = up to 2 rows per lane for 5-point rows: both rows' offsets and dense
+  // operands are requested before the nonzero stream (rows past the tile are clamped to its last row, not stored)
+  constexpr int RPL = 2;
+  int rr[RPL], ra[RPL], rb[RPL];
+  typename Epi::Pre pre[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    rr[i] = r0 + i * GLA_BLOCK + tid;
+    const int rc = min(rr[i], r1 - 1);
+    ra[i] = rowptr[rc];
+    rb[i] = rowptr[rc + 1];
+    pre[i] = epi.load((int64_t)rc, 0);
   }
   const auto gxs = epi.template gx_load<T>(0);
   const int sa = s & ~7;                       // multiple of 8 -> 8-byte aligned codes, 16-byte aligned deltas
@@ -393,19 +398,22 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_packed_kernel(
   __syncthreads();
 
   T red = T(0);
-  if (r < r1) {
-    T acc = T(0);
-    int j = ra - sa;
-    const int jend = rb - sa;
-    for (; j + 4 <= jend; j += 4) {
-      const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
-      acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    if (rr[i] < r1) {
+      T acc = T(0);
+      int j = ra[i] - sa;
+      const int jend = rb[i] - sa;
+      for (; j + 4 <= jend; j += 4) {
+        const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
+        acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+      }
+      for (; j < jend; ++j) acc = acc + prod[j];
+      epi.apply((int64_t)rr[i], 0, acc, pre[i]);
+      if constexpr (Epi::NRED > 0) red = red + epi.redv(acc, pre[i]);
     }
-    for (; j < jend; ++j) acc = acc + prod[j];
-    epi.apply((int64_t)r, 0, acc, pre);
-    if constexpr (Epi::NRED > 0) red = epi.redv(acc, pre);
   }
-  for (int r2 = r + GLA_BLOCK; r2 < r1; r2 += GLA_BLOCK) {
+  for (int r2 = r0 + RPL * GLA_BLOCK + tid; r2 < r1; r2 += GLA_BLOCK) {
     const int a = rowptr[r2] - sa, b = rowptr[r2 + 1] - sa;
     T acc = T(0);
     for (int j = a; j < b; ++j) acc = acc + prod[j];
