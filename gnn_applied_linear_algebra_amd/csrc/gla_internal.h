@@ -42,6 +42,7 @@ struct gla_tuning {
   int spmv_variant = 0;     // experimental kernel selection for K = 1 (see launch_rows)
   int tile_nnz = 0;         // 0 = automatic (256 * average row length)
   int spmm_variant = 0;     // 0 = paired-rhs 16-byte kernel when alignment allows, 1 = scalar lanes
+  int xcd_chunk = 64;       // consecutive tiles per XCD turn (1 = identity mapping, 0 = one contiguous span per XCD)
   int compress = 0;         // 1: gla_csr_set_values also builds the packed stream when the matrix allows it
 };
 extern gla_tuning g_tuning;

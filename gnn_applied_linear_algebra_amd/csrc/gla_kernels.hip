@@ -33,11 +33,32 @@ struct TileMap {
   const int32_t* tile_list;   // nullptr = identity
   int n_tiles;                // tiles to run in this launch
   int tiles_per_xcd;
+  int xcd_chunk;              // see map_tile
 };
+
+// grid = 8 * tiles_per_xcd workgroups; with chunking the per-XCD count is rounded up to whole chunks so that the
+// slot formula of map_tile is a bijection onto [0, 8 * tiles_per_xcd) (slots >= n_tiles exit at once)
+inline void set_tile_mapping(TileMap& tm) {
+  tm.xcd_chunk = g_tuning.xcd_chunk;
+  const int C = tm.xcd_chunk > 0 ? tm.xcd_chunk : 1;
+  const int per_round = GLA_XCDS * C;
+  tm.tiles_per_xcd = ((tm.n_tiles + per_round - 1) / per_round) * C;
+}
 
 __device__ __forceinline__ int map_tile(const TileMap& m) {
   const int bid = blockIdx.x;
-  const int slot = (bid % GLA_XCDS) * m.tiles_per_xcd + bid / GLA_XCDS;
+  // Workgroups b and b+8 share an XCD (round-robin dispatch).  xcd_chunk = C > 0: XCD e takes C consecutive tiles,
+  // then the next XCD the next C, ... (C = 1 is the plain identity mapping); xcd_chunk = 0: each XCD walks one
+  // contiguous eighth of the tiles.  Measured (tools/ab_spmv.py): small chunks win -- all XCDs then stream one
+  // common region of HBM, and a tile's x window (a few grid lines) is re-fetched by neighbouring XCDs from the
+  // Infinity Cache rather than from DRAM.
+  int slot;
+  if (m.xcd_chunk > 0) {
+    const int C = m.xcd_chunk, xcd = bid % GLA_XCDS, j = bid / GLA_XCDS;
+    slot = (j / C) * (GLA_XCDS * C) + xcd * C + (j % C);
+  } else {
+    slot = (bid % GLA_XCDS) * m.tiles_per_xcd + bid / GLA_XCDS;
+  }
   if (slot >= m.n_tiles) return -1;
   return m.tile_list ? m.tile_list[slot] : slot;
 }
@@ -620,7 +641,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   else return GLA_ERR_INVALID_ARG;
   if (which != 0 && A->tile_lists == nullptr) return GLA_ERR_INVALID_ARG;
   if (tm.n_tiles == 0) return GLA_OK;
-  tm.tiles_per_xcd = (tm.n_tiles + GLA_XCDS - 1) / GLA_XCDS;
+  set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   if (K == 1 && A->packed && g_tuning.compress && A->n_cols * (int64_t)sizeof(T) < ((int64_t)1 << 32)) {
     const size_t ldsp = (size_t)(256 + A->lds_elems + 16) * sizeof(T);
@@ -968,7 +989,7 @@ inline TileMap all_tiles(gla_csr* A) {
   tm.tile_info = reinterpret_cast<const int4*>(A->tile_info);
   tm.tile_list = nullptr;
   tm.n_tiles = A->n_tiles;
-  tm.tiles_per_xcd = (A->n_tiles + GLA_XCDS - 1) / GLA_XCDS;
+  set_tile_mapping(tm);
   return tm;
 }
 

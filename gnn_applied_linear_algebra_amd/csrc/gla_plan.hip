@@ -402,6 +402,7 @@ int gla_version(void) { return 100; }
 int gla_set_option(const char* name, int64_t value) {
   if (!name) return GLA_ERR_INVALID_ARG;
   if (!strcmp(name, "spmv_variant")) { g_tuning.spmv_variant = (int)value; return GLA_OK; }
+  if (!strcmp(name, "xcd_chunk")) { if (value < 0) return GLA_ERR_INVALID_ARG; g_tuning.xcd_chunk = (int)value; return GLA_OK; }
   if (!strcmp(name, "compress")) { g_tuning.compress = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "spmm_variant")) { g_tuning.spmm_variant = (int)value; return GLA_OK; }
   if (!strcmp(name, "tile_nnz")) {
