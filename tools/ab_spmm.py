@@ -32,9 +32,13 @@ ops = {
     "cheby_next": (lambda p: p.cheby_next(P, P2, R, Xo, -0.25, -0.26, 0.1), base + 48 * n * K),
 }
 res = {}
+chunks = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [64]
 for rnd in range(6):
+  for ch in chunks:
+    check(lib().gla_set_option(b"xcd_chunk", ch))
     for tnz in tiles:
-        for name, (fn, nb) in ops.items():
+        for name0, (fn, nb) in ops.items():
+            name = f"{name0}/C{ch}"
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(plans[tnz])
@@ -45,5 +49,5 @@ for rnd in range(6):
 for (name, tnz), ts in sorted(res.items()):
     ts.sort()
     med = ts[len(ts) // 2]
-    nb = ops[name][1]
-    print(f"{name:12s} K={K} tile_nnz={plans[tnz].info.tile_nnz:5d}: {med:8.1f} us  {nb / med / 1e3:7.1f} GB/s ({nb / med / 8e6 * 100:5.1f}%)")
+    nb = ops[name.split('/')[0]][1]
+    print(f"{name:16s} K={K} tile_nnz={plans[tnz].info.tile_nnz:5d}: {med:8.1f} us  {nb / med / 1e3:7.1f} GB/s ({nb / med / 8e6 * 100:5.1f}%)")
