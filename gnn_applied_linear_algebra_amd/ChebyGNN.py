@@ -8,7 +8,7 @@ operation order, so alpha/beta are bit-identical.
 """
 import torch
 
-from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
+from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, split_cols, stack_cols, to_dev
 
 
 def chebyshev_relax(plan, b, x0, g, deg):
@@ -50,7 +50,7 @@ class ChebyRelaxGNN(torch.nn.Module):
         if va.shape[1] != 2:
             raise ValueError("vertex_attr must be [n, 2] = [b, x]")
         plan = plan_for(ei, va.shape[0], edge_attr=ea)
-        b, x0 = cols(va, 0), cols(va, 1)
+        b, x0 = split_cols(va) if va.dim() == 2 else (cols(va, 0), cols(va, 1))
         x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg)
         ea_out = edge_cols(ea, plan.edge_products(gathered)) if self.return_edge_attr else None
         return back(stack_cols([b, x, r, p], va), vertex_attr), back(ea_out, edge_attr), g_out

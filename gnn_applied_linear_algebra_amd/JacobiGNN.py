@@ -8,7 +8,7 @@ write of x; the [A_ij, c_ij] edge tensor the reference re-materialises every swe
 import torch
 
 from . import meta
-from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
+from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, split_cols, stack_cols, to_dev
 
 
 def edge_to_vertex_aggregation(edgeij_pair, edge_attr, n_vertices):
@@ -46,9 +46,11 @@ def _prep(vertex_attr, edgeij_pair, edge_attr, g):
     if va.shape[1] != 3:
         raise ValueError("vertex_attr must be [n, 3] = [A_ii, b, x]")
     plan = plan_for(ei, va.shape[0], edge_attr=ea)
-    diag = (va[:, 0] if va.dim() == 2 else va[:, 0, 0]).contiguous()
     w = float(g.reshape(-1)[0])                  # w = g[0] in the tensor's own dtype (JacobiGNN.py:108)
-    return plan, va, ea, diag, cols(va, 1), cols(va, 2), w
+    if va.dim() == 2:
+        d_col, b, x = split_cols(va)             # one pass over the AoS rows
+        return plan, va, ea, d_col.reshape(-1), b, x, w
+    return plan, va, ea, va[:, 0, 0].contiguous(), cols(va, 1), cols(va, 2), w
 
 
 def _iterate(vertex_attr, edgeij_pair, edge_attr, g):

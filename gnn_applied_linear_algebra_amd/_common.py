@@ -56,6 +56,20 @@ def cols(t, idx):
     raise ValueError(f"attribute tensor must be [n, a] or [n, a, K], got {tuple(t.shape)}")
 
 
+def split_cols(t):
+    """All attribute columns of a 2-D AoS tensor [n, a] as contiguous [n, 1] operands in ONE device pass
+    (gla_split_columns); 3-D multi-RHS tensors [n, a, K] fall back to per-column copies."""
+    if t.dim() != 2 or not t.is_cuda or t.shape[1] > 8 or t.stride(1) != 1 or t.dtype not in (torch.float32, torch.float64):
+        return [cols(t, k) for k in range(t.shape[1])]
+    import ctypes
+    n, a = t.shape
+    outs = [torch.empty((n, 1), dtype=t.dtype, device=t.device) for _ in range(a)]
+    arr = (ctypes.c_void_p * a)(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.lib().gla_split_columns(_lib.dtype_code(t.dtype), n, a, _lib.ptr(t), t.stride(0) if n > 1 else a,
+                                            arr, _lib.stream_ptr(t.device)))
+    return outs
+
+
 def stack_cols(parts, like):
     """Inverse of `cols`: list of [n, K] -> [n, a] (like.dim()==2) or [n, a, K]."""
     if like.dim() == 2:
@@ -78,4 +92,4 @@ def aggregate(edgeij_pair, src, n_vertices, reduce="sum"):
     return back(plan.segment_reduce(to_dev(src, dev), reduce), src)
 
 
-__all__ = ["aggregate", "compute_device", "to_dev", "back", "float_dtype", "cols", "stack_cols", "edge_cols", "plan_for"]
+__all__ = ["aggregate", "split_cols", "compute_device", "to_dev", "back", "float_dtype", "cols", "stack_cols", "edge_cols", "plan_for"]

@@ -913,6 +913,22 @@ __global__ __launch_bounds__(GLA_BLOCK) void segment_reduce_kernel(
   }
 }
 
+// AoS -> SoA split of the reference's attribute tensors (vertex_attr [n, a] row-major -> a contiguous vectors): one
+// pass over the AoS rows instead of `a` strided copies.  The a (<= 8) column pointers are passed by value.
+struct SplitPtrs { void* p[8]; };
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void split_columns_kernel(const T* __restrict__ src, int64_t n, int a, int64_t ld,
+                                                                  SplitPtrs out) {
+  // lanes walk the flat [n, a] array (coalesced reads); each element goes to out[col][row]
+  const int64_t total = n * a;
+  for (int64_t idx = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int64_t r = idx / a;
+    const int c = (int)(idx - r * a);
+    static_cast<T*>(out.p[c])[r] = src[r * ld + c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // column dots / scaling (global aggregations of the power method)
 // ------------------------------------------------------------------------------------------------
@@ -1232,6 +1248,25 @@ int gla_segment_reduce(gla_csr_t A, int dtype, int K, const void* src, int64_t l
   if (dtype == GLA_F64)
     return launch_segment_reduce<double>(A, K, (const double*)src, ld_src, op, (double*)out, ld_out, (hipStream_t)stream);
   return launch_segment_reduce<float>(A, K, (const float*)src, ld_src, op, (float*)out, ld_out, (hipStream_t)stream);
+}
+
+int gla_split_columns(int dtype, int64_t n, int a, const void* src, int64_t ld, void* const* cols_host,
+                      gla_stream_t stream) {
+  if (n < 0 || a < 1 || a > 8 || ld < a || !cols_host || (n > 0 && !src) || (dtype != GLA_F32 && dtype != GLA_F64))
+    return GLA_ERR_INVALID_ARG;
+  if (n == 0) return GLA_OK;
+  SplitPtrs sp;
+  for (int c = 0; c < 8; ++c) sp.p[c] = c < a ? cols_host[c] : nullptr;
+  for (int c = 0; c < a; ++c) if (!sp.p[c]) return GLA_ERR_INVALID_ARG;
+  const unsigned grid = grid_for(n * a, GLA_BLOCK * 4, 256 * 16);
+  if (dtype == GLA_F64)
+    hipLaunchKernelGGL((split_columns_kernel<double>), dim3(grid), dim3(GLA_BLOCK), 0, (hipStream_t)stream,
+                       (const double*)src, n, a, ld, sp);
+  else
+    hipLaunchKernelGGL((split_columns_kernel<float>), dim3(grid), dim3(GLA_BLOCK), 0, (hipStream_t)stream,
+                       (const float*)src, n, a, ld, sp);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
 }
 
 int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,

@@ -157,6 +157,12 @@ int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, co
 int gla_segment_reduce(gla_csr_t A, int dtype, int K, const void* src, int64_t ld_src, int op, void* out,
                        int64_t ld_out, gla_stream_t stream);
 
+/* Split a row-major attribute tensor src [n, a] (a <= 8, leading dimension ld) into `a` contiguous vectors
+ * cols_host[c][i] = src[i*ld + c] in one pass (cols_host: HOST array of a device pointers).  The reference keeps
+ * vertex attributes as AoS [A_ii, b, x] / [b, x] / ... (JacobiGNN.py:104-106); the kernels read SoA. */
+int gla_split_columns(int dtype, int64_t n, int a, const void* src, int64_t ld, void* const* cols_host,
+                      gla_stream_t stream);
+
 /* Edge products in EDGE order: C[e,k] = A_e * X[col_e,k] -- the `c_ij`/`z_ij` column every EdgeUpdate
  * returns (e.g. JacobiGNN.py:83-88); materialised only when a caller asks for edge_attr. */
 int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,
