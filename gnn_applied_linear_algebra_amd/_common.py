@@ -65,8 +65,10 @@ def split_cols(t):
     n, a = t.shape
     outs = [torch.empty((n, 1), dtype=t.dtype, device=t.device) for _ in range(a)]
     arr = (ctypes.c_void_p * a)(*[o.data_ptr() for o in outs])
-    _lib.check(_lib.lib().gla_split_columns(_lib.dtype_code(t.dtype), n, a, _lib.ptr(t), t.stride(0) if n > 1 else a,
-                                            arr, _lib.stream_ptr(t.device)))
+    from .plan import _DeviceGuard
+    with _DeviceGuard(t.device):
+        _lib.check(_lib.lib().gla_split_columns(_lib.dtype_code(t.dtype), n, a, _lib.ptr(t),
+                                                t.stride(0) if n > 1 else a, arr, _lib.stream_ptr(t.device)))
     return outs
 
 

@@ -16,6 +16,32 @@ from ._lib import check, dtype_code, lib, ptr, stream_ptr
 ALL_TILES, INTERIOR_TILES, BOUNDARY_TILES = 0, 1, 2
 
 
+class _DeviceGuard:
+    """libgla_hip launches on the calling thread's current HIP device: make it the operands' device for the call
+    (a no-op in the usual one-process-per-GPU setting, where torch.cuda.set_device has been called once)."""
+
+    def __init__(self, device):
+        self.idx, self.prev = device.index, None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.idx is not None and cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+def _on_device(fn):
+    def wrapped(self, *a, **k):
+        with _DeviceGuard(self.device):
+            return fn(self, *a, **k)
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
 def _dense(t, rows, name):
     """Validate a row-major [rows, K] (or [rows]) GPU operand; return (2-D view, K, leading dimension)."""
     if not t.is_cuda:
@@ -70,6 +96,7 @@ class CsrPlan:
             self._h = None
 
     # ---- values ---------------------------------------------------------------------------------
+    @_on_device
     def set_values(self, edge_val):
         """edge_val: [nnz] or [nnz, n_e] (column 0 holds A_ij, as in the reference's edge_attr)."""
         if edge_val.shape[0] != self.nnz:
@@ -96,6 +123,7 @@ class CsrPlan:
             self._val_key = key
             self._val_ref = weakref.ref(edge_attr)
 
+    @_on_device
     def arrays(self):
         """(rowptr, col, perm) as int32 GPU tensors -- for the CSR-indexing parity tests."""
         rowptr = torch.empty(self.n_rows + 1, dtype=torch.int32, device=self.device)
@@ -104,6 +132,7 @@ class CsrPlan:
         check(lib().gla_csr_export(self._h, ptr(rowptr), ptr(col), ptr(perm), stream_ptr(self.device)))
         return rowptr, col, perm
 
+    @_on_device
     def classify_tiles(self, col_limit):
         ni, nb = ctypes.c_int32(), ctypes.c_int32()
         check(lib().gla_csr_classify_tiles(self._h, int(col_limit), stream_ptr(self.device), ctypes.byref(ni),
@@ -116,6 +145,7 @@ class CsrPlan:
         if self.nnz and self.val_dtype != dtype:
             raise _lib.GlaError(f"plan holds values of dtype {self.val_dtype}, operands are {dtype}")
 
+    @_on_device
     def spmm(self, X, out=None, which=ALL_TILES):
         X, K, ldx = _dense(X, self.n_cols, "X")
         self._need(X.dtype)
@@ -126,6 +156,7 @@ class CsrPlan:
                              stream_ptr(self.device)))
         return Y
 
+    @_on_device
     def residual(self, B, X, out=None, which=ALL_TILES):
         X, K, ldx = _dense(X, self.n_cols, "X")
         B, Kb, ldb = _dense(B, self.n_rows, "B")
@@ -137,6 +168,7 @@ class CsrPlan:
                                  stream_ptr(self.device)))
         return R
 
+    @_on_device
     def jacobi_sweep(self, diag, B, X, Xout, w, which=ALL_TILES):
         X, K, ldx = _dense(X, self.n_cols, "X")
         B, Kb, ldb = _dense(B, self.n_rows, "B")
@@ -149,6 +181,7 @@ class CsrPlan:
                                      ptr(Xout), ldxo, float(w), which, stream_ptr(self.device)))
         return Xout
 
+    @_on_device
     def jacobi_sweeps(self, diag, B, X0, w, n_iters):
         """n_iters fused sweeps; returns a new [n, K] tensor, X0 untouched (JacobiGNN.py:138-148)."""
         assert self.n_rows == self.n_cols
@@ -165,6 +198,7 @@ class CsrPlan:
                                       ptr(Xout), ptr(Xtmp), K, float(w), int(n_iters), stream_ptr(self.device)))
         return Xout
 
+    @_on_device
     def cheby_first(self, B, X, R, P, Xout, alpha, which=ALL_TILES):
         X, K, ldx = _dense(X, self.n_cols, "X")
         B, _, ldb = _dense(B, self.n_rows, "B")
@@ -178,6 +212,7 @@ class CsrPlan:
         check(lib().gla_cheby_first(self._h, dtype_code(X.dtype), K, ptr(B), ldb, ptr(X), ldx, ptr(R), ldr, ptr(P),
                                     ldp, ptr(Xout), ldxo, float(alpha), which, stream_ptr(self.device)))
 
+    @_on_device
     def cheby_next(self, P, Pout, R, X, alpha_old, alpha_new, beta, which=ALL_TILES):
         P, K, ldp = _dense(P, self.n_cols, "P")
         Pout, _, ldpo = _dense(Pout, self.n_rows, "Pout")
@@ -191,6 +226,7 @@ class CsrPlan:
                                    ptr(X), ldx, float(alpha_old), float(alpha_new), float(beta), which,
                                    stream_ptr(self.device)))
 
+    @_on_device
     def power_step(self, X, nrm=None, out=None, which=ALL_TILES, work=None, sumsq=None):
         """Fused power-method step: Y = A (X ./ nrm), sumsq[k] = sum_i Y[i,k]^2 (PowerMethodGNN.py:86-207).
         Returns (Y, sumsq, work); raises GlaError(-5) when the plan / K has no fused kernel."""
@@ -211,6 +247,7 @@ class CsrPlan:
                                    ptr(work), which, stream_ptr(self.device)))
         return Y, sumsq, work
 
+    @_on_device
     def segment_reduce(self, src, reduce="sum"):
         """torch_scatter.scatter(src, row, dim=0, dim_size=n_rows, reduce=...) on the plan's row structure; src is in
         EDGE order, [nnz] or [nnz, K]; returns [n_rows] resp. [n_rows, K]."""
@@ -226,6 +263,7 @@ class CsrPlan:
                                        stream_ptr(self.device)))
         return out.reshape(-1) if one_d else out
 
+    @_on_device
     def edge_products(self, X):
         """c_e = A_e * X[col_e] in EDGE order, [nnz, K]."""
         X, K, ldx = _dense(X, self.n_cols, "X")
@@ -235,6 +273,7 @@ class CsrPlan:
                                       stream_ptr(self.device)))
         return C
 
+    @_on_device
     def soc_classic(self, theta, dtype):
         self._need(dtype)
         v = torch.empty((self.n_rows, 1), dtype=dtype, device=self.device)
@@ -243,6 +282,7 @@ class CsrPlan:
                                     stream_ptr(self.device)))
         return v, S
 
+    @_on_device
     def direct_interp(self, diag, cf, S, want_alpha=False):
         dtype = diag.dtype
         self._need(dtype)
@@ -255,6 +295,7 @@ class CsrPlan:
                                       stream_ptr(self.device)))
         return (w, alpha) if want_alpha else w
 
+    @_on_device
     def soc_sa(self, diag):
         dtype = diag.dtype
         self._need(dtype)
@@ -275,7 +316,8 @@ def col_dot(X, Y):
     code = dtype_code(X.dtype)
     work = torch.empty(lib().gla_dot_work_bytes(n, K, code), dtype=torch.uint8, device=X.device)
     out = torch.empty(K, dtype=X.dtype, device=X.device)
-    check(lib().gla_col_dot(code, n, K, ptr(X), ldx, ptr(Y), ldy, ptr(out), ptr(work), stream_ptr(X.device)))
+    with _DeviceGuard(X.device):
+        check(lib().gla_col_dot(code, n, K, ptr(X), ldx, ptr(Y), ldy, ptr(out), ptr(work), stream_ptr(X.device)))
     return out
 
 
@@ -285,8 +327,9 @@ def col_scale_rsqrt(X, sumsq):
     X, K, ldx = _dense(X, n, "X")
     assert sumsq.numel() == K and sumsq.dtype == X.dtype and sumsq.is_cuda
     Y = torch.empty((n, K), dtype=X.dtype, device=X.device)
-    check(lib().gla_col_scale_rsqrt(dtype_code(X.dtype), n, K, ptr(X), ldx, ptr(sumsq), ptr(Y), K,
-                                    stream_ptr(X.device)))
+    with _DeviceGuard(X.device):
+        check(lib().gla_col_scale_rsqrt(dtype_code(X.dtype), n, K, ptr(X), ldx, ptr(sumsq), ptr(Y), K,
+                                        stream_ptr(X.device)))
     return Y
 
 

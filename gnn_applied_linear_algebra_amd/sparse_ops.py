@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from ._lib import check, dtype_code, lib, ptr, stream_ptr
-from .plan import CsrPlan
+from .plan import CsrPlan, _DeviceGuard
 
 
 def coalesce(edge_index, values, n_rows, n_cols):
@@ -26,9 +26,10 @@ def coalesce(edge_index, values, n_rows, n_cols):
     out_i = torch.empty((2, nnz), dtype=torch.long, device=ei.device)
     out_v = torch.empty(nnz, dtype=vals.dtype, device=ei.device)
     n_out = ctypes.c_int64()
-    check(lib().gla_coo_coalesce(int(n_rows), int(n_cols), nnz, ptr(ei[0]), ptr(ei[1]), ptr(vals), 1,
-                                 dtype_code(vals.dtype), ptr(out_i[0]), ptr(out_i[1]), ptr(out_v),
-                                 ctypes.byref(n_out), stream_ptr(ei.device)))
+    with _DeviceGuard(ei.device):
+        check(lib().gla_coo_coalesce(int(n_rows), int(n_cols), nnz, ptr(ei[0]), ptr(ei[1]), ptr(vals), 1,
+                                     dtype_code(vals.dtype), ptr(out_i[0]), ptr(out_i[1]), ptr(out_v),
+                                     ctypes.byref(n_out), stream_ptr(ei.device)))
     return out_i[:, :n_out.value].contiguous(), out_v[:n_out.value].contiguous()
 
 
@@ -40,12 +41,13 @@ def spgemm(A: CsrPlan, B: CsrPlan):
         raise ValueError("both plans need values of the same dtype")
     dev, dt = A.device, A.val_dtype
     n_prod = ctypes.c_int64()
-    check(lib().gla_spgemm_count(A._h, B._h, ctypes.byref(n_prod), stream_ptr(dev)))
-    out_i = torch.empty((2, n_prod.value), dtype=torch.long, device=dev)
-    out_v = torch.empty(n_prod.value, dtype=dt, device=dev)
-    n_out = ctypes.c_int64()
-    check(lib().gla_spgemm(A._h, B._h, dtype_code(dt), n_prod.value, ptr(out_i[0]), ptr(out_i[1]), ptr(out_v),
-                           ctypes.byref(n_out), stream_ptr(dev)))
+    with _DeviceGuard(dev):
+        check(lib().gla_spgemm_count(A._h, B._h, ctypes.byref(n_prod), stream_ptr(dev)))
+        out_i = torch.empty((2, n_prod.value), dtype=torch.long, device=dev)
+        out_v = torch.empty(n_prod.value, dtype=dt, device=dev)
+        n_out = ctypes.c_int64()
+        check(lib().gla_spgemm(A._h, B._h, dtype_code(dt), n_prod.value, ptr(out_i[0]), ptr(out_i[1]), ptr(out_v),
+                               ctypes.byref(n_out), stream_ptr(dev)))
     return out_i[:, :n_out.value].contiguous(), out_v[:n_out.value].contiguous()
 
 
