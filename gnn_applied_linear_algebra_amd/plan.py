@@ -253,7 +253,12 @@ class CsrPlan:
         EDGE order, [nnz] or [nnz, K]; returns [n_rows] resp. [n_rows, K]."""
         op = {"sum": 0, "add": 0, "max": 1, "min": 2, "mean": 3}[reduce]
         one_d = src.dim() == 1
-        s2 = src.reshape(self.nnz, -1)
+        if src.shape[0] != self.nnz:
+            raise ValueError(f"src has {src.shape[0]} rows, plan has {self.nnz} edges")
+        width = 1
+        for dsz in src.shape[1:]:
+            width *= dsz
+        s2 = src.reshape(self.nnz, width)
         if s2.shape[1] > 1 and s2.stride(1) != 1 or not s2.is_cuda:
             s2 = s2.contiguous().to(self.device)
         K = s2.shape[1]

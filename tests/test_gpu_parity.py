@@ -824,3 +824,42 @@ def test_unfused_l3_modules_golden(golden, N):
     va, ea, _ = la(d(torch.hstack([diag, split])), d(eio), d(torch.hstack([evr, Sflag])), None, batch=None)
     va, ea, _ = lb(va, d(eio), ea, None, batch=None)
     eq(ea[:, 2], golden[f"N{N}_di_rnd_w"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# property test: random COO graphs (ragged, unsorted, duplicates, empty rows, rectangular) vs the oracle
+# ---------------------------------------------------------------------------------------------------
+def test_random_graphs_property():
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(n_rows=st.integers(1, 300), n_cols=st.integers(1, 300), nnz=st.integers(0, 3000),
+           K=st.sampled_from([1, 2, 3, 8, 16]), f32=st.booleans(), sort=st.booleans(), seed=st.integers(0, 2 ** 31 - 1),
+           compress=st.booleans())
+    def check(n_rows, n_cols, nnz, K, f32, sort, seed, compress):
+        from gnn_applied_linear_algebra_amd._lib import lib, check as chk
+        gen = torch.Generator().manual_seed(seed)
+        dtype = torch.float32 if f32 else torch.float64
+        row = torch.randint(0, n_rows, (nnz,), generator=gen)
+        col = torch.randint(0, n_cols, (nnz,), generator=gen)
+        if sort:
+            order = torch.argsort(row, stable=True)
+            row, col = row[order], col[order]
+        ei = torch.stack([row, col])
+        vals = (torch.randint(-3, 4, (nnz, 1), generator=gen).to(dtype) if compress
+                else (torch.rand(nnz, 1, generator=gen, dtype=torch.float64) - 0.5).to(dtype))
+        X = (torch.rand(n_cols, K, generator=gen, dtype=torch.float64) - 0.5).to(dtype)
+        B = (torch.rand(n_rows, K, generator=gen, dtype=torch.float64) - 0.5).to(dtype)
+        want = rp.scatter_sum(vals * X[col], row, n_rows)
+        chk(lib().gla_set_option(b"compress", 1 if compress else 0))
+        try:
+            plan = gla.CsrPlan(d(ei), n_rows, n_cols)
+            plan.set_values(d(vals))
+            eq(plan.spmm(d(X)), want)
+            eq(plan.residual(d(B), d(X)), B - want)
+            eq(plan.edge_products(d(X)), vals * X[col])
+            eq(plan.segment_reduce(d(vals * X[col])), want)
+        finally:
+            chk(lib().gla_set_option(b"compress", 0))
+
+    check()
