@@ -49,7 +49,23 @@ def cpu_baseline(n_grid, sweeps):
     t0 = time.perf_counter()
     rp.jacobi_forward(sweeps, va, ei, ea, g)
     dt = time.perf_counter() - t0
+    # for scale: the same sweep with a plain CPU CSR SpMV (torch.sparse_csr, same threads),
+    # so that the speed-up is not read off the reference's gather/concat overhead alone
+    csr_value = None
+    try:
+        crow = torch.zeros(n + 1, dtype=torch.int64)
+        crow[1:] = torch.cumsum(torch.bincount(ei[0], minlength=n), 0)
+        A_csr = torch.sparse_csr_tensor(crow, ei[1], ev.flatten(), (n, n))
+        xc = x.clone()
+        xc = xc + 0.7 * (b - A_csr @ xc) / -4.0
+        t1 = time.perf_counter()
+        for _ in range(sweeps):
+            xc = xc + 0.7 * (b - A_csr @ xc) / -4.0
+        csr_value = sweeps / (time.perf_counter() - t1)
+    except Exception:
+        pass
     return {"value": sweeps / dt, "unit": "sweeps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "csr_spmv_sweeps_per_s": None if csr_value is None else round(csr_value, 3),
             "sample": f"{sweeps} sweeps of the {n_grid}x{n_grid} fp64 JacobiGNN in the reference's COO "
                       f"gather/cat/scatter_add formulation (oracle/reference_port.py), torch CPU, "
                       f"{torch.get_num_threads()} threads of {os.cpu_count()} logical cores",
