@@ -13,6 +13,11 @@ sys.dont_write_bytecode = True
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a clean checkout has no libgla_hip.so (built artefacts are git-ignored): build it once, hipcc cross-compiles
+    lib = os.path.join(ROOT, "gnn_applied_linear_algebra_amd", "libgla_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.run(["bash", os.path.join(ROOT, "gnn_applied_linear_algebra_amd", "csrc", "build.sh")], check=True)
 
 
 @pytest.fixture(scope="session")
