@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling instead of the default weak scaling: a FIXED (grid x grid) Laplacian "
                          "(BASELINE config 4: --grid 8192) is cut into N row blocks; reports scaling=strong")
+    ap.add_argument("--no-col16", action="store_true",
+                    help="read 4-byte columns (the plain CSR stream of SURVEY's byte model) instead of int16 "
+                         "tile-relative columns")
     ap.add_argument("--compress", action="store_true",
                     help="opt-in packed matrix stream (int16 tile-relative columns + value dictionary, 3 B/nnz)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal of the N>1 path)")
@@ -115,6 +118,8 @@ def main():
     from gnn_applied_linear_algebra_amd import UtilsGNN
     if args.compress:
         gla._lib.check(gla._lib.lib().gla_set_option(b"compress", 1))
+    if args.no_col16:
+        gla._lib.check(gla._lib.lib().gla_set_option(b"col16", 0))
 
     Nx = args.n
     if args.strong:
@@ -201,7 +206,8 @@ def main():
         if world == 1 and os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                if tj.get("n") == args.n:
+                if tj.get("n") == args.n and int(tj.get("col16", 0)) == int(plan.info.col16) \
+                        and not bool(plan.info.packed):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -209,6 +215,13 @@ def main():
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "algorithmic_bytes_per_launch": B,
                 "avg_launch_us": round(t_launch * 1e6, 2)}
+        info = plan.info if world == 1 else None
+        if info is not None and bool(info.col16) and not bool(info.packed):
+            # default layout: 2-byte tile-relative columns.  `achieved` / `frac` keep SURVEY 8(d)'s CSR byte model
+            # (12 B per nonzero) as prescribed; `layout_*` is what the kernel really has to move (10 B per nonzero)
+            Bl = 10 * nnz_local + 4 * (n_local + 1) + 32 * n_local
+            roof.update({"layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
+                         "layout_frac": round(Bl / t_launch / 8e12, 4)})
         if args.compress and world == 1 and bool(plan.info.packed):
             # the packed layout moves 3 B per nonzero instead of the 12 B of SURVEY's CSR model: `achieved` keeps the
             # SURVEY byte model as prescribed (it can exceed what HBM delivers), `layout_*` is what is really moved

@@ -35,7 +35,9 @@ struct gla_csr {
   int16_t* col16 = nullptr;      // [nnz + 16] column minus the first row of the nonzero's tile
   uint8_t* vcode = nullptr;      // [nnz + 16] index into vdict
   void* vdict = nullptr;         // [256] distinct values (bit patterns ascending), dtype = val_dtype
-  int32_t packed = 0, col16_state = 0;   // col16_state: 0 not tried, 1 built, -1 does not fit int16
+  uint32_t* col16_wide = nullptr; // bit t set: tile t has a column outside int16 range of its first row (reads col)
+  int32_t packed = 0, col16_state = 0;   // col16_state: 0 not tried, 1 built, -1 most tiles do not fit int16
+  int32_t col16_wide_tiles = 0;
 };
 
 struct gla_tuning {
@@ -43,6 +45,7 @@ struct gla_tuning {
   int tile_nnz = 0;         // 0 = automatic (256 * average row length)
   int spmm_variant = 0;     // 0 = paired-rhs 16-byte kernel when alignment allows, 1 = scalar lanes
   int xcd_chunk = 64;       // consecutive tiles per XCD turn (1 = identity mapping, 0 = one contiguous span per XCD)
+  int col16 = 1;            // K = 1 kernels read int16 tile-relative columns when the plan could build them
   int compress = 0;         // 1: gla_csr_set_values also builds the packed stream when the matrix allows it
 };
 extern gla_tuning g_tuning;

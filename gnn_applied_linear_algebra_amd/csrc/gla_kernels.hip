@@ -19,6 +19,7 @@
 // Multi-RHS (K > 1, row-major [n, K]): val/col are staged in LDS instead of products, and the lanes
 // are (row, rhs) pairs so that every gather reads K contiguous values of one X row.
 #include "gla_internal.h"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -257,10 +258,11 @@ __device__ __forceinline__ T wave_sum(T v) {
 // nnz window is aligned down to an even index (the extra element is staged but never summed).
 // PF: the row lane's rowptr / dense operands are requested before the nnz stream so that the block runs through
 // three dependent memory round trips (tile record -> streams -> x gather) instead of five.
-template <typename T, class Epi, int PPT, bool NT, bool PF>
+template <typename T, class Epi, int PPT, bool NT, bool PF, bool COL16 = false>
 __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
-    const T* __restrict__ x, TileMap tm, Epi epi) {
+    const T* __restrict__ x, TileMap tm, Epi epi, const int16_t* __restrict__ col16 = nullptr,
+    const uint32_t* __restrict__ wide_mask = nullptr, unsigned n_cols = 0) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* prod = reinterpret_cast<T*>(smem_raw);
   typedef T T2 __attribute__((ext_vector_type(2)));
@@ -284,8 +286,15 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
   const int npairs = (e - sa + 1) >> 1;
   const T2* val2 = reinterpret_cast<const T2*>(val + sa);
   const I2* col2 = reinterpret_cast<const I2*>(col + sa);
+  // COL16: columns are read as int16 offsets from the tile's first row (2 B instead of 4 B per nonzero); tiles
+  // with a column out of that range (halo columns of a row-block partition) are flagged in wide_mask and read int32
+  const unsigned* colp = reinterpret_cast<const unsigned*>(COL16 ? col16 + sa : nullptr);
+  bool wide = false;
+  if constexpr (COL16) wide = (wide_mask[t >> 5] >> (t & 31)) & 1u;
   T2* prod2 = reinterpret_cast<T2*>(prod);
 
+  auto stream_tile = [&](auto c16_tag) {
+  constexpr bool C16 = decltype(c16_tag)::value;
   for (int base = 0; base < npairs; base += GLA_BLOCK * PPT) {
     T2 v[PPT];
     I2 c[PPT];
@@ -297,7 +306,14 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       qc[u] = min(base + u * GLA_BLOCK + tid, npairs - 1);
-      c[u] = ld_stream<NT>(col2 + qc[u]);
+      if constexpr (C16) {
+        const unsigned pk = ld_stream<NT>(colp + qc[u]);
+        // the alignment-slack element belongs to a neighbouring tile and may decode out of range: clamp (never summed)
+        c[u].x = (int)min((unsigned)(r0 + (int)(short)(pk & 0xFFFFu)), n_cols - 1);
+        c[u].y = (int)min((unsigned)(r0 + (int)(short)(pk >> 16)), n_cols - 1);
+      } else {
+        c[u] = ld_stream<NT>(col2 + qc[u]);
+      }
       v[u] = ld_stream<NT>(val2 + qc[u]);
     }
     T2 xv[PPT];
@@ -313,6 +329,12 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
       p.y = v[u].y * xv[u].y;
       prod2[qc[u]] = p;
     }
+  }
+  };
+  if constexpr (COL16) {
+    if (wide) stream_tile(std::false_type{}); else stream_tile(std::true_type{});
+  } else {
+    stream_tile(std::false_type{});
   }
   __syncthreads();
 
@@ -658,6 +680,12 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
 #define GLA_SPMV2(N_, NT_, PF_) \
   hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
                      X, tm, epi)
+    if (A->col16_state == 1 && g_tuning.col16 && g_tuning.spmv_variant == 0) {
+      hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, true>), grid, block, lds, st, A->rowptr,
+                         A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols);
+      GLA_LAUNCH_CHECK();
+      return GLA_OK;
+    }
     switch (g_tuning.spmv_variant) {          // A/B knobs (tools/ab_spmv.py); 0 is the tuned default
       case 1: GLA_SPMV2(3, false, false); break;
       case 2: GLA_SPMV2(2, false, true); break;

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void compact_apply_kernel(const int64_t*
 // ---- packed stream (option "compress") ---------------------------------------------------------------------
 // col16[p] = col[p] - (first row of p's tile); flag set when a delta does not fit int16
 __global__ __launch_bounds__(GLA_BLOCK) void col16_kernel(const int32_t* __restrict__ col, const int4* __restrict__ tile_info,
-                                                          int n_tiles, int16_t* __restrict__ col16, int* fail) {
+                                                          int n_tiles, int16_t* __restrict__ col16,
+                                                          uint32_t* __restrict__ wide, int* fail) {
   const int t = blockIdx.x;
   if (t >= n_tiles) return;
   const int4 ti = tile_info[t];
@@ -244,7 +245,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void col16_kernel(const int32_t* __restr
     if (d < -32768 || d > 32767) bad = 1;
     col16[p] = (int16_t)d;
   }
-  if (bad) atomicOr(fail, 1);
+  if (__syncthreads_or(bad) && threadIdx.x == 0) {
+    atomicOr(&wide[t >> 5], 1u << (t & 31));
+    atomicAdd(fail, 1);
+  }
 }
 
 template <typename T, typename U>
@@ -285,27 +289,48 @@ __global__ __launch_bounds__(GLA_BLOCK) void val_code_kernel(const T* __restrict
   }
 }
 
+int build_col16(gla_csr* p, hipStream_t st) {
+  if (p->col16_state != 0 || p->nnz == 0 || p->long_rows) return GLA_OK;
+  hipError_t e;
+#define PK(expr) do { e = (expr); if (e != hipSuccess) return -(1000 + (int)e); } while (0)
+  int* d_fail = nullptr;
+  {
+    PK(hipMalloc(&p->col16, (p->nnz + 16) * sizeof(int16_t)));
+    PK(hipMemsetAsync(p->col16, 0, (p->nnz + 16) * sizeof(int16_t), st));
+    const size_t mask_bytes = ((size_t)p->n_tiles / 32 + 1) * sizeof(uint32_t);
+    PK(hipMalloc(&p->col16_wide, mask_bytes));
+    PK(hipMemsetAsync(p->col16_wide, 0, mask_bytes, st));
+    PK(hipMalloc(&d_fail, sizeof(int)));
+    PK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+    hipLaunchKernelGGL(col16_kernel, dim3(p->n_tiles), dim3(GLA_BLOCK), 0, st, p->col,
+                       reinterpret_cast<const int4*>(p->tile_info), p->n_tiles, p->col16, p->col16_wide, d_fail);
+    int h_fail = 0;
+    PK(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+    PK(hipStreamSynchronize(st));
+    (void)hipFree(d_fail);
+    p->col16_wide_tiles = h_fail;
+    p->col16_state = (2 * (int64_t)h_fail > p->n_tiles) ? -1 : 1;   // mostly wide: not worth the second stream
+    if (p->col16_state < 0) {
+      (void)hipFree(p->col16);
+      (void)hipFree(p->col16_wide);
+      p->col16 = nullptr;
+      p->col16_wide = nullptr;
+    }
+  }
+  return GLA_OK;
+#undef PK
+}
+
 template <typename T, typename U>
 int build_packed(gla_csr* p, hipStream_t st) {
   p->packed = 0;
   if (p->nnz == 0 || p->long_rows) return GLA_OK;
   hipError_t e;
-#define PK(expr) do { e = (expr); if (e != hipSuccess) return -(1000 + (int)e); } while (0)
-  int* d_fail = nullptr;
-  if (p->col16_state == 0) {
-    PK(hipMalloc(&p->col16, (p->nnz + 16) * sizeof(int16_t)));
-    PK(hipMemsetAsync(p->col16, 0, (p->nnz + 16) * sizeof(int16_t), st));
-    PK(hipMalloc(&d_fail, sizeof(int)));
-    PK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
-    hipLaunchKernelGGL(col16_kernel, dim3(p->n_tiles), dim3(GLA_BLOCK), 0, st, p->col,
-                       reinterpret_cast<const int4*>(p->tile_info), p->n_tiles, p->col16, d_fail);
-    int h_fail = 0;
-    PK(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
-    PK(hipStreamSynchronize(st));
-    (void)hipFree(d_fail);
-    p->col16_state = h_fail ? -1 : 1;
+  {
+    const int rc0 = build_col16(p, st);
+    if (rc0) return rc0;
   }
-  if (p->col16_state < 0) return GLA_OK;
+  if (p->col16_state != 1 || p->col16_wide_tiles != 0) return GLA_OK;   // the packed kernel has no int32 fallback
   // value dictionary: sort the bit patterns, count the distinct ones
   U *keys = nullptr, *keys2 = nullptr;
   int64_t *flags = nullptr, *pos = nullptr;
@@ -351,7 +376,6 @@ done:
   if (tmp) (void)hipFree(tmp);
   if (tmp2) (void)hipFree(tmp2);
   return rc;
-#undef PK
 #undef PKG
 }
 
@@ -403,6 +427,7 @@ int gla_set_option(const char* name, int64_t value) {
   if (!name) return GLA_ERR_INVALID_ARG;
   if (!strcmp(name, "spmv_variant")) { g_tuning.spmv_variant = (int)value; return GLA_OK; }
   if (!strcmp(name, "xcd_chunk")) { if (value < 0) return GLA_ERR_INVALID_ARG; g_tuning.xcd_chunk = (int)value; return GLA_OK; }
+  if (!strcmp(name, "col16")) { g_tuning.col16 = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "compress")) { g_tuning.compress = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "spmm_variant")) { g_tuning.spmm_variant = (int)value; return GLA_OK; }
   if (!strcmp(name, "tile_nnz")) {
@@ -437,6 +462,7 @@ int gla_csr_destroy(gla_csr_t p) {
   if (p->tile_info) (void)hipFree(p->tile_info);
   if (p->tile_lists) (void)hipFree(p->tile_lists);
   if (p->col16) (void)hipFree(p->col16);
+  if (p->col16_wide) (void)hipFree(p->col16_wide);
   if (p->vcode) (void)hipFree(p->vcode);
   if (p->vdict) (void)hipFree(p->vdict);
   delete p;
@@ -520,6 +546,10 @@ int gla_csr_create_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const i
     PLAN_CHECK(hipGetLastError());
   }
   PLAN_CHECK(hipStreamSynchronize(st));
+  if (g_tuning.col16 || g_tuning.compress) {
+    rc = build_col16(p, st);              // int16 tile-relative columns for the K = 1 kernels (when the band fits)
+    if (rc) goto fail;
+  }
   (void)hipFree(d_flags);
   if (keys_sorted) (void)hipFree(keys_sorted);
   *out = p;
@@ -556,6 +586,7 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->sorted_input = p->sorted_input; info->max_row_len = p->max_row_len;
   info->n_tiles = p->n_tiles; info->tile_nnz = p->tile_nnz; info->lds_elems = p->lds_elems;
   info->long_rows = p->long_rows; info->val_dtype = p->val_dtype; info->packed = p->packed;
+  info->col16 = (p->col16_state == 1 && g_tuning.col16) ? 1 : 0; info->col16_wide_tiles = p->col16_wide_tiles;
   return GLA_OK;
 }
 

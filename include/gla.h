@@ -49,7 +49,11 @@ int gla_version(void);
 /* Tuning knobs (process-wide): "spmv_variant" (kernel flavour for K = 1), "tile_nnz" (target nnz per row
  * tile for plans created afterwards; 0 = automatic), "compress" (1: gla_csr_set_values additionally builds a packed
  * stream -- int16 tile-relative columns + a <= 256-entry value dictionary -- when the matrix allows it; the K = 1
- * kernels then read 3 bytes per nonzero instead of 12, results are bit-identical; default 0). */
+ * kernels then read 3 bytes per nonzero instead of 12, results are bit-identical; default 0), "col16" (1, the
+ * default: plans created afterwards also keep the columns as int16 offsets from the first row of the nonzero's row
+ * tile, and the K = 1 kernels read those 2 bytes instead of the 4-byte column; tiles with a column outside that
+ * range -- halo columns of a row-block partition -- are read as int32; results are bit-identical), "xcd_chunk",
+ * "spmm_variant" (A/B knobs). */
 int gla_set_option(const char* name, int64_t value);
 const char* gla_error_string(int code);
 
@@ -76,6 +80,8 @@ typedef struct {
   int32_t long_rows;        /* 1: some row exceeds the LDS tile -> CSR-vector kernels are used */
   int32_t val_dtype;        /* GLA_F32 / GLA_F64 / -1 */
   int32_t packed;           /* 1: the 3-byte-per-nonzero packed stream is in use for K = 1 (option "compress") */
+  int32_t col16;            /* 1: int16 tile-relative columns are in use for K = 1 (option "col16") */
+  int32_t col16_wide_tiles; /* row tiles that keep int32 columns (a column out of int16 range) */
 } gla_csr_info_t;
 int gla_csr_info(gla_csr_t plan, gla_csr_info_t* info_host);
 

@@ -657,6 +657,71 @@ def test_full_size_config4_8192():
     eq(r, b.numpy() - A.spmm(want))
 
 
+def test_col16_columns_bit_identical():
+    """The default K = 1 kernels read int16 tile-relative columns (option "col16"); tiles with a far column keep
+    int32.  Every fused op must give exactly the int32-column result, tile partition unchanged (also the partials)."""
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+
+    def run_all(ei, ev, n, n_cols, dtype):
+        ei_d, ev_d = d(ei), d(ev.to(dtype))
+        x = d(torch.rand(n_cols, 1, generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(dtype))
+        plan = gla.CsrPlan(ei_d, n, n_cols)
+        plan.set_values(ev_d)
+        outs = [plan.spmm(x)]
+        if n == n_cols:
+            b = d(torch.rand(n, 1, generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(dtype))
+            diag = torch.full((n,), -4.0, dtype=dtype, device=DEV)
+            outs += [plan.residual(b, x), plan.jacobi_sweeps(diag, b, x, 0.7, 5)]
+            r, p, xo, p2 = (torch.empty_like(x) for _ in range(4))
+            plan.cheby_first(b, x, r, p, xo, -0.25)
+            plan.cheby_next(p, p2, r, xo, -0.25, -0.26, 0.1)
+            y, ss, _ = plan.power_step(x, nrm=torch.tensor([1.7], dtype=dtype, device=DEV))
+            outs += [r, p2, xo, y, ss]
+        return plan, outs
+
+    gen = torch.Generator().manual_seed(77)
+    cases = []
+    ei, ev = rp.laplacianfun_torch(300)
+    cases.append(("laplacian", ei, ev, 90000, 90000, 1, 0))
+    ei, ev = rp.heateqnfem2dfun([71, 59], [1.0, 4.0])
+    cases.append(("fem", ei, ev, 70 * 58, 70 * 58, 1, 0))
+    # a row block with halo columns appended far behind the own columns: only the tiles touching them stay int32
+    n, n_cols = 60000, 60000 + 50000
+    k = torch.arange(n)
+    far = torch.where(k < 300, n + 49000 + k % 7, (k + 1) % n)
+    ei = torch.stack([torch.cat([k, k, k]), torch.cat([k, (k + 3) % n, far])])
+    ei = ei[:, torch.argsort(ei[0], stable=True)]
+    cases.append(("halo tail", ei, torch.rand(3 * n, 1, generator=gen, dtype=torch.float64), n, n_cols, 1, None))
+    n = 100000                                   # every tile has a coupling 50000 columns away: no int16 stream
+    k = torch.arange(n)
+    ei = torch.stack([torch.cat([k, k]), torch.cat([k, (k + 50000) % n])])
+    ei = ei[:, torch.argsort(ei[0], stable=True)]
+    cases.append(("wide band", ei, torch.ones(2 * n, 1, dtype=torch.float64), n, n, 0, None))
+    n = 70000                                    # +40000 for the first rows (int32 tiles), -30000 for the rest (int16)
+    k = torch.arange(n)
+    ei = torch.stack([torch.cat([k, k]), torch.cat([k, (k + 40000) % n])])
+    ei = ei[:, torch.argsort(ei[0], stable=True)]
+    cases.append(("half wide", ei, torch.rand(2 * n, 1, generator=gen, dtype=torch.float64), n, n, 1, -1))
+    for name, ei, ev, n, n_cols, want16, want_wide in cases:
+        for dtype in (torch.float64, torch.float32):
+            try:
+                check(lib().gla_set_option(b"col16", 0))
+                plan32, ref_out = run_all(ei, ev, n, n_cols, dtype)
+                assert plan32.info.col16 == 0
+            finally:
+                check(lib().gla_set_option(b"col16", 1))
+            plan, out = run_all(ei, ev, n, n_cols, dtype)
+            assert plan.info.col16 == want16, (name, plan.info.col16)
+            if want_wide == -1:
+                assert 0 < plan.info.col16_wide_tiles <= plan.info.n_tiles // 2, (name, plan.info.col16_wide_tiles)
+            elif want_wide is not None:
+                assert plan.info.col16_wide_tiles == want_wide, (name, plan.info.col16_wide_tiles)
+            elif want16:
+                assert 0 < plan.info.col16_wide_tiles < plan.info.n_tiles // 4, (name, plan.info.col16_wide_tiles)
+            for a, b_ in zip(out, ref_out):
+                eq(a, b_)
+
+
 # ---------------------------------------------------------------------------------------------------
 # opt-in packed matrix stream (option "compress"): bit-identical results, falls back when not applicable
 # ---------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc")
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
+col16 = int(sys.argv[4]) if len(sys.argv) > 4 else 1      # the workload ran with int16 tile-relative columns
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
@@ -28,15 +29,17 @@ fetch_factor = calib_read / mean(c["FETCH_SIZE"])
 write_factor = 512 * 1024 / mean(c["WRITE_SIZE"])
 n, nnz = N * N, 5 * N * N - 4 * N
 alg = 12 * nnz + 4 * (n + 1) + 32 * n
+layout = (10 if col16 else 12) * nnz + 4 * (n + 1) + 32 * n
 rd = mean(j["FETCH_SIZE"]) * 1024 * 2.0
 wr = mean(j["WRITE_SIZE"]) * 1024
-out = {"n": N, "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "launches": len(j["FETCH_SIZE"]),
+out = {"n": N, "col16": col16, "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "launches": len(j["FETCH_SIZE"]),
        "FETCH_SIZE_KiB": mean(j["FETCH_SIZE"]), "WRITE_SIZE_KiB": mean(j["WRITE_SIZE"]),
        "fetch_correction": 2.0, "calibration_fetch_factor_measured": round(fetch_factor, 4),
        "calibration_write_factor_measured": round(write_factor, 4),
        "hbm_read_bytes_per_launch": int(rd), "hbm_write_bytes_per_launch": int(wr),
        "hbm_bytes_per_launch": int(rd + wr), "algorithmic_bytes_per_launch": alg,
        "traffic_over_algorithmic": round((rd + wr) / alg, 4),
+       "layout_bytes_per_launch": layout, "traffic_over_layout": round((rd + wr) / layout, 4),
        "TCC_HIT_sum": mean(j["TCC_HIT_sum"]) if j.get("TCC_HIT_sum") else None,
        "TCC_MISS_sum": mean(j["TCC_MISS_sum"]) if j.get("TCC_MISS_sum") else None}
 os.makedirs(os.path.join(ROOT, "profiles", tag), exist_ok=True)
