@@ -9,8 +9,9 @@ from . import _lib  # noqa: F401
 from .meta import MetaLayer  # noqa: F401
 from .plan import CsrPlan, plan_for, col_dot, col_scale_rsqrt  # noqa: F401
 from . import sparse_ops  # noqa: F401
+from . import autograd  # noqa: F401
 from . import (UtilsGNN, MatVecGNN, GNNResidual, JacobiGNN, ChebyGNN, PowerMethodGNN, SOCClassicGNN,  # noqa: F401
-               DirectInterpGNN, SOCSAGNN, MatrixWeightedNorm, VCycle)
+               DirectInterpGNN, SOCSAGNN, MatrixWeightedNorm, VCycle, TrainableJacobiDiag)
 
 __all__ = ["MetaLayer", "CsrPlan", "plan_for", "UtilsGNN", "MatVecGNN", "GNNResidual", "JacobiGNN", "ChebyGNN",
-           "PowerMethodGNN", "SOCClassicGNN", "DirectInterpGNN", "SOCSAGNN", "MatrixWeightedNorm", "VCycle"]
+           "PowerMethodGNN", "SOCClassicGNN", "DirectInterpGNN", "SOCSAGNN", "MatrixWeightedNorm", "VCycle", "TrainableJacobiDiag", "autograd"]

@@ -941,6 +941,70 @@ __global__ __launch_bounds__(GLA_BLOCK) void segment_reduce_kernel(
   }
 }
 
+// The four row statistics of TrainableJacobiGNN.py:53-70 in one pass over src: out[r, :] = cat(min, mean, sum, max)
+// (each K wide).  Same visiting order and empty-row / NaN rules as segment_reduce_kernel.
+template <typename T, int KP>
+__global__ __launch_bounds__(GLA_BLOCK) void segment_stats_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm, const T* __restrict__ src, int64_t lds_,
+    int K, int64_t n_rows, T* __restrict__ out, int64_t ldo) {
+  constexpr int RPP = GLA_BLOCK / KP;
+  const int k0 = threadIdx.x % KP, rsub = threadIdx.x / KP;
+  for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n_rows; r += (int64_t)gridDim.x * RPP) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    for (int k = k0; k < K; k += KP) {
+      T sum = T(0), mn = T(0), mx = T(0);
+      for (int p = a; p < b; ++p) {
+        const int64_t e = perm ? (int64_t)perm[p] : (int64_t)p;
+        const T v = src[e * lds_ + k];
+        sum = sum + v;
+        if (p == a) { mn = v; mx = v; }
+        else {
+          mx = (v > mx || v != v) ? v : mx;
+          mn = (v < mn || v != v) ? v : mn;
+        }
+      }
+      T* o = out + r * ldo + k;
+      o[0] = mn;
+      o[K] = b > a ? sum / T(b - a) : sum;
+      o[2 * (int64_t)K] = sum;
+      o[3 * (int64_t)K] = mx;
+    }
+  }
+}
+
+// Edge-wise dot products (SDDMM on the plan's pattern): out[e] = sum_k G[row(e), k] * X[col(e), k] -- the gradient of
+// Y = A X with respect to the stored values (loss.py:92-128 differentiates through `A @ Y`).  KP lanes share a row:
+// each keeps its slice of G[row, :] in registers-by-reload, walks the row's edges and the KP partial sums are
+// combined by a fixed xor-shuffle tree (deterministic; not the sequential k order -- this is a gradient).
+template <typename T, int KP>
+__global__ __launch_bounds__(GLA_BLOCK) void edge_dot_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+    const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx, int K, int64_t n_rows,
+    T* __restrict__ out) {
+  constexpr int RPP = GLA_BLOCK / KP;
+  const int k0 = threadIdx.x % KP, rsub = threadIdx.x / KP;
+  const int64_t n_round = ((n_rows + RPP - 1) / RPP) * RPP;        // whole groups stay together for the shuffles
+  for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n_round; r += (int64_t)gridDim.x * RPP) {
+    const bool live = r < n_rows;
+    const int a = live ? rowptr[r] : 0, b = live ? rowptr[r + 1] : 0;
+    int len = b - a;
+    int maxlen = len;                                              // lanes of one wave must shuffle together
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+    for (int j = 0; j < maxlen; ++j) {
+      const int p = a + j;
+      T acc = T(0);
+      if (j < len) {
+        const int64_t c = col[p];
+        for (int k = k0; k < K; k += KP) acc = acc + G[r * ldg + k] * X[c * ldx + k];
+      }
+#pragma unroll
+      for (int o = KP >> 1; o >= 1; o >>= 1) acc = acc + __shfl_xor(acc, o);
+      if (j < len && k0 == 0) out[perm ? (int64_t)perm[p] : (int64_t)p] = acc;
+    }
+  }
+}
+
 // AoS -> SoA split of the reference's attribute tensors (vertex_attr [n, a] row-major -> a contiguous vectors): one
 // pass over the AoS rows instead of `a` strided copies.  The a (<= 8) column pointers are passed by value.
 struct SplitPtrs { void* p[8]; };
@@ -1114,6 +1178,48 @@ int launch_segment_reduce(gla_csr* A, int K, const T* src, int64_t ld_src, int o
   return GLA_OK;
 }
 
+template <typename T>
+int launch_segment_stats(gla_csr* A, int K, const T* src, int64_t ld_src, T* out, int64_t ld_out, hipStream_t st) {
+  int kp = 1;
+  while (kp < K && kp < 64) kp <<= 1;
+  const unsigned grid = grid_for(A->n_rows, GLA_BLOCK / kp, 256 * 16);
+#define GLA_SEG(KP_)                                                                                            \
+  hipLaunchKernelGGL((segment_stats_kernel<T, KP_>), dim3(grid), dim3(GLA_BLOCK), 0, st, A->rowptr, A->perm,   \
+                     src, ld_src, K, A->n_rows, out, ld_out)
+  switch (kp) {
+    case 1: GLA_SEG(1); break;
+    case 2: GLA_SEG(2); break;
+    case 4: GLA_SEG(4); break;
+    case 8: GLA_SEG(8); break;
+    case 16: GLA_SEG(16); break;
+    case 32: GLA_SEG(32); break;
+    default: GLA_SEG(64); break;
+  }
+#undef GLA_SEG
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+template <typename T>
+int launch_edge_dot(gla_csr* A, int K, const T* G, int64_t ldg, const T* X, int64_t ldx, T* out, hipStream_t st) {
+  int kp = 1;
+  while (kp * 2 <= K && kp < 16) kp <<= 1;         // largest power of two <= min(K, 16)
+  const unsigned grid = grid_for(A->n_rows, GLA_BLOCK / kp, 256 * 16);
+#define GLA_EDOT(KP_)                                                                                           \
+  hipLaunchKernelGGL((edge_dot_kernel<T, KP_>), dim3(grid), dim3(GLA_BLOCK), 0, st, A->rowptr, A->col, A->perm, \
+                     G, ldg, X, ldx, K, A->n_rows, out)
+  switch (kp) {
+    case 1: GLA_EDOT(1); break;
+    case 2: GLA_EDOT(2); break;
+    case 4: GLA_EDOT(4); break;
+    case 8: GLA_EDOT(8); break;
+    default: GLA_EDOT(16); break;
+  }
+#undef GLA_EDOT
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1276,6 +1382,29 @@ int gla_segment_reduce(gla_csr_t A, int dtype, int K, const void* src, int64_t l
   if (dtype == GLA_F64)
     return launch_segment_reduce<double>(A, K, (const double*)src, ld_src, op, (double*)out, ld_out, (hipStream_t)stream);
   return launch_segment_reduce<float>(A, K, (const float*)src, ld_src, op, (float*)out, ld_out, (hipStream_t)stream);
+}
+
+int gla_segment_stats(gla_csr_t A, int dtype, int K, const void* src, int64_t ld_src, void* out, int64_t ld_out,
+                      gla_stream_t stream) {
+  if (!A || K < 1 || (dtype != GLA_F32 && dtype != GLA_F64) || ld_src < K || ld_out < 4 * (int64_t)K)
+    return GLA_ERR_INVALID_ARG;
+  if (A->n_rows == 0) return GLA_OK;
+  if (!out || (A->nnz > 0 && !src)) return GLA_ERR_INVALID_ARG;
+  if (dtype == GLA_F64)
+    return launch_segment_stats<double>(A, K, (const double*)src, ld_src, (double*)out, ld_out, (hipStream_t)stream);
+  return launch_segment_stats<float>(A, K, (const float*)src, ld_src, (float*)out, ld_out, (hipStream_t)stream);
+}
+
+int gla_edge_dot(gla_csr_t A, int dtype, int K, const void* G, int64_t ldg, const void* X, int64_t ldx,
+                 void* out_edge, gla_stream_t stream) {
+  if (!A || K < 1 || (dtype != GLA_F32 && dtype != GLA_F64) || ldg < K || ldx < K) return GLA_ERR_INVALID_ARG;
+  if (A->n_rows == 0 || A->nnz == 0) return GLA_OK;
+  if (!G || !X || !out_edge) return GLA_ERR_INVALID_ARG;
+  if (dtype == GLA_F64)
+    return launch_edge_dot<double>(A, K, (const double*)G, ldg, (const double*)X, ldx, (double*)out_edge,
+                                   (hipStream_t)stream);
+  return launch_edge_dot<float>(A, K, (const float*)G, ldg, (const float*)X, ldx, (float*)out_edge,
+                                (hipStream_t)stream);
 }
 
 int gla_split_columns(int dtype, int64_t n, int a, const void* src, int64_t ld, void* const* cols_host,

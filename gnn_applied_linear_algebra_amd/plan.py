@@ -269,6 +269,37 @@ class CsrPlan:
         return out.reshape(-1) if one_d else out
 
     @_on_device
+    def segment_stats(self, src):
+        """cat(min, mean, sum, max) of src over each row's edges, one pass: src [nnz] or [nnz, K] in EDGE order ->
+        [n_rows, 4K] (TrainableJacobiGNN.py:53-70)."""
+        if src.shape[0] != self.nnz:
+            raise ValueError(f"src has {src.shape[0]} rows, plan has {self.nnz} edges")
+        width = 1
+        for dsz in src.shape[1:]:
+            width *= dsz
+        s2 = src.reshape(self.nnz, width)
+        if s2.shape[1] > 1 and s2.stride(1) != 1 or not s2.is_cuda:
+            s2 = s2.contiguous().to(self.device)
+        K = s2.shape[1]
+        ld = s2.stride(0) if self.nnz > 1 else K
+        out = torch.empty((self.n_rows, 4 * K), dtype=s2.dtype, device=self.device)
+        check(lib().gla_segment_stats(self._h, dtype_code(s2.dtype), K, ptr(s2), max(ld, K), ptr(out), 4 * K,
+                                      stream_ptr(self.device)))
+        return out
+
+    @_on_device
+    def edge_dot(self, G, X):
+        """out[e] = sum_k G[row_e, k] * X[col_e, k] in EDGE order, [nnz] (dL/dvalues of Y = A X for G = dL/dY)."""
+        G, K, ldg = _dense(G, self.n_rows, "G")
+        X, Kx, ldx = _dense(X, self.n_cols, "X")
+        if Kx != K or X.dtype != G.dtype:
+            raise ValueError("G and X must have the same number of columns and dtype")
+        out = torch.empty(self.nnz, dtype=G.dtype, device=self.device)
+        check(lib().gla_edge_dot(self._h, dtype_code(G.dtype), K, ptr(G), ldg, ptr(X), ldx, ptr(out),
+                                 stream_ptr(self.device)))
+        return out
+
+    @_on_device
     def edge_products(self, X):
         """c_e = A_e * X[col_e] in EDGE order, [nnz, K]."""
         X, K, ldx = _dense(X, self.n_cols, "X")

@@ -163,6 +163,19 @@ int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, co
 int gla_segment_reduce(gla_csr_t A, int dtype, int K, const void* src, int64_t ld_src, int op, void* out,
                        int64_t ld_out, gla_stream_t stream);
 
+/* The four row statistics of the trainable-Jacobi model in one pass: out[i, 0:K] = min, [K:2K] = mean, [2K:3K] = sum,
+ * [3K:4K] = max over the edges of row i of src [nnz, K] (edge order; empty rows give 0; ld_out >= 4K).
+ * TrainableJacobiDiag/TrainableJacobiGNN.py:53-70 (four torch_scatter.scatter calls + torch.cat). */
+int gla_segment_stats(gla_csr_t A, int dtype, int K, const void* src, int64_t ld_src, void* out, int64_t ld_out,
+                      gla_stream_t stream);
+
+/* Edge-wise dot products on the plan's pattern: out_edge[e] = sum_k G[row(e), k] * X[col(e), k], EDGE order [nnz].
+ * This is dL/dA_e of Y = A X given G = dL/dY: the backward of the `A @ Y` products the reference differentiates
+ * through with torch autograd (TrainableJacobiDiag/loss.py:92-128, train.py:105).  dL/dX = A^T G is gla_spmm on a
+ * plan of the flipped edge list.  Only the plan's index side is used. */
+int gla_edge_dot(gla_csr_t A, int dtype, int K, const void* G, int64_t ldg, const void* X, int64_t ldx,
+                 void* out_edge, gla_stream_t stream);
+
 /* Split a row-major attribute tensor src [n, a] (a <= 8, leading dimension ld) into `a` contiguous vectors
  * cols_host[c][i] = src[i*ld + c] in one pass (cols_host: HOST array of a device pointers).  The reference keeps
  * vertex attributes as AoS [A_ii, b, x] / [b, x] / ... (JacobiGNN.py:104-106); the kernels read SoA. */

@@ -438,3 +438,69 @@ def vcycle(A, b, x, splitting, n_pre=3, n_post=3, cheb_deg=4, theta=0.25, w=0.7)
     xc = run_cheby(Ac, rc, torch.zeros_like(rc), -3.4, -4.0)                   # :221-223
     x = x + P @ xc                                                             # :226
     return run_jacobi(n_post, x)
+
+
+# ---------------------------------------------------------------------------------------------------
+# learned Jacobi diagonal: pytorch/TrainableJacobiDiag/{TrainableJacobiGNN,loss}.py.
+# Pinned by tests/golden/trainable_vectors.npz (oracle/gen_golden_trainable.py, unmodified reference).
+# ---------------------------------------------------------------------------------------------------
+def trainable_edge_stats(ei, edge_attr, n):
+    """TrainableJacobiGNN.py:53-70  cat(min, mean, sum, max) of the edge attributes per sending vertex."""
+    idx = ei[0].reshape(-1, 1).expand_as(edge_attr)
+    zeros = torch.zeros((n, edge_attr.shape[1]), dtype=edge_attr.dtype)
+    s = zeros.clone().scatter_add_(0, idx, edge_attr)
+    cnt = zeros.clone().scatter_add_(0, idx, torch.ones_like(edge_attr))
+    mn = zeros.clone().scatter_reduce_(0, idx, edge_attr, "amin", include_self=False)
+    mx = zeros.clone().scatter_reduce_(0, idx, edge_attr, "amax", include_self=False)
+    return torch.cat((mn, s / cnt.clamp(min=1), s, mx), 1)
+
+
+def trainable_mlp(params, x):
+    """TrainableJacobiGNN.py:86-91  Linear(5,50) ReLU Linear(50,20) ReLU Linear(20,1); params = the state dict."""
+    for k in (0, 2, 4):
+        x = x @ params[f"node_model.vertex_update.{k}.weight"].T + params[f"node_model.vertex_update.{k}.bias"]
+        if k != 4:
+            x = torch.relu(x)
+    return x
+
+
+def trainable_model(params, vertex_attr, ei, edge_attr):
+    """TrainableJacobiGNN.py:93-111  MLP(cat(vertex_attr, edge statistics))."""
+    return trainable_mlp(params, torch.cat([vertex_attr, trainable_edge_stats(ei, edge_attr, vertex_attr.shape[0])], 1))
+
+
+def trainable_error_matrix(A_ind, A_val, n, diag, omega):
+    """loss.py:92-102  T = I - omega D^-1 A, coalesced torch sparse tensor (A coalesced)."""
+    T_val = -omega * (1 / diag[A_ind[0, :]].reshape(-1)) * A_val
+    eye = torch.arange(n)
+    T = torch.sparse_coo_tensor(torch.hstack((A_ind, torch.stack((eye, eye)))),
+                                torch.hstack((T_val, torch.ones(n, dtype=T_val.dtype))), (n, n))
+    return T.coalesce()
+
+
+def trainable_eigval_approx(K, T, Y):
+    """loss.py:105-128  max_j ||T^K y_j||^(1/K) for given normalised test vectors."""
+    for _ in range(K):
+        Y = T @ Y
+    return torch.max(torch.linalg.vector_norm(Y, dim=0)) ** (1 / K)
+
+
+def trainable_high_freq(N, m):
+    """loss.py:139-170 with xy=None (consumes torch's global CPU generator exactly like the reference)."""
+    import math
+    n = int(math.sqrt(N))
+    xx = torch.zeros(n * n, 1)
+    yy = torch.zeros(n * n, 1)
+    for j in range(n):
+        for i in range(n):
+            me = (j - 1) * n + i
+            xx[me] = (i + 1) / (n + 1)
+            yy[me] = (j + 1) / (n + 1)
+    Y = torch.zeros(N, m)
+    k = 0
+    while k < m:
+        thetax, thetay = (n - 1) * torch.rand(2) + 1
+        if thetax > n / 2 or thetay > n / 2:
+            Y[:, k] = (torch.sin(thetax * torch.pi * xx) * torch.sin(thetay * torch.pi * yy)).squeeze()
+            k += 1
+    return Y @ torch.diagflat(1 / torch.linalg.vector_norm(Y, dim=0))

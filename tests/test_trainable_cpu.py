@@ -1,0 +1,61 @@
+"""CPU checks of the learned-Jacobi tier: the oracle restatement (oracle/reference_port.py trainable_*) against the
+golden vectors generated from the unmodified reference (tests/golden/trainable_vectors.npz)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import reference_port as rp  # noqa: E402
+
+CASES = ("demo4", "lap4", "var4", "lap8", "var8")
+
+
+@pytest.fixture(scope="module")
+def tg():
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "trainable_vectors.npz")))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def load_case(tg, name):
+    va, ei, ea = T(tg[f"{name}_va"]), T(tg[f"{name}_ei"]).long(), T(tg[f"{name}_ea"])
+    params = {k[len(name) + 7:]: T(v) for k, v in tg.items() if k.startswith(f"{name}_param_")}
+    return va, ei, ea, params
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_edge_stats_and_model(tg, name):
+    va, ei, ea, params = load_case(tg, name)
+    agg = rp.trainable_edge_stats(ei, ea, va.shape[0])
+    assert torch.equal(agg, T(tg[f"{name}_agg"]))
+    out = rp.trainable_model(params, va, ei, ea)
+    torch.testing.assert_close(out, T(tg[f"{name}_model_out"]), rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_error_matrix_and_damping_factor(tg, name):
+    va, ei, ea, params = load_case(tg, name)
+    n = va.shape[0]
+    A = T(tg[f"{name}_A"]).to_sparse().coalesce()
+    d = T(tg[f"{name}_model_out"]).clone().requires_grad_(True)
+    Tm = rp.trainable_error_matrix(A.indices(), A.values(), n, d, 2. / 3.)
+    assert torch.equal(Tm.indices(), T(tg[f"{name}_T_ind"]).long())
+    assert torch.equal(Tm.values().detach(), T(tg[f"{name}_T_val"]))
+    df = rp.trainable_eigval_approx(3, Tm, T(tg[f"{name}_Y_uniform"]))
+    df.backward()
+    torch.testing.assert_close(df.detach(), T(tg[f"{name}_df_uniform"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(d.grad, T(tg[f"{name}_df_uniform_grad"]), rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_high_freq_vectors(tg, name):
+    n = tg[f"{name}_va"].shape[0]
+    torch.manual_seed(77)
+    Y = rp.trainable_high_freq(n, 20)
+    assert torch.equal(Y, T(tg[f"{name}_Y_highfreq"]))
