@@ -19,7 +19,14 @@ def _as_sparse(A, device=None):
     if isinstance(A, SparseMatrix):
         return A
     if isinstance(A, torch.Tensor) and A.layout == torch.sparse_coo:
-        return SparseMatrix.from_torch(A, device)
+        cached = getattr(A, "_gla_sparse", None)        # device copy (and its cached plans) kept with the tensor
+        if cached is None:
+            cached = SparseMatrix.from_torch(A, device)
+            try:
+                A._gla_sparse = cached
+            except Exception:
+                pass
+        return cached
     raise TypeError("expected a SparseMatrix or a torch sparse COO tensor")
 
 
@@ -48,13 +55,20 @@ def build_error_matrix(A, diag, omega):
     n = A.shape[0]
     diag = diag.to(dev)
     T_val = -omega * (1 / diag[A_ind[0, :]].reshape(-1)) * A_val
-    eye = torch.arange(n, device=dev)
-    # pattern of A union I: slot of every stacked entry in the coalesced list
-    stacked = torch.hstack((A_ind, torch.stack((eye, eye))))
-    T_ind, _ = coalesce(stacked, torch.zeros(stacked.shape[1], dtype=A_val.dtype, device=dev), n, A.shape[1])
-    keys = T_ind[0] * A.shape[1] + T_ind[1]
-    slot_A = torch.searchsorted(keys, A_ind[0] * A.shape[1] + A_ind[1])
-    slot_I = torch.searchsorted(keys, eye * A.shape[1] + eye)
+    pattern = getattr(A, "_error_pattern", None)
+    if pattern is None:
+        # pattern of A union I and the slot of every stacked entry in the coalesced list: integer work done once per
+        # matrix (the training loop calls this every step with a new diagonal), which also keeps T's edge-index
+        # tensor -- and with it the CSR plans of T and T^T cached on that tensor -- alive across steps
+        eye = torch.arange(n, device=dev)
+        stacked = torch.hstack((A_ind, torch.stack((eye, eye))))
+        T_ind, _ = coalesce(stacked, torch.zeros(stacked.shape[1], dtype=A_val.dtype, device=dev), n, A.shape[1])
+        keys = T_ind[0] * A.shape[1] + T_ind[1]
+        slot_A = torch.searchsorted(keys, A_ind[0] * A.shape[1] + A_ind[1])
+        slot_I = torch.searchsorted(keys, eye * A.shape[1] + eye)
+        pattern = (T_ind, slot_A, slot_I)
+        A._error_pattern = pattern
+    T_ind, slot_A, slot_I = pattern
     out = torch.zeros(T_ind.shape[1], dtype=T_val.dtype, device=dev)
     out = out.index_add(0, slot_A, T_val)                       # A is coalesced: one entry per slot
     out = out.index_add(0, slot_I, torch.ones(n, dtype=T_val.dtype, device=dev))

@@ -20,6 +20,7 @@
 // are (row, rhs) pairs so that every gather reads K contiguous values of one X row.
 #include "gla_internal.h"
 #include <type_traits>
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -118,7 +119,7 @@ struct EpiStore {                       // y = A x                       MatVecG
   template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>&) const {
     stv<V>(y + r * ldy + k, acc);
   }
-  bool vec2_ok() const { return al16(y) && ldy % 2 == 0; }
+  bool vec_ok(int w) const { return al16(y) && ldy % w == 0; }
   GLA_EPI_SCALAR_API
 };
 
@@ -132,7 +133,7 @@ struct EpiResidual {                    // r = b - A x                   GNNResi
   template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& p) const {
     stv<V>(res + r * ldr + k, p.b - acc);
   }
-  bool vec2_ok() const { return al16(b) && al16(res) && ldb % 2 == 0 && ldr % 2 == 0; }
+  bool vec_ok(int w) const { return al16(b) && al16(res) && ldb % w == 0 && ldr % w == 0; }
   GLA_EPI_SCALAR_API
 };
 
@@ -146,8 +147,8 @@ struct EpiJacobi {                      // x + (w*(b - A x))/A_ii        JacobiG
   template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& p) const {
     stv<V>(xo + r * ldxo + k, p.x + (w * (p.b - acc)) / p.d);
   }
-  bool vec2_ok() const {
-    return al16(b) && al16(x) && al16(xo) && ldb % 2 == 0 && ldx % 2 == 0 && ldxo % 2 == 0;
+  bool vec_ok(int w) const {
+    return al16(b) && al16(x) && al16(xo) && ldb % w == 0 && ldx % w == 0 && ldxo % w == 0;
   }
   GLA_EPI_SCALAR_API
 };
@@ -166,9 +167,9 @@ struct EpiChebyFirst {                  // r = b - A x; p = r; x += alpha p    C
     stv<V>(p + r * ldp + k, ri);
     stv<V>(xo + r * ldxo + k, q.x + alpha * ri);
   }
-  bool vec2_ok() const {
-    return al16(b) && al16(x) && al16(res) && al16(p) && al16(xo) && ldb % 2 == 0 && ldx % 2 == 0 &&
-           ldr % 2 == 0 && ldp % 2 == 0 && ldxo % 2 == 0;
+  bool vec_ok(int w) const {
+    return al16(b) && al16(x) && al16(res) && al16(p) && al16(xo) && ldb % w == 0 && ldx % w == 0 &&
+           ldr % w == 0 && ldp % w == 0 && ldxo % w == 0;
   }
   GLA_EPI_SCALAR_API
 };
@@ -188,9 +189,9 @@ struct EpiChebyNext {                   // r -= a_old*(A p); p = r + beta p; x +
     stv<V>(po + r * ldpo + k, pn);
     stv<V>(x + r * ldx + k, q.x + a_new * pn);
   }
-  bool vec2_ok() const {
-    return al16(p) && al16(po) && al16(res) && al16(x) && ldp % 2 == 0 && ldpo % 2 == 0 && ldr % 2 == 0 &&
-           ldx % 2 == 0;
+  bool vec_ok(int w) const {
+    return al16(p) && al16(po) && al16(res) && al16(x) && ldp % w == 0 && ldpo % w == 0 && ldr % w == 0 &&
+           ldx % w == 0;
   }
   GLA_EPI_SCALAR_API
 };
@@ -218,15 +219,23 @@ struct EpiPower {
     GxV<V> g;
     if constexpr (sizeof(V) == sizeof(T)) { g.n = nrm ? nrm[k] : T(1); g.rn = nrm ? rnrm[k] : T(1); }
     else {
-      g.n.x = nrm ? nrm[k] : T(1); g.n.y = nrm ? nrm[k + 1] : T(1);
-      g.rn.x = nrm ? rnrm[k] : T(1); g.rn.y = nrm ? rnrm[k + 1] : T(1);
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(V) / sizeof(T)); ++i) {
+        g.n[i] = nrm ? nrm[k + i] : T(1);
+        g.rn[i] = nrm ? rnrm[k + i] : T(1);
+      }
     }
     return g;
   }
   template <typename V> __device__ __forceinline__ V gx(V xv, const GxV<V>& g) const {
     if (!nrm) return xv;
     if constexpr (sizeof(V) == sizeof(T)) return div_by(xv, g.n, g.rn);
-    else { V o; o.x = div_by(xv.x, g.n.x, g.rn.x); o.y = div_by(xv.y, g.n.y, g.rn.y); return o; }
+    else {
+      V o;
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(V) / sizeof(T)); ++i) o[i] = div_by(xv[i], g.n[i], g.rn[i]);
+      return o;
+    }
   }
   template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t, int) const { return PreV<V>{}; }
   template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>&) const {
@@ -234,7 +243,7 @@ struct EpiPower {
   }
   template <typename V> __device__ __forceinline__ V redv(V acc, const PreV<V>&) const { return acc * acc; }
   __device__ __forceinline__ T* partials_ptr() const { return partials; }
-  bool vec2_ok() const { return al16(y) && ldy % 2 == 0; }
+  bool vec_ok(int w) const { return al16(y) && ldy % w == 0; }
   GLA_EPI_SCALAR_CORE
 };
 
@@ -245,6 +254,32 @@ template <bool NT, typename U>
 __device__ __forceinline__ U ld_stream(const U* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
   else return *p;
+}
+
+// Sum over aligned groups of KP (<= 16) lanes with DPP moves (full-rate VALU; ds_bpermute-based __shfl_xor runs
+// through the LDS pipe and was the bottleneck of gla_edge_dot).  quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror: after log2(KP) steps every lane of the group holds the group's sum (fixed order).
+template <int CTRL, typename T>
+__device__ __forceinline__ T dpp_move(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+  } else {
+    typedef int I2v __attribute__((ext_vector_type(2)));
+    I2v w = __builtin_bit_cast(I2v, v);
+    w.x = __builtin_amdgcn_update_dpp(0, w.x, CTRL, 0xF, 0xF, true);
+    w.y = __builtin_amdgcn_update_dpp(0, w.y, CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(T, w);
+  }
+}
+
+template <int KP, typename T>
+__device__ __forceinline__ T group_sum(T v) {
+  static_assert(KP == 1 || KP == 2 || KP == 4 || KP == 8 || KP == 16, "group of 1..16 lanes");
+  if constexpr (KP >= 2) v = v + dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+  if constexpr (KP >= 4) v = v + dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+  if constexpr (KP >= 8) v = v + dpp_move<0x141>(v);     // row_half_mirror
+  if constexpr (KP >= 16) v = v + dpp_move<0x140>(v);    // row_mirror
+  return v;
 }
 
 template <typename T>
@@ -520,12 +555,12 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_kernel(
 // MODE 1: branch-free clamped batches (surplus lanes re-read the last entry and are masked out of the sum).
 constexpr int SPMM_ROWCAP = 1024;               // row offsets staged per tile (more rows -> read rowptr directly)
 
-template <typename T, int LPR, int MODE, class Epi>
+template <typename T, int LPR, int MODE, class Epi, int VW = 2>
 __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
     const T* __restrict__ X, int64_t ldx, int K, int lds_elems, TileMap tm, Epi epi) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef T T2 __attribute__((ext_vector_type(VW)));      // VW adjacent right-hand sides per lane (2, or 4 for fp32)
   T* sval = reinterpret_cast<T*>(smem_raw);
   int32_t* scol = reinterpret_cast<int32_t*>(sval + lds_elems);
   int32_t* srow = scol + lds_elems;             // [SPMM_ROWCAP + 1] offsets relative to the tile's first nnz
@@ -548,17 +583,17 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
   }
   __syncthreads();
   constexpr int RPP = GLA_BLOCK / LPR;          // rows per pass
-  const int k0 = (tid % LPR) * 2, rsub = tid / LPR;
-  T2 red = {T(0), T(0)};
-  const auto gxs0 = epi.template gx_load<T2>(min(k0, max(K - 2, 0)));
+  const int k0 = (tid % LPR) * VW, rsub = tid / LPR;
+  T2 red = T2(T(0));
+  const auto gxs0 = epi.template gx_load<T2>(min(k0, max(K - VW, 0)));
   for (int r = r0 + rsub; r < r1; r += RPP) {
     int a, b;
     if (r - r0 < SPMM_ROWCAP) { a = srow[r - r0]; b = srow[r - r0 + 1]; }
     else { a = rowptr[r] - s; b = rowptr[r + 1] - s; }
-    for (int k = k0; k < K; k += 2 * LPR) {
+    for (int k = k0; k < K; k += VW * LPR) {
       const auto pre = epi.template loadv<T2>((int64_t)r, k);
       const auto gxs = (k == k0) ? gxs0 : epi.template gx_load<T2>(k);
-      T2 acc = {T(0), T(0)};
+      T2 acc = T2(T(0));
       const T* Xk = X + k;
       if constexpr (MODE == 0) {
         int j = a;
@@ -607,9 +642,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
       if (tid < st) sred[tid] = sred[tid] + sred[tid + st];
       __syncthreads();
     }
-    if (tid < LPR && k0 < K) {
-      epi.partials_ptr()[(int64_t)t * K + k0] = sred[tid].x;
-      if (k0 + 1 < K) epi.partials_ptr()[(int64_t)t * K + k0 + 1] = sred[tid].y;
+    if (tid < LPR) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i)
+        if (k0 + i < K) epi.partials_ptr()[(int64_t)t * K + k0 + i] = sred[tid][i];
     }
   }
 }
@@ -642,7 +678,7 @@ template <typename T, class Epi>
 int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int which, hipStream_t st) {
   if (A->n_rows == 0) return GLA_OK;
   const T* val = static_cast<const T*>(A->val);
-  if (Epi::NRED > 0 && (A->long_rows || (K > 1 && !((K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec2_ok()))))
+  if (Epi::NRED > 0 && (A->long_rows || (K > 1 && !((K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec_ok(2)))))
     return GLA_ERR_UNSUPPORTED;           // reducing epilogues exist for the K = 1 and paired-rhs kernels only
   if (A->long_rows) {
     if (which == 1) return GLA_OK;        // nothing is "interior" for the fallback: all rows run after the halo
@@ -696,7 +732,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
 #undef GLA_SPMV2
   } else {
     const size_t lds = (size_t)A->lds_elems * (sizeof(T) + sizeof(int32_t));
-    const bool vec2 = (K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec2_ok() &&
+    const bool vec2 = (K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec_ok(2) &&
                       (g_tuning.spmm_variant != 1 || Epi::NRED > 0);
 #define GLA_SPMM_CASE(KP_)                                                                              \
   hipLaunchKernelGGL((spmm_stream_kernel<T, KP_, Epi>), grid, block, lds, st, A->rowptr, A->col, val, X, \
@@ -711,7 +747,21 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
       hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, LPR_, 0, Epi>), grid, block, lds2, st, A->rowptr, A->col, \
                          val, X, ldx, K, A->lds_elems, tm, epi);                                               \
   } while (0)
-    if (vec2) {
+    const bool vec4 = sizeof(T) == 4 && vec2 && (K % 4 == 0) && (ldx % 4 == 0) && epi.vec_ok(4) &&
+                      g_tuning.spmm_variant != 3;      // fp32: four right-hand sides (16 bytes) per lane
+    if (vec4) {
+#define GLA_SPMM4_CASE(LPR_)                                                                                      \
+  hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, LPR_, 0, Epi, 4>), grid, block,                                  \
+                     lds + (SPMM_ROWCAP + 1) * sizeof(int32_t), st, A->rowptr, A->col, val, X, ldx, K,            \
+                     A->lds_elems, tm, epi)
+      if (K <= 4) GLA_SPMM4_CASE(1);
+      else if (K <= 8) GLA_SPMM4_CASE(2);
+      else if (K <= 16) GLA_SPMM4_CASE(4);
+      else if (K <= 32) GLA_SPMM4_CASE(8);
+      else if (K <= 64) GLA_SPMM4_CASE(16);
+      else GLA_SPMM4_CASE(32);
+#undef GLA_SPMM4_CASE
+    } else if (vec2) {
       if (K <= 2) GLA_SPMM2_CASE(1);
       else if (K <= 4) GLA_SPMM2_CASE(2);
       else if (K <= 8) GLA_SPMM2_CASE(4);
@@ -973,33 +1023,150 @@ __global__ __launch_bounds__(GLA_BLOCK) void segment_stats_kernel(
 }
 
 // Edge-wise dot products (SDDMM on the plan's pattern): out[e] = sum_k G[row(e), k] * X[col(e), k] -- the gradient of
-// Y = A X with respect to the stored values (loss.py:92-128 differentiates through `A @ Y`).  KP lanes share a row:
-// each keeps its slice of G[row, :] in registers-by-reload, walks the row's edges and the KP partial sums are
+// Y = A X with respect to the stored values (loss.py:92-128 differentiates through `A @ Y`).  KP lanes share a row;
+// lane q owns the contiguous slice [q*kc, (q+1)*kc) of the K columns (kc <= GLA_EDOT_KC) and keeps its slice of
+// G[row, :] in registers.  The row's edges are taken four at a time: the four columns are loaded first, then all
+// 4*kc gathers are issued back to back (clamped indices, no exec-mask branches), then the KP partial sums are
 // combined by a fixed xor-shuffle tree (deterministic; not the sequential k order -- this is a gradient).
+#define GLA_EDOT_KC 8
 template <typename T, int KP>
 __global__ __launch_bounds__(GLA_BLOCK) void edge_dot_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+    const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx, int K, int64_t n_rows, int nnz,
+    T* __restrict__ out) {
+  constexpr int RPP = GLA_BLOCK / KP;
+  const int q = threadIdx.x % KP, rsub = threadIdx.x / KP;
+  const int kc = (K + KP - 1) / KP;
+  const int k_lo = q * kc;
+  const int64_t n_round = ((n_rows + RPP - 1) / RPP) * RPP;        // whole groups stay together for the shuffles
+  for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n_round; r += (int64_t)gridDim.x * RPP) {
+    const bool live = r < n_rows;
+    const int64_t rr = live ? r : n_rows - 1;
+    const int a = live ? rowptr[rr] : 0, b = live ? rowptr[rr + 1] : 0;
+    const int len = b - a;
+    T g[GLA_EDOT_KC];
+    int kk[GLA_EDOT_KC];
+#pragma unroll
+    for (int i = 0; i < GLA_EDOT_KC; ++i) {
+      const bool in = i < kc && k_lo + i < K;
+      kk[i] = in ? k_lo + i : 0;                                   // out-of-slice slots read column 0, times g = 0
+      const T gv = G[rr * ldg + kk[i]];
+      g[i] = in ? gv : T(0);
+    }
+    for (int j0 = 0; __any(j0 < len); j0 += 4) {                   // wave-uniform trip count (all lanes stay active)
+      int64_t c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = col[min(a + min(j0 + u, max(len - 1, 0)), nnz - 1)];
+      T acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        T xv[GLA_EDOT_KC];
+#pragma unroll
+        for (int i = 0; i < GLA_EDOT_KC; ++i) xv[i] = X[c[u] * ldx + kk[i]];
+        T s = T(0);
+#pragma unroll
+        for (int i = 0; i < GLA_EDOT_KC; ++i) s = s + g[i] * xv[i];
+        acc[u] = s;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[u] = group_sum<KP>(acc[u]);
+        const int p = a + j0 + u;
+        if (j0 + u < len && q == 0) out[perm ? (int64_t)perm[p] : (int64_t)p] = acc[u];
+      }
+    }
+  }
+}
+
+// Vector variant (default when K, the leading dimensions and the base pointers allow 16-byte accesses): the KP lanes
+// of a row take CONSECUTIVE 16-byte vectors of the K-wide rows (lane q: vectors q, q + KP, ...), so one wave-level
+// load reads whole rows of G / X -- every fetched line is consumed by the instruction that fetched it.  Measured on
+// the 2048^2 pattern, K = 20 (profiles/r01/edge_dot_variants.txt): scalar slices spend their time in the texture
+// address path (5e8 L1 accesses), one-lane-per-row 16-byte loads thrash L1 (1.2e8 L2 read requests, 3x write
+// amplification); this mapping has neither problem.
+template <typename T, int KP, int VC, bool PERM, int U>
+__global__ __launch_bounds__(GLA_BLOCK) void edge_dot_vec_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+    const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx, int nvec, int64_t n_rows, int nnz,
+    T* __restrict__ out) {
+  constexpr int VW = 16 / sizeof(T);
+  typedef T TV __attribute__((ext_vector_type(VW)));
+  constexpr int RPP = GLA_BLOCK / KP;
+  const int q = threadIdx.x % KP, rsub = threadIdx.x / KP;
+  int vo[VC];
+  bool in[VC];
+#pragma unroll
+  for (int i = 0; i < VC; ++i) {
+    in[i] = q + i * KP < nvec;
+    vo[i] = in[i] ? q + i * KP : 0;
+  }
+  const int64_t n_round = ((n_rows + RPP - 1) / RPP) * RPP;        // whole groups stay together (uniform trip counts)
+  for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n_round; r += (int64_t)gridDim.x * RPP) {
+    const bool live = r < n_rows;
+    const int64_t rr = live ? r : n_rows - 1;                      // dead lanes redo the last row, store nothing
+    const int a = rowptr[rr], b = rowptr[rr + 1];
+    const int len = live ? b - a : 0;
+    TV g[VC];
+    const TV* gp = reinterpret_cast<const TV*>(G + rr * ldg);
+#pragma unroll
+    for (int i = 0; i < VC; ++i) {
+      const TV t = gp[vo[i]];
+      g[i] = in[i] ? t : TV(T(0));
+    }
+    for (int j0 = 0; __any(j0 < len); j0 += U) {                   // wave-uniform trip count (all lanes stay active)
+      const TV* xp[U];
+      int64_t e[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pc = min(a + min(j0 + u, max(len - 1, 0)), nnz - 1);       // clamped: every lane issues every load
+        const int64_t c = col[pc];
+        if constexpr (PERM) e[u] = (int64_t)perm[pc];
+        else e[u] = (int64_t)pc;
+        xp[u] = reinterpret_cast<const TV*>(X + c * ldx);
+      }
+      TV xv[U][VC];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < VC; ++i) xv[u][i] = xp[u][vo[i]];
+      T acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        T s_ = T(0);
+#pragma unroll
+        for (int i = 0; i < VC; ++i)
+#pragma unroll
+          for (int k = 0; k < VW; ++k) s_ = s_ + g[i][k] * xv[u][i][k];
+        acc[u] = group_sum<KP>(s_);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (j0 + u < len && q == 0) out[e[u]] = acc[u];
+    }
+  }
+}
+
+// K beyond KP * GLA_EDOT_KC columns: same lane layout, G re-read per edge (L1 hits), one edge at a time.
+template <typename T, int KP>
+__global__ __launch_bounds__(GLA_BLOCK) void edge_dot_wide_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
     const T* __restrict__ G, int64_t ldg, const T* __restrict__ X, int64_t ldx, int K, int64_t n_rows,
     T* __restrict__ out) {
   constexpr int RPP = GLA_BLOCK / KP;
   const int k0 = threadIdx.x % KP, rsub = threadIdx.x / KP;
-  const int64_t n_round = ((n_rows + RPP - 1) / RPP) * RPP;        // whole groups stay together for the shuffles
+  const int64_t n_round = ((n_rows + RPP - 1) / RPP) * RPP;
   for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n_round; r += (int64_t)gridDim.x * RPP) {
     const bool live = r < n_rows;
     const int a = live ? rowptr[r] : 0, b = live ? rowptr[r + 1] : 0;
-    int len = b - a;
-    int maxlen = len;                                              // lanes of one wave must shuffle together
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
-    for (int j = 0; j < maxlen; ++j) {
+    const int len = b - a;
+    for (int j = 0; __any(j < len); ++j) {
       const int p = a + j;
       T acc = T(0);
       if (j < len) {
         const int64_t c = col[p];
         for (int k = k0; k < K; k += KP) acc = acc + G[r * ldg + k] * X[c * ldx + k];
       }
-#pragma unroll
-      for (int o = KP >> 1; o >= 1; o >>= 1) acc = acc + __shfl_xor(acc, o);
+      acc = group_sum<KP>(acc);
       if (j < len && k0 == 0) out[perm ? (int64_t)perm[p] : (int64_t)p] = acc;
     }
   }
@@ -1203,11 +1370,58 @@ int launch_segment_stats(gla_csr* A, int K, const T* src, int64_t ld_src, T* out
 template <typename T>
 int launch_edge_dot(gla_csr* A, int K, const T* G, int64_t ldg, const T* X, int64_t ldx, T* out, hipStream_t st) {
   int kp = 1;
-  while (kp * 2 <= K && kp < 16) kp <<= 1;         // largest power of two <= min(K, 16)
+  while (kp * GLA_EDOT_KC < K && kp < 16) kp <<= 1;   // fewest lanes per row whose register slice covers K
   const unsigned grid = grid_for(A->n_rows, GLA_BLOCK / kp, 256 * 16);
+  {
+    constexpr int VW = 16 / (int)sizeof(T);
+    const int nvec = K / VW;
+    const bool vec_ok = K % VW == 0 && ldg % VW == 0 && ldx % VW == 0 && nvec <= 64 &&
+                        ((uintptr_t)G % 16) == 0 && ((uintptr_t)X % 16) == 0;
+    if (vec_ok && g_tuning.spmm_variant != 7) {      // spmm_variant 7: scalar-slice kernel (A/B)
+      int vkp = 1;
+      while (vkp < nvec && vkp < 16) vkp <<= 1;
+      const int vc = (nvec + vkp - 1) / vkp;
+      const unsigned vgrid = grid_for(A->n_rows, GLA_BLOCK / vkp, 256 * 16);
+      // edges are taken U at a time: U = 5 when the longest row (5-point, 9/10-point stencils) wastes fewer slots
+      const int L = A->max_row_len > 0 ? A->max_row_len : 1;
+      const bool u5 = ((L + 4) / 5) * 5 - L < ((L + 3) / 4) * 4 - L;
+#define GLA_EDOTV2(KP_, VC_, PERM_)                                                                              \
+  do {                                                                                                           \
+    if (u5)                                                                                                      \
+      hipLaunchKernelGGL((edge_dot_vec_kernel<T, KP_, VC_, PERM_, 5>), dim3(vgrid), dim3(GLA_BLOCK), 0, st,      \
+                         A->rowptr, A->col, A->perm, G, ldg, X, ldx, nvec, A->n_rows, (int)A->nnz, out);         \
+    else                                                                                                         \
+      hipLaunchKernelGGL((edge_dot_vec_kernel<T, KP_, VC_, PERM_, 4>), dim3(vgrid), dim3(GLA_BLOCK), 0, st,      \
+                         A->rowptr, A->col, A->perm, G, ldg, X, ldx, nvec, A->n_rows, (int)A->nnz, out);         \
+  } while (0)
+#define GLA_EDOTV(KP_, VC_)                                                                                      \
+  do {                                                                                                           \
+    if (A->perm) GLA_EDOTV2(KP_, VC_, true);                                                                     \
+    else GLA_EDOTV2(KP_, VC_, false);                                                                            \
+  } while (0)
+      if (vkp == 1) GLA_EDOTV(1, 1);
+      else if (vkp == 2) GLA_EDOTV(2, 1);
+      else if (vkp == 4) GLA_EDOTV(4, 1);
+      else if (vkp == 8) GLA_EDOTV(8, 1);
+      else if (vc == 1) GLA_EDOTV(16, 1);
+      else if (vc == 2) GLA_EDOTV(16, 2);
+      else if (vc == 3) GLA_EDOTV(16, 3);
+      else GLA_EDOTV(16, 4);
+#undef GLA_EDOTV
+#undef GLA_EDOTV2
+      GLA_LAUNCH_CHECK();
+      return GLA_OK;
+    }
+  }
+  if ((int64_t)kp * GLA_EDOT_KC < K) {
+    hipLaunchKernelGGL((edge_dot_wide_kernel<T, 16>), dim3(grid), dim3(GLA_BLOCK), 0, st, A->rowptr, A->col, A->perm,
+                       G, ldg, X, ldx, K, A->n_rows, out);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  }
 #define GLA_EDOT(KP_)                                                                                           \
   hipLaunchKernelGGL((edge_dot_kernel<T, KP_>), dim3(grid), dim3(GLA_BLOCK), 0, st, A->rowptr, A->col, A->perm, \
-                     G, ldg, X, ldx, K, A->n_rows, out)
+                     G, ldg, X, ldx, K, A->n_rows, (int)A->nnz, out)
   switch (kp) {
     case 1: GLA_EDOT(1); break;
     case 2: GLA_EDOT(2); break;

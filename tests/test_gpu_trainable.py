@@ -139,7 +139,7 @@ def test_segment_stats_vs_oracle(dtype, sort):
     assert torch.equal(got, four)
 
 
-@pytest.mark.parametrize("K", [1, 3, 20])
+@pytest.mark.parametrize("K", [1, 3, 20, 40, 130])
 @pytest.mark.parametrize("sort", [True, False])
 def test_sparse_mm_autograd_vs_oracle(K, sort):
     """Forward and both gradients of Y = A X against torch's CPU sparse autograd, rectangular A, fp64."""
