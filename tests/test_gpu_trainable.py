@@ -139,7 +139,7 @@ def test_segment_stats_vs_oracle(dtype, sort):
     assert torch.equal(got, four)
 
 
-@pytest.mark.parametrize("K", [1, 3, 20, 40, 130])
+@pytest.mark.parametrize("K", [1, 3, 4, 8, 20, 40, 130])
 @pytest.mark.parametrize("sort", [True, False])
 def test_sparse_mm_autograd_vs_oracle(K, sort):
     """Forward and both gradients of Y = A X against torch's CPU sparse autograd, rectangular A, fp64."""
@@ -161,6 +161,18 @@ def test_sparse_mm_autograd_vs_oracle(K, sort):
     dots = gla.plan_for(ei.to(DEV), n, m).edge_dot(W.to(DEV), X.to(DEV))
     want = (W[ei[0]] * X[ei[1]]).sum(1)
     np.testing.assert_allclose(dots.cpu().numpy(), want.numpy(), rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("K", [4, 8, 12, 20, 64, 68])
+def test_edge_dot_fp32_lane_groups(K):
+    """fp32 takes other lane-group widths (4 values per 16-byte vector) than fp64: every width against an fp64 result."""
+    n, m = 2500, 1900
+    ei, gen = random_graph(n, m, 6, 40 + K, sort=True)
+    G = torch.randn(n, K, generator=gen, dtype=torch.float64)
+    X = torch.randn(m, K, generator=gen, dtype=torch.float64)
+    want = (G[ei[0]] * X[ei[1]]).sum(1)
+    got = gla.plan_for(ei.to(DEV), n, m).edge_dot(G.float().to(DEV), X.float().to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-5 * K ** 0.5)
 
 
 def test_damping_factor_vs_oracle_fp64():
