@@ -11,18 +11,26 @@ import torch
 from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, split_cols, stack_cols, to_dev
 
 
-def chebyshev_relax(plan, b, x0, g, deg):
-    """Core of ChebyRelaxGNN on SoA operands: b, x0 [n, K] contiguous, g = [c, d] (any device).  Runs `deg` fused
-    steps on `plan` and returns (x, r, p, gathered, g_out) where `gathered` is the vector the last SpMV read
-    (x0 for deg 1, the previous p otherwise -- the z_ij = A_ij * gathered_j of the returned edge attributes)."""
+def chebyshev_relax(plan, b, x0, g, deg, out=None):
+    """Core of ChebyRelaxGNN on SoA operands: b, x0 [n, K] (row-major, any leading dimension), g = [c, d] (any
+    device).  Runs `deg` fused steps on `plan` and returns (x, r, p, gathered, g_out) where `gathered` is the vector
+    the last SpMV read (x0 for deg 1, the previous p otherwise -- the z_ij = A_ij * gathered_j of the returned edge
+    attributes).  out = (x, r, p): caller-owned destinations (e.g. column views of the AoS result) the final
+    iterates are written into directly."""
     gh = g.detach().to("cpu")
     c, d = gh[0], gh[1]
     alpha = 1 / d                                                    # ChebyGNN.py:137
     beta = None
-    r, p, x = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
+    if out is None:
+        r, p, x = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
+        p_next = torch.empty_like(p) if deg > 1 else None
+    else:
+        x, r, p_final = out
+        scratch = torch.empty((b.shape[0], b.shape[1]), dtype=b.dtype, device=b.device) if deg > 1 else None
+        # p ping-pongs deg - 1 times: start so that the last one lands in the caller's buffer
+        p, p_next = (p_final, scratch) if (deg - 1) % 2 == 0 else (scratch, p_final)
     plan.cheby_first(b, x0, r, p, x, float(alpha))
     gathered = x0
-    p_next = torch.empty_like(p) if deg > 1 else None
     for it in range(2, deg + 1):
         beta = 0.5 * (c * alpha) ** 2 if it == 2 else ((c * alpha) / 2) ** 2      # :262 / :282
         alpha_new = 1 / (d - beta / alpha)                                          # :263 / :283
@@ -50,10 +58,19 @@ class ChebyRelaxGNN(torch.nn.Module):
         if va.shape[1] != 2:
             raise ValueError("vertex_attr must be [n, 2] = [b, x]")
         plan = plan_for(ei, va.shape[0], edge_attr=ea)
-        b, x0 = split_cols(va) if va.dim() == 2 else (cols(va, 0), cols(va, 1))
-        x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg)
+        if va.dim() == 3 and va.shape[2] > 1 and va.is_contiguous():
+            # multi-RHS: the kernels take leading dimensions, so b / x0 are read in place from the AoS input and
+            # x, r, p are written straight into the AoS result (no split / stack passes over the K-wide vectors)
+            res = torch.empty((va.shape[0], 4, va.shape[2]), dtype=va.dtype, device=va.device)
+            res[:, 0, :] = va[:, 0, :]
+            _, _, _, gathered, g_out = chebyshev_relax(plan, va[:, 0, :], va[:, 1, :], g, self.deg,
+                                                       out=(res[:, 1, :], res[:, 2, :], res[:, 3, :]))
+        else:
+            b, x0 = split_cols(va) if va.dim() == 2 else (cols(va, 0), cols(va, 1))
+            x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg)
+            res = stack_cols([b, x, r, p], va)
         ea_out = edge_cols(ea, plan.edge_products(gathered)) if self.return_edge_attr else None
-        return back(stack_cols([b, x, r, p], va), vertex_attr), back(ea_out, edge_attr), g_out
+        return back(res, vertex_attr), back(ea_out, edge_attr), g_out
 
 
 # ---- the reference's per-layer update modules (ChebyGNN.py:49-285), usable in a MetaLayer like the originals --------

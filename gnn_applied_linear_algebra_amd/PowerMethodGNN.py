@@ -30,7 +30,10 @@ class PowerMethodGNN(torch.nn.Module):
         if va.shape[1] != 2:
             raise ValueError("vertex_attr must be [n, 2] = [b, y]")
         plan = plan_for(ei, va.shape[0], edge_attr=ea)
-        b = cols(va, 0)
+        # multi-RHS: b is read in place from the AoS input and [b, b^2] written straight into the AoS result
+        in_place = va.dim() == 3 and va.shape[2] > 1 and va.is_contiguous()
+        b = va[:, 0, :] if in_place else cols(va, 0)
+        res = torch.empty_like(va) if in_place else None
         K = b.shape[1]
         out_dtype = torch.result_type(va, g)
         gd = to_dev(g, dev).to(out_dtype).reshape(3, -1)
@@ -47,15 +50,23 @@ class PowerMethodGNN(torch.nn.Module):
                 for it in range(self.num_iter):                  # unfused path, same arithmetic
                     y = plan.spmm(y if it == 0 else col_scale_rsqrt(y, ss))
                     ss = col_dot(y, y)
-            b = col_scale_rsqrt(y, ss)                           # Layer 3 of the last iteration: b <- b / n
+            # Layer 3 of the last iteration: b <- b / n
+            b = col_scale_rsqrt(y, ss, out=res[:, 0, :] if in_place else None)
             nrm = torch.sqrt(ss).to(out_dtype)
+        elif in_place:
+            res[:, 0, :] = b
+            b = res[:, 0, :]
         Ab = plan.spmm(b)                             # Rayleigh layer 1: y = b * (A b); n_A = sum y  (:209-266)
         n_A = col_dot(b, Ab).to(out_dtype)
         lam = n_A / col_dot(b, b).to(out_dtype)       # Rayleigh layer 2: lambda = n_A / sum b^2      (:268-294)
         g_out = torch.stack([nrm, n_A, lam], 0)
         g_out = g_out.reshape(3) if g.dim() == 1 else g_out
         ea_out = edge_cols(ea, plan.edge_products(b)) if self.return_edge_attr else None
-        return (back(stack_cols([b, b * b], va), vertex_attr), back(ea_out, edge_attr), back(g_out, g))
+        if in_place:
+            torch.mul(b, b, out=res[:, 1, :])
+        else:
+            res = stack_cols([b, b * b], va)
+        return (back(res, vertex_attr), back(ea_out, edge_attr), back(g_out, g))
 
 
 # ---- the reference's per-layer update modules (PowerMethodGNN.py:50-294) -------------------------------------------

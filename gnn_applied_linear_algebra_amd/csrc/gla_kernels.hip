@@ -293,8 +293,8 @@ __device__ __forceinline__ T wave_sum(T v) {
 // nnz window is aligned down to an even index (the extra element is staged but never summed).
 // PF: the row lane's rowptr / dense operands are requested before the nnz stream so that the block runs through
 // three dependent memory round trips (tile record -> streams -> x gather) instead of five.
-template <typename T, class Epi, int PPT, bool NT, bool PF, bool COL16 = false>
-__global__ __launch_bounds__(GLA_BLOCK) void spmv_stream_vec2_kernel(
+template <typename T, class Epi, int PPT, bool NT, bool PF, bool COL16 = false, int MINW = 1>
+__global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
     const T* __restrict__ x, TileMap tm, Epi epi, const int16_t* __restrict__ col16 = nullptr,
     const uint32_t* __restrict__ wide_mask = nullptr, unsigned n_cols = 0) {
@@ -716,9 +716,14 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
 #define GLA_SPMV2(N_, NT_, PF_) \
   hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
                      X, tm, epi)
-    if (A->col16_state == 1 && g_tuning.col16 && g_tuning.spmv_variant == 0) {
-      hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, true>), grid, block, lds, st, A->rowptr,
-                         A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols);
+    if (A->col16_state == 1 && g_tuning.col16 && (g_tuning.spmv_variant == 0 || g_tuning.spmv_variant == 5)) {
+      // MINW = 6 caps the kernel at 80 VGPRs (it takes 83 unconstrained): 7 instead of 5 waves per SIMD, +1.5 %
+      if (g_tuning.spmv_variant == 5)
+        hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, true, 1>), grid, block, lds, st, A->rowptr,
+                           A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols);
+      else
+        hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, true, 6>), grid, block, lds, st, A->rowptr,
+                           A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols);
       GLA_LAUNCH_CHECK();
       return GLA_OK;
     }
@@ -727,7 +732,10 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
       case 2: GLA_SPMV2(2, false, true); break;
       case 3: GLA_SPMV2(4, false, true); break;
       case 4: GLA_SPMV2(3, true, true); break;
-      default: GLA_SPMV2(3, false, true); break;
+      default:
+        hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, false, 6>), grid, block, lds, st,
+                           A->rowptr, A->col, val, X, tm, epi);
+        break;
     }
 #undef GLA_SPMV2
   } else {

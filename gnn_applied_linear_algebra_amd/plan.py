@@ -357,14 +357,16 @@ def col_dot(X, Y):
     return out
 
 
-def col_scale_rsqrt(X, sumsq):
-    """X[:, k] / sqrt(sumsq[k]) (PowerMethodGNN.py:160-207)."""
+def col_scale_rsqrt(X, sumsq, out=None):
+    """X[:, k] / sqrt(sumsq[k]) (PowerMethodGNN.py:160-207); `out`: row-major [n, K] destination (may be strided)."""
     n = X.shape[0]
     X, K, ldx = _dense(X, n, "X")
     assert sumsq.numel() == K and sumsq.dtype == X.dtype and sumsq.is_cuda
-    Y = torch.empty((n, K), dtype=X.dtype, device=X.device)
+    Y = torch.empty((n, K), dtype=X.dtype, device=X.device) if out is None else out
+    Y2, Ky, ldy = _dense(Y, n, "out")
+    assert Ky == K and Y2.dtype == X.dtype
     with _DeviceGuard(X.device):
-        check(lib().gla_col_scale_rsqrt(dtype_code(X.dtype), n, K, ptr(X), ldx, ptr(sumsq), ptr(Y), K,
+        check(lib().gla_col_scale_rsqrt(dtype_code(X.dtype), n, K, ptr(X), ldx, ptr(sumsq), ptr(Y2), ldy,
                                         stream_ptr(X.device)))
     return Y
 
