@@ -8,7 +8,7 @@ operation order, so alpha/beta are bit-identical.
 """
 import torch
 
-from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, split_cols, stack_cols, to_dev
+from ._common import aggregate, back, cols, compute_device, float_dtype, plan_for, split_cols, stack_cols, to_dev
 
 
 def chebyshev_relax(plan, b, x0, g, deg, out=None):
@@ -69,7 +69,7 @@ class ChebyRelaxGNN(torch.nn.Module):
             b, x0 = split_cols(va) if va.dim() == 2 else (cols(va, 0), cols(va, 1))
             x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg)
             res = stack_cols([b, x, r, p], va)
-        ea_out = edge_cols(ea, plan.edge_products(gathered)) if self.return_edge_attr else None
+        ea_out = plan.edge_attr(gathered) if self.return_edge_attr else None    # [A_ij, z_ij] in one pass
         return back(res, vertex_attr), back(ea_out, edge_attr), g_out
 
 

@@ -58,8 +58,7 @@ def _fused_layer(layer, x, edgeij_pair, edge_attr, u, batch):
     plan = plan_for(ei, va.shape[0], edge_attr=ea)
     b, xx = cols(va, 0), cols(va, 1)
     r = plan.residual(b, xx)
-    c = plan.edge_products(xx)
-    return back(torch.cat([b, xx, r], 1), x), back(torch.cat([ea[:, 0:1], c], 1), edge_attr), u
+    return back(torch.cat([b, xx, r], 1), x), back(plan.edge_attr(xx), edge_attr), u
 
 
 meta.register_fused("residual.edge", "residual.vertex", None, _fused_layer)

@@ -8,7 +8,7 @@ write of x; the [A_ij, c_ij] edge tensor the reference re-materialises every swe
 import torch
 
 from . import meta
-from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, split_cols, stack_cols, to_dev
+from ._common import aggregate, back, cols, compute_device, float_dtype, plan_for, split_cols, stack_cols, to_dev
 
 
 def edge_to_vertex_aggregation(edgeij_pair, edge_attr, n_vertices):
@@ -56,9 +56,9 @@ def _prep(vertex_attr, edgeij_pair, edge_attr, g):
 def _iterate(vertex_attr, edgeij_pair, edge_attr, g):
     """One fused sweep; returns (vertex_attr [n,3], edge_attr [nnz,2] = [A_ij, A_ij*x_j(old)], g)."""
     plan, va, ea, diag, b, x, w = _prep(vertex_attr, edgeij_pair, edge_attr, g)
-    c = plan.edge_products(x)
+    ea_out = plan.edge_attr(x)                         # [A_ij, A_ij * x_j(old)] in one pass
     x_new = plan.jacobi_sweeps(diag, b, x, w, 1)
-    return (back(stack_cols([cols(va, 0), b, x_new], va), vertex_attr), back(edge_cols(ea, c), edge_attr), g)
+    return (back(stack_cols([cols(va, 0), b, x_new], va), vertex_attr), back(ea_out, edge_attr), g)
 
 
 class JacobiGNN(torch.nn.Module):

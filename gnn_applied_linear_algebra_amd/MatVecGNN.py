@@ -50,8 +50,7 @@ def _fused_matvec(layer, x, edgeij_pair, edge_attr, u, batch):
     plan = plan_for(ei, xd.shape[0], edge_attr=ea)
     X = xd.contiguous()
     y = plan.spmm(X)
-    c = plan.edge_products(X)
-    return back(torch.cat([xd, y], 1), x), back(torch.cat([ea, c], 1), edge_attr), u
+    return back(torch.cat([xd, y], 1), x), back(plan.edge_attr(X), edge_attr), u
 
 
 def _dispatch(layer, x, ei, ea, u, batch):

@@ -56,10 +56,9 @@ def _fused(layer, x, edgeij_pair, edge_attr, u, batch):
     plan = plan_for(ei, xd.shape[0], edge_attr=ea)
     X = xd.contiguous()
     Wx = plan.spmm(X)                                # (W x)_i
-    c = plan.edge_products(X)
     y = X * Wx
     gn = torch.sqrt(col_dot(X, Wx)[0])               # sqrt(sum_i x_i (W x)_i)
-    return back(torch.cat([xd, y], 1), x), back(torch.cat([ea, c], 1), edge_attr), back(gn, x)
+    return back(torch.cat([xd, y], 1), x), back(plan.edge_attr(X), edge_attr), back(gn, x)
 
 
 meta.register_fused("wnorm.edge", "wnorm.vertex", "wnorm.global", _fused)

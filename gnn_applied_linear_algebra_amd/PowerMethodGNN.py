@@ -10,7 +10,7 @@ block is an SpMV plus two reductions.
 import torch
 
 from . import _lib
-from ._common import aggregate, back, cols, compute_device, edge_cols, float_dtype, plan_for, stack_cols, to_dev
+from ._common import aggregate, back, cols, compute_device, float_dtype, plan_for, stack_cols, to_dev
 from .plan import col_dot, col_scale_rsqrt
 
 
@@ -61,7 +61,7 @@ class PowerMethodGNN(torch.nn.Module):
         lam = n_A / col_dot(b, b).to(out_dtype)       # Rayleigh layer 2: lambda = n_A / sum b^2      (:268-294)
         g_out = torch.stack([nrm, n_A, lam], 0)
         g_out = g_out.reshape(3) if g.dim() == 1 else g_out
-        ea_out = edge_cols(ea, plan.edge_products(b)) if self.return_edge_attr else None
+        ea_out = plan.edge_attr(b) if self.return_edge_attr else None           # [A_ij, A_ij * b_j] in one pass
         if in_place:
             torch.mul(b, b, out=res[:, 1, :])
         else:

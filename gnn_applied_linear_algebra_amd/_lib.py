@@ -60,6 +60,7 @@ SIGNATURES = {
     "gla_edge_dot": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _P]),
     "gla_split_columns": (_I, [_I, _I64, _I, _P, _I64, ctypes.POINTER(_P), _P]),
     "gla_edge_products": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P]),
+    "gla_edge_attr": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P]),
     "gla_soc_classic": (_I, [_P, _I, _D, _P, _P, _P]),
     "gla_direct_interp": (_I, [_P, _I, _P, _P, _P, _P, _P, _P]),
     "gla_soc_sa": (_I, [_P, _I, _P, _P, _P]),

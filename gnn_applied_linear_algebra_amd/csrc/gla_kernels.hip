@@ -1301,6 +1301,38 @@ int launch_col_dot(int64_t n, int K, const T* x, int64_t ldx, const T* y, int64_
   return GLA_OK;
 }
 
+// The returned edge attributes of every EdgeUpdate in one pass: out[e, :] = [A_e, A_e * X[col_e, 0..K)] -- the
+// reference's torch.cat([A_ij, c_ij], 1) (e.g. JacobiGNN.py:88-89) written as whole rows of 1 + K values instead of a
+// product pass plus a concatenation pass.  KC1 = 1 + K at compile time (0: runtime).
+template <typename T, int KC1>
+__global__ __launch_bounds__(GLA_BLOCK) void edge_attr_kernel(
+    const int32_t* __restrict__ col, const T* __restrict__ val, const int32_t* __restrict__ perm,
+    const T* __restrict__ X, int64_t ldx, T* __restrict__ out, int64_t ldo, int64_t nnz, int K1rt) {
+  const int K1 = KC1 > 0 ? KC1 : K1rt;
+  const int64_t total = nnz * K1;
+  for (int64_t base = (int64_t)blockIdx.x * (GLA_BLOCK * 4) + threadIdx.x; base < total;
+       base += (int64_t)gridDim.x * (GLA_BLOCK * 4)) {
+    int64_t e[4];
+    int j[4];
+    T v[4];
+    int c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t idx = min(base + (int64_t)u * GLA_BLOCK, total - 1);
+      const int64_t p = idx / K1;
+      j[u] = (int)(idx - p * K1);
+      e[u] = perm ? (int64_t)perm[p] : p;
+      v[u] = val[p];
+      c[u] = col[p];
+    }
+    T xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = X[(int64_t)c[u] * ldx + max(j[u] - 1, 0)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[e[u] * ldo + j[u]] = j[u] == 0 ? v[u] : v[u] * xv[u];
+  }
+}
+
 #define GLA_K_SWITCH(K, ...)                      \
   switch (K) {                                    \
     case 1: { constexpr int KC = 1; __VA_ARGS__; } break;   \
@@ -1311,6 +1343,15 @@ int launch_col_dot(int64_t n, int K, const T* x, int64_t ldx, const T* y, int64_
     case 32: { constexpr int KC = 32; __VA_ARGS__; } break; \
     default: { constexpr int KC = 0; __VA_ARGS__; } break;  \
   }
+
+template <typename T>
+int launch_edge_attr(gla_csr* A, int K, const T* X, int64_t ldx, T* out, int64_t ldo, hipStream_t st) {
+  const dim3 grid(grid_for(A->nnz * (K + 1), GLA_BLOCK * 4, 256 * 16));
+  GLA_K_SWITCH(K, hipLaunchKernelGGL((edge_attr_kernel<T, (KC > 0 ? KC + 1 : 0)>), grid, dim3(GLA_BLOCK), 0, st,
+                                     A->col, (const T*)A->val, A->perm, X, ldx, out, ldo, A->nnz, K + 1))
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
 
 template <typename T>
 int launch_edge_products(gla_csr* A, int K, const T* X, int64_t ldx, T* C, int64_t ldc, hipStream_t st) {
@@ -1657,6 +1698,17 @@ int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx,
   if (A->nnz == 0) return GLA_OK;
   GLA_DISPATCH(dtype, {
     return launch_edge_products<T>(A, K, (const T*)X, ldx, (T*)C, ldc, (hipStream_t)stream);
+  })
+}
+
+int gla_edge_attr(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* out, int64_t ldo,
+                  gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0 || A->nnz == 0) return GLA_OK;
+  if (!X || !out || ldx < K || ldo < K + 1) return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    return launch_edge_attr<T>(A, K, (const T*)X, ldx, (T*)out, ldo, (hipStream_t)stream);
   })
 }
 

@@ -310,6 +310,16 @@ class CsrPlan:
         return C
 
     @_on_device
+    def edge_attr(self, X):
+        """[A_e, A_e * X[col_e]] in EDGE order, [nnz, 1 + K]: the edge attributes an EdgeUpdate returns, one pass."""
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        self._need(X.dtype)
+        out = torch.empty((self.nnz, 1 + K), dtype=X.dtype, device=self.device)
+        check(lib().gla_edge_attr(self._h, dtype_code(X.dtype), K, ptr(X), ldx, ptr(out), 1 + K,
+                                  stream_ptr(self.device)))
+        return out
+
+    @_on_device
     def soc_classic(self, theta, dtype):
         self._need(dtype)
         v = torch.empty((self.n_rows, 1), dtype=dtype, device=self.device)

@@ -187,6 +187,12 @@ int gla_split_columns(int dtype, int64_t n, int a, const void* src, int64_t ld, 
 int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,
                       gla_stream_t stream);
 
+/* The edge attributes every EdgeUpdate returns, in one pass: out[e, 0] = A_e, out[e, 1 + k] = A_e * X[col(e), k],
+ * EDGE order, [nnz, 1 + K] with leading dimension ldo >= 1 + K.  The reference's
+ * `torch.cat([A_ij, c_ij], 1)` (MatVecGNN.py:83-84, JacobiGNN.py:88-89, ChebyGNN.py:69-70, PowerMethodGNN.py:105-106). */
+int gla_edge_attr(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* out, int64_t ldo,
+                  gla_stream_t stream);
+
 /* Classical strength of connection on the OFF-DIAGONAL plan: v_i = max_j(-A_ij) (0 for empty rows),
  * S_e = relu(-A_e / v_row(e) - theta), S in edge order.  SOCClassicGNN.py:50-147. */
 int gla_soc_classic(gla_csr_t A_od, int dtype, double theta, void* v_out, void* S_out, gla_stream_t stream);
