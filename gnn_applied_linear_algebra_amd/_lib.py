@@ -58,6 +58,8 @@ SIGNATURES = {
     "gla_segment_reduce": (_I, [_P, _I, _I, _P, _I64, _I, _P, _I64, _P]),
     "gla_segment_stats": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P]),
     "gla_edge_dot": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _P]),
+    "gla_mlp_work_bytes": (_I64, [_I]),
+    "gla_mlp_relu3": (_I, [_I, _I64, _I, _I, _I, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gla_split_columns": (_I, [_I, _I64, _I, _P, _I64, ctypes.POINTER(_P), _P]),
     "gla_edge_products": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P]),
     "gla_edge_attr": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P]),

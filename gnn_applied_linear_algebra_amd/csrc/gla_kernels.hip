@@ -199,14 +199,17 @@ struct EpiChebyNext {                   // r -= a_old*(A p); p = r + beta p; x +
 // Fused power-method step (PowerMethodGNN.py:86-207, three MetaLayers): the gathered operand is normalised on
 // the fly (b_j = y_j / n, rounded like the reference's Layer 3), y_i = sum_j A_ij b_j is stored, and the workgroup
 // leaves sum_i y_i^2 of its tile in partials[tile * K + k] for the deterministic second-stage reduction.
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T>
 __device__ __forceinline__ T div_by(T a, T b, T rb) {
   // a / b from the correctly rounded reciprocal rb = RN(1/b) with one Markstein correction step: q = RN(a*rb),
   // r = a - q*b (exact in an FMA), q' = RN(q + r*rb) -- the correctly rounded quotient except for rare
   // last-place cases, at 3 instructions instead of the ~30 of an IEEE fp64 division per gathered value.
   const T q = a * rb;
-  const T r = __builtin_fma(-q, b, a);
-  return __builtin_fma(r, rb, q);
+  const T r = fma_t(-q, b, a);
+  return fma_t(r, rb, q);
 }
 
 template <typename T>

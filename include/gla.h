@@ -176,6 +176,17 @@ int gla_segment_stats(gla_csr_t A, int dtype, int K, const void* src, int64_t ld
 int gla_edge_dot(gla_csr_t A, int dtype, int K, const void* G, int64_t ldg, const void* X, int64_t ldx,
                  void* out_edge, gla_stream_t stream);
 
+/* Inference of the learned-Jacobi vertex model: out[i] = W3 relu(W2 relu(W1 x_i + b1) + b2) + b3, x_i = X[i, 0:in_dim]
+ * (row-major, leading dimension ldx), weights in torch.nn.Linear layout (W1 [h1, in_dim], W2 [h2, h1], W3 [1, h2]).
+ * TrainableJacobiDiag/TrainableJacobiGNN.py:86-91,110-111 (Sequential(Linear(5,50), ReLU, Linear(50,20), ReLU,
+ * Linear(20,1)) applied to every vertex).  Limits: in_dim <= 8, h1 <= 512, h2 <= 32.  `work`: device scratch of
+ * gla_mlp_work_bytes(h1) bytes (the packed weights).  Sums use fused multiply-adds in index order (torch's GEMM
+ * order is unspecified): agrees with the reference to fp rounding, not bit for bit. */
+int64_t gla_mlp_work_bytes(int h1);
+int gla_mlp_relu3(int dtype, int64_t n, int in_dim, int h1, int h2, const void* X, int64_t ldx, const void* W1,
+                  const void* b1, const void* W2, const void* b2, const void* W3, const void* b3, void* out,
+                  void* work, gla_stream_t stream);
+
 /* Split a row-major attribute tensor src [n, a] (a <= 8, leading dimension ld) into `a` contiguous vectors
  * cols_host[c][i] = src[i*ld + c] in one pass (cols_host: HOST array of a device pointers).  The reference keeps
  * vertex attributes as AoS [A_ii, b, x] / [b, x] / ... (JacobiGNN.py:104-106); the kernels read SoA. */

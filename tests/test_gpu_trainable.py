@@ -112,6 +112,40 @@ def test_golden_training_step(tg, name):
         np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=5e-3, atol=2e-5 * max(np.abs(want).max(), 1e-30))
 
 
+@pytest.mark.parametrize("dtype,rtol", [(torch.float32, 2e-5), (torch.float64, 1e-13)])
+def test_fused_inference_matches_torch_mlp(dtype, rtol):
+    """gla_mlp_relu3 (no_grad path of VertexUpdate) against the torch Sequential it replaces, and against golden."""
+    torch.manual_seed(11)
+    gnn = TJ.get_model().to(DEV).to(dtype)
+    n = 70001
+    gen = torch.Generator().manual_seed(12)
+    x = (torch.randn(n, 5, generator=gen, dtype=torch.float64) * 3).to(dtype).to(DEV)
+    want = gnn.node_model.vertex_update(x)
+    with torch.no_grad():
+        got = TJ._fused_inference(gnn.node_model.vertex_update, x)
+    assert got is not None and got.shape == (n, 1)
+    np.testing.assert_allclose(got.cpu().numpy(), want.detach().cpu().numpy(), rtol=rtol, atol=0)
+    # other widths, incl. the limits, and negative weights so that the ReLUs bite
+    for dims in ((1, 1, 1), (8, 512, 32), (3, 17, 5)):
+        seq = torch.nn.Sequential(torch.nn.Linear(dims[0], dims[1]), torch.nn.ReLU(), torch.nn.Linear(dims[1], dims[2]),
+                                  torch.nn.ReLU(), torch.nn.Linear(dims[2], 1)).to(DEV).to(dtype)
+        xs = torch.randn(1000, dims[0], generator=gen, dtype=torch.float64).to(dtype).to(DEV)
+        with torch.no_grad():
+            got = TJ._fused_inference(seq, xs)
+            want = seq(xs)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=50 * rtol, atol=50 * rtol)
+    assert TJ._fused_inference(torch.nn.Sequential(torch.nn.Linear(5, 1)), x) is None      # other shapes: torch path
+
+
+def test_model_no_grad_uses_fused_kernel_and_matches_golden(tg):
+    for name in CASES:
+        va, ei, ea, params = load_case(tg, name)
+        gnn = model_with(params)
+        with torch.no_grad():
+            out, _, _ = gnn(va.to(DEV), ei.to(DEV), ea.to(DEV), batch=None)
+        np.testing.assert_allclose(out.cpu().numpy(), tg[f"{name}_model_out"], rtol=1e-5, atol=0)
+
+
 def random_graph(n, n_cols, deg, seed, sort=True):
     gen = torch.Generator().manual_seed(seed)
     rows = torch.randint(0, n, (n * deg,), generator=gen)

@@ -58,8 +58,9 @@ for dtype, w in ((torch.float32, 4), (torch.float64, 8)):
            w * eio.shape[1] + 4 * (n + 1) + 4 * w * n)
     model = TJ.get_model().to(dev).to(dtype)
     va = (4.0 * s * s).to(dtype).reshape(-1, 1)
+    report("model forward, autograd on (stats + torch MLP)", timeit(lambda: model(va, eio, evo, batch=None)))
     with torch.no_grad():
-        report("model inference (stats + 5-50-20-1 MLP)", timeit(lambda: model(va, eio, evo, batch=None)))
+        report("model inference, no_grad (stats + gla_mlp_relu3)", timeit(lambda: model(va, eio, evo, batch=None)))
 
     # kernels of the loss
     T = L.build_error_matrix(A, diag.detach(), 2. / 3.)
