@@ -923,7 +923,13 @@ def test_random_graphs_property():
             eq(plan.spmm(d(X)), want)
             eq(plan.residual(d(B), d(X)), B - want)
             eq(plan.edge_products(d(X)), vals * X[col])
+            eq(plan.edge_attr(d(X)), torch.cat([vals, vals * X[col]], 1))
             eq(plan.segment_reduce(d(vals * X[col])), want)
+            eq(plan.segment_stats(d(vals * X[col])), rp.trainable_edge_stats(ei, vals * X[col], n_rows))
+            dots = plan.edge_dot(d(B), d(X)).cpu()                    # tree-ordered sums over k: tolerance
+            ref = (B[row].double() * X[col].double()).sum(1)
+            np.testing.assert_allclose(dots.double().numpy(), ref.numpy(), rtol=0,
+                                       atol=(2e-6 if f32 else 1e-15) * K)
         finally:
             chk(lib().gla_set_option(b"compress", 0))
 

@@ -146,6 +146,37 @@ def test_model_no_grad_uses_fused_kernel_and_matches_golden(tg):
         np.testing.assert_allclose(out.cpu().numpy(), tg[f"{name}_model_out"], rtol=1e-5, atol=0)
 
 
+def test_golden_training_run(tg):
+    """Four Adam steps of the reference's training loop (train.py:98-108) on a two-graph batch: the loss trajectory
+    and the trained model's output follow the reference (fp32; steps amplify rounding differences: 1e-3 / 1e-2)."""
+    xs, eis, eas, bvec, mats = [], [], [], [], []
+    off = 0
+    for gi, name in enumerate(("var8", "lap8")):
+        va, ei, ea, params = load_case(tg, name)
+        xs.append(va); eis.append(ei + off); eas.append(ea)
+        bvec.append(torch.full((va.shape[0],), gi, dtype=torch.long))
+        mats.append(T(tg[f"{name}_A"]).to_sparse().coalesce())              # torch sparse tensors, as Data.py holds
+        off += va.shape[0]
+    batch = types.SimpleNamespace(x=torch.cat(xs).to(DEV), edgeij_pair=torch.cat(eis, 1).to(DEV),
+                                  edge_attr=torch.cat(eas).to(DEV), batch=torch.cat(bvec).to(DEV), num_graphs=2,
+                                  matrix=mats, coords=[None, None])
+    gnn = model_with(params)                                               # the seeded initial weights (same for all)
+    opt = torch.optim.Adam(gnn.parameters(), lr=1e-2)
+    losses = []
+    for step in range(4):
+        opt.zero_grad()
+        torch.manual_seed(500 + step)
+        loss = L.loss_batch(gnn, batch)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, tg["train_losses"], rtol=1e-3)
+    assert losses[-1] < 0.5 * losses[0]
+    with torch.no_grad():
+        out = gnn(batch.x, batch.edgeij_pair, batch.edge_attr, [], batch.batch)[0]
+    np.testing.assert_allclose(out.cpu().numpy(), tg["train_final_out"], rtol=1e-2)
+
+
 def random_graph(n, n_cols, deg, seed, sort=True):
     gen = torch.Generator().manual_seed(seed)
     rows = torch.randint(0, n, (n * deg,), generator=gen)
