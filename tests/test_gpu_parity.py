@@ -891,6 +891,22 @@ def test_unfused_l3_modules_golden(golden, N):
     eq(ea[:, 2], golden[f"N{N}_di_rnd_w"])
 
 
+def test_vcycle_hip_graph_capture_bit_identical():
+    """AMGHierarchy.capture_cycle: one V-cycle replayed as a HIP graph equals the eager cycle bit for bit."""
+    m = 63
+    ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 2.0], device=DEV)
+    n = m * m
+    H = gla.VCycle.AMGHierarchy(gla.VCycle._as_sparse(ei, ev, (n, n)), levels=4, splitting=gla.VCycle.GridSplitting(m, m),
+                                min_coarse=10, coarse_solver="cheby")
+    run = H.capture_cycle()
+    b = torch.rand(n, 1, generator=torch.Generator().manual_seed(4), dtype=torch.float64).to(DEV)
+    xg = xe = torch.zeros_like(b)
+    for _ in range(3):
+        xg, xe = run(b, xg), H.cycle(b, xe)
+        assert torch.equal(xg, xe)
+    assert float(torch.norm(H.residual(b, xe))) < float(torch.norm(b))
+
+
 # ---------------------------------------------------------------------------------------------------
 # property test: random COO graphs (ragged, unsorted, duplicates, empty rows, rectangular) vs the oracle
 # ---------------------------------------------------------------------------------------------------

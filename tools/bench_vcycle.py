@@ -16,7 +16,7 @@ splitting = sys.argv[3] if len(sys.argv) > 3 else None
 sign = int(os.environ.get("GLA_SIGN", "1"))   # +1: SPD stiffness matrix (classical AMG convention); -1: the reference's negative convention
 coarse_sweeps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 coarse_deg = int(sys.argv[5]) if len(sys.argv) > 5 else None
-coarse_solver = sys.argv[6] if len(sys.argv) > 6 else 'cheby'
+coarse_solver = sys.argv[6] if len(sys.argv) > 6 and not sys.argv[6].startswith('--') else 'cheby'
 dev = torch.device("cuda:0")
 t0 = time.perf_counter()
 ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 1.0], device=dev)
@@ -46,5 +46,19 @@ for _ in range(ncyc):
 torch.cuda.synchronize()
 t4 = time.perf_counter()
 r = float(torch.norm(H.residual(b, x)))
+if "--graph" in sys.argv:
+    run = H.capture_cycle()
+    xg = torch.zeros_like(b)
+    xe = torch.zeros_like(b)
+    for _ in range(2):
+        xg, xe = run(b, xg), H.cycle(b, xe)
+    same = bool(torch.equal(xg, xe))
+    torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    for _ in range(ncyc):
+        xg = run(b, xg)
+    torch.cuda.synchronize()
+    t6 = time.perf_counter()
+    print(f"captured cycle (HIP graph replay) {1e3 * (t6 - t5) / ncyc:.2f} ms  bit-identical to eager: {same}")
 print(f"cycle {1e3 * (t4 - t3) / ncyc:.2f} ms  residual {r0:.3e} -> {r:.3e} after {ncyc + 1} cycles  "
       f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB (torch only)")
