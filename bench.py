@@ -219,8 +219,9 @@ def main():
         info = plan.info if world == 1 else None
         if info is not None and bool(info.col16) and not bool(info.packed):
             # default layout: 2-byte tile-relative columns.  `achieved` / `frac` keep SURVEY 8(d)'s CSR byte model
-            # (12 B per nonzero) as prescribed; `layout_*` is what the kernel really has to move (10 B per nonzero)
-            Bl = 10 * nnz_local + 4 * (n_local + 1) + 32 * n_local
+            # (12 B per nonzero, 4 B per row offset) as prescribed; `layout_*` is what the kernel really has to move
+            # (10 B per nonzero, 2-byte tile-relative row offsets)
+            Bl = 10 * nnz_local + 2 * (n_local + int(info.n_tiles)) + 32 * n_local
             roof.update({"layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
                          "layout_frac": round(Bl / t_launch / 8e12, 4)})
         if args.compress and world == 1 and bool(plan.info.packed):

@@ -35,6 +35,7 @@ struct gla_csr {
   int16_t* col16 = nullptr;      // [nnz + 16] column minus the first row of the nonzero's tile
   uint8_t* vcode = nullptr;      // [nnz + 16] index into vdict
   void* vdict = nullptr;         // [256] distinct values (bit patterns ascending), dtype = val_dtype
+  uint16_t* rowoff16 = nullptr;  // [n_rows + n_tiles] rowptr minus the tile's first nonzero; tile t's rows at r + t
   uint32_t* col16_wide = nullptr; // bit t set: tile t has a column outside int16 range of its first row (reads col)
   int32_t packed = 0, col16_state = 0;   // col16_state: 0 not tried, 1 built, -1 most tiles do not fit int16
   int32_t col16_wide_tiles = 0;

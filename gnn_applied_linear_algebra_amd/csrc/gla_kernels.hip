@@ -300,7 +300,8 @@ template <typename T, class Epi, int PPT, bool NT, bool PF, bool COL16 = false, 
 __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
     const T* __restrict__ x, TileMap tm, Epi epi, const int16_t* __restrict__ col16 = nullptr,
-    const uint32_t* __restrict__ wide_mask = nullptr, unsigned n_cols = 0) {
+    const uint32_t* __restrict__ wide_mask = nullptr, unsigned n_cols = 0,
+    const uint16_t* __restrict__ rowoff16 = nullptr) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* prod = reinterpret_cast<T*>(smem_raw);
   typedef T T2 __attribute__((ext_vector_type(2)));
@@ -314,9 +315,18 @@ __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
   const int r = r0 + tid;
   int ra = 0, rb = 0;
   typename Epi::Pre pre;
+  // COL16: row offsets are read as uint16 relative to the tile's first nonzero, entry r + t (2 B per row, not 4)
+  auto row_range = [&](int row, int& a, int& b) {
+    if constexpr (COL16) {
+      a = s + (int)rowoff16[row + t];
+      b = s + (int)rowoff16[row + t + 1];
+    } else {
+      a = rowptr[row];
+      b = rowptr[row + 1];
+    }
+  };
   if (PF && r < r1) {
-    ra = rowptr[r];
-    rb = rowptr[r + 1];
+    row_range(r, ra, rb);
     pre = epi.load((int64_t)r, 0);
   }
   const auto gxs = epi.template gx_load<T>(0);
@@ -379,8 +389,7 @@ __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
   T red = T(0);
   if (r < r1) {
     if (!PF) {
-      ra = rowptr[r];
-      rb = rowptr[r + 1];
+      row_range(r, ra, rb);
       pre = epi.load((int64_t)r, 0);
     }
     T acc = T(0);
@@ -395,7 +404,10 @@ __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
     if constexpr (Epi::NRED > 0) red = epi.redv(acc, pre);
   }
   for (int r2 = r + GLA_BLOCK; r2 < r1; r2 += GLA_BLOCK) {       // tiles with more than 256 (short) rows
-    const int a = rowptr[r2] - sa, b = rowptr[r2 + 1] - sa;
+    int a, b;
+    row_range(r2, a, b);
+    a -= sa;
+    b -= sa;
     T acc = T(0);
     for (int j = a; j < b; ++j) acc = acc + prod[j];
     const auto pre2 = epi.load((int64_t)r2, 0);
@@ -723,10 +735,10 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
       // MINW = 6 caps the kernel at 80 VGPRs (it takes 83 unconstrained): 7 instead of 5 waves per SIMD, +1.5 %
       if (g_tuning.spmv_variant == 5)
         hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, true, 1>), grid, block, lds, st, A->rowptr,
-                           A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols);
+                           A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols, A->rowoff16);
       else
         hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, true, 6>), grid, block, lds, st, A->rowptr,
-                           A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols);
+                           A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols, A->rowoff16);
       GLA_LAUNCH_CHECK();
       return GLA_OK;
     }

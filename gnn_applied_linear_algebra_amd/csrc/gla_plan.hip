@@ -289,6 +289,16 @@ __global__ __launch_bounds__(GLA_BLOCK) void val_code_kernel(const T* __restrict
   }
 }
 
+// rowoff16[r + t] = rowptr[r] - (first nonzero of tile t) for the rows r0 .. r1 (inclusive) of tile t
+__global__ __launch_bounds__(GLA_BLOCK) void rowoff16_kernel(const int32_t* __restrict__ rowptr,
+                                                             const int4* __restrict__ tile_info, int n_tiles,
+                                                             uint16_t* __restrict__ rowoff16) {
+  const int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  const int4 ti = tile_info[t];
+  for (int i = threadIdx.x; i <= ti.y - ti.x; i += GLA_BLOCK) rowoff16[ti.x + t + i] = (uint16_t)(rowptr[ti.x + i] - ti.z);
+}
+
 int build_col16(gla_csr* p, hipStream_t st) {
   if (p->col16_state != 0 || p->nnz == 0 || p->long_rows) return GLA_OK;
   hipError_t e;
@@ -304,6 +314,9 @@ int build_col16(gla_csr* p, hipStream_t st) {
     PK(hipMemsetAsync(d_fail, 0, sizeof(int), st));
     hipLaunchKernelGGL(col16_kernel, dim3(p->n_tiles), dim3(GLA_BLOCK), 0, st, p->col,
                        reinterpret_cast<const int4*>(p->tile_info), p->n_tiles, p->col16, p->col16_wide, d_fail);
+    PK(hipMalloc(&p->rowoff16, ((size_t)p->n_rows + p->n_tiles + 2) * sizeof(uint16_t)));
+    hipLaunchKernelGGL(rowoff16_kernel, dim3(p->n_tiles), dim3(GLA_BLOCK), 0, st, p->rowptr,
+                       reinterpret_cast<const int4*>(p->tile_info), p->n_tiles, p->rowoff16);
     int h_fail = 0;
     PK(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
     PK(hipStreamSynchronize(st));
@@ -313,8 +326,10 @@ int build_col16(gla_csr* p, hipStream_t st) {
     if (p->col16_state < 0) {
       (void)hipFree(p->col16);
       (void)hipFree(p->col16_wide);
+      (void)hipFree(p->rowoff16);
       p->col16 = nullptr;
       p->col16_wide = nullptr;
+      p->rowoff16 = nullptr;
     }
   }
   return GLA_OK;
@@ -463,6 +478,7 @@ int gla_csr_destroy(gla_csr_t p) {
   if (p->tile_lists) (void)hipFree(p->tile_lists);
   if (p->col16) (void)hipFree(p->col16);
   if (p->col16_wide) (void)hipFree(p->col16_wide);
+  if (p->rowoff16) (void)hipFree(p->rowoff16);
   if (p->vcode) (void)hipFree(p->vcode);
   if (p->vdict) (void)hipFree(p->vdict);
   delete p;

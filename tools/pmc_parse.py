@@ -29,7 +29,7 @@ fetch_factor = calib_read / mean(c["FETCH_SIZE"])
 write_factor = 512 * 1024 / mean(c["WRITE_SIZE"])
 n, nnz = N * N, 5 * N * N - 4 * N
 alg = 12 * nnz + 4 * (n + 1) + 32 * n
-layout = (10 if col16 else 12) * nnz + 4 * (n + 1) + 32 * n
+layout = (10 * nnz + 2 * (n + n // 256) + 32 * n) if col16 else alg      # int16 columns + uint16 row offsets
 rd = mean(j["FETCH_SIZE"]) * 1024 * 2.0
 wr = mean(j["WRITE_SIZE"]) * 1024
 out = {"n": N, "col16": col16, "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "launches": len(j["FETCH_SIZE"]),
