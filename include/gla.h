@@ -51,8 +51,9 @@ int gla_version(void);
  * stream -- int16 tile-relative columns + a <= 256-entry value dictionary -- when the matrix allows it; the K = 1
  * kernels then read 3 bytes per nonzero instead of 12, results are bit-identical; default 0), "col16" (1, the
  * default: plans created afterwards also keep the columns as int16 offsets from the first row of the nonzero's row
- * tile, and the K = 1 kernels read those 2 bytes instead of the 4-byte column; tiles with a column outside that
- * range -- halo columns of a row-block partition -- are read as int32; results are bit-identical), "xcd_chunk",
+ * tile (and the row offsets as uint16 relative to the tile's first nonzero), and the K = 1 kernels read those 2 bytes
+ * instead of the 4-byte column / row pointer; tiles with a column outside that range -- halo columns of a row-block
+ * partition -- are read as int32; results are bit-identical), "xcd_chunk",
  * "spmm_variant" (A/B knobs). */
 int gla_set_option(const char* name, int64_t value);
 const char* gla_error_string(int code);
