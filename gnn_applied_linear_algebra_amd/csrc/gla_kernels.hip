@@ -570,7 +570,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_kernel(
 // MODE 1: branch-free clamped batches (surplus lanes re-read the last entry and are masked out of the sum).
 constexpr int SPMM_ROWCAP = 1024;               // row offsets staged per tile (more rows -> read rowptr directly)
 
-template <typename T, int LPR, int MODE, class Epi, int VW = 2>
+template <typename T, int LPR, int MODE, class Epi, int VW = 2, bool FLAT = false>
 __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
     const T* __restrict__ X, int64_t ldx, int K, int lds_elems, TileMap tm, Epi epi) {
@@ -597,55 +597,78 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
 #undef MM_ST
   }
   __syncthreads();
-  constexpr int RPP = GLA_BLOCK / LPR;          // rows per pass
-  const int k0 = (tid % LPR) * VW, rsub = tid / LPR;
   T2 red = T2(T(0));
-  const auto gxs0 = epi.template gx_load<T2>(min(k0, max(K - VW, 0)));
-  for (int r = r0 + rsub; r < r1; r += RPP) {
-    int a, b;
-    if (r - r0 < SPMM_ROWCAP) { a = srow[r - r0]; b = srow[r - r0 + 1]; }
-    else { a = rowptr[r] - s; b = rowptr[r + 1] - s; }
-    for (int k = k0; k < K; k += VW * LPR) {
-      const auto pre = epi.template loadv<T2>((int64_t)r, k);
-      const auto gxs = (k == k0) ? gxs0 : epi.template gx_load<T2>(k);
-      T2 acc = T2(T(0));
-      const T* Xk = X + k;
-      if constexpr (MODE == 0) {
-        int j = a;
-        for (; j + 4 <= b; j += 4) {
-          T2 xv[4];
+  // one (row, vector of VW right-hand sides) unit: gather the row's X vectors, in-order sum, fused vertex update
+  auto row_vec = [&](int r, int k, int a, int b, const auto& gxs) {
+    const auto pre = epi.template loadv<T2>((int64_t)r, k);
+    T2 acc = T2(T(0));
+    const T* Xk = X + k;
+    if constexpr (MODE == 0) {
+      int j = a;
+      for (; j + 4 <= b; j += 4) {
+        T2 xv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + u] * ldx), gxs);
+        for (int u = 0; u < 4; ++u) xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + u] * ldx), gxs);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc = acc + sval[j + u] * xv[u];
+        for (int u = 0; u < 4; ++u) acc = acc + sval[j + u] * xv[u];
+      }
+      if (j + 2 <= b) {
+        const T2 x0 = epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
+        const T2 x1 = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + 1] * ldx), gxs);
+        acc = acc + sval[j] * x0;
+        acc = acc + sval[j + 1] * x1;
+        j += 2;
+      }
+      if (j < b) acc = acc + sval[j] * epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
+    } else {
+      for (int j = a; j < b; j += 4) {
+        T v[4];
+        T2 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jj = min(j + u, b - 1);
+          v[u] = sval[jj];
+          xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[jj] * ldx), gxs);
         }
-        if (j + 2 <= b) {
-          const T2 x0 = epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
-          const T2 x1 = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + 1] * ldx), gxs);
-          acc = acc + sval[j] * x0;
-          acc = acc + sval[j + 1] * x1;
-          j += 2;
-        }
-        if (j < b) acc = acc + sval[j] * epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
-      } else {
-        for (int j = a; j < b; j += 4) {
-          T v[4];
-          T2 xv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int jj = min(j + u, b - 1);
-            v[u] = sval[jj];
-            xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[jj] * ldx), gxs);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const T2 nxt = acc + v[u] * xv[u];
-            acc = (j + u < b) ? nxt : acc;
-          }
+        for (int u = 0; u < 4; ++u) {
+          const T2 nxt = acc + v[u] * xv[u];
+          acc = (j + u < b) ? nxt : acc;
         }
       }
-      epi.template applyv<T2>((int64_t)r, k, acc, pre);
-      if constexpr (Epi::NRED > 0) red = red + epi.template redv<T2>(acc, pre);
+    }
+    epi.template applyv<T2>((int64_t)r, k, acc, pre);
+    if constexpr (Epi::NRED > 0) red = red + epi.template redv<T2>(acc, pre);
+  };
+  auto row_bounds = [&](int r, int& a, int& b) {
+    if (r - r0 < SPMM_ROWCAP) { a = srow[r - r0]; b = srow[r - r0 + 1]; }
+    else { a = rowptr[r] - s; b = rowptr[r + 1] - s; }
+  };
+  const int k0 = (tid % LPR) * VW;
+  if constexpr (FLAT) {
+    // K / VW is not a power of two (e.g. K = 20): lanes walk the flattened (row, vector) index space of the tile, so
+    // every lane of a wave-level gather is busy (with LPR = 16 lane groups only 10 of 16 would be at K = 20)
+    static_assert(Epi::NRED == 0, "the block reduction assumes the lane-group layout");
+    const int nvec = K / VW;
+    const int total = (r1 - r0) * nvec;
+    const auto gxs = epi.template gx_load<T2>(0);
+    for (int f = tid; f < total; f += GLA_BLOCK) {
+      const int rr = f / nvec;
+      int a, b;
+      row_bounds(r0 + rr, a, b);
+      row_vec(r0 + rr, (f - rr * nvec) * VW, a, b, gxs);
+    }
+  } else {
+    constexpr int RPP = GLA_BLOCK / LPR;          // rows per pass
+    const int rsub = tid / LPR;
+    const auto gxs0 = epi.template gx_load<T2>(min(k0, max(K - VW, 0)));
+    for (int r = r0 + rsub; r < r1; r += RPP) {
+      int a, b;
+      row_bounds(r, a, b);
+      for (int k = k0; k < K; k += VW * LPR) {
+        if (k == k0) row_vec(r, k, a, b, gxs0);
+        else row_vec(r, k, a, b, epi.template gx_load<T2>(k));
+      }
     }
   }
   if constexpr (Epi::NRED > 0) {       // lanes with the same rhs pair are LPR apart: fixed-order tree over the rows
@@ -772,6 +795,23 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   } while (0)
     const bool vec4 = sizeof(T) == 4 && vec2 && (K % 4 == 0) && (ldx % 4 == 0) && epi.vec_ok(4) &&
                       g_tuning.spmm_variant != 3;      // fp32: four right-hand sides (16 bytes) per lane
+    {
+      const int vw = vec4 ? 4 : 2;
+      const int nvec = K / vw;
+      if constexpr (Epi::NRED == 0) {
+        if ((vec4 || vec2) && (nvec & (nvec - 1)) != 0 && g_tuning.spmm_variant != 4) {   // 4: lane groups (A/B)
+          const size_t ldsf = lds + (SPMM_ROWCAP + 1) * sizeof(int32_t);
+          if (vec4)
+            hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, 1, 0, Epi, (sizeof(T) == 4 ? 4 : 2), true>), grid, block, ldsf,
+                               st, A->rowptr, A->col, val, X, ldx, K, A->lds_elems, tm, epi);
+          else
+            hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, 1, 0, Epi, 2, true>), grid, block, ldsf, st, A->rowptr, A->col,
+                               val, X, ldx, K, A->lds_elems, tm, epi);
+          GLA_LAUNCH_CHECK();
+          return GLA_OK;
+        }
+      }
+    }
     if (vec4) {
 #define GLA_SPMM4_CASE(LPR_)                                                                                      \
   hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, LPR_, 0, Epi, 4>), grid, block,                                  \
