@@ -1,0 +1,223 @@
+// Shared device / launch helpers of libgla_hip.so (gfx950 only; wave = 64 lanes): tile map and workgroup -> tile
+// mapping, branch-free tile loop, vector load / store, DPP lane-group sums, the two-stage column reduction, grid
+// sizing and the dtype / K dispatch macros.  Included by gla_rows.hip and gla_edges.hip; everything lives in an
+// anonymous namespace (one private copy per translation unit).
+#pragma once
+#include "gla_internal.h"
+
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// device views
+// ------------------------------------------------------------------------------------------------
+struct TileMap {
+  const int4* tile_info;      // per tile {first row, end row, first nnz, end nnz}
+  const int32_t* tile_row;
+  const int32_t* tile_list;   // nullptr = identity
+  int n_tiles;                // tiles to run in this launch
+  int tiles_per_xcd;
+  int xcd_chunk;              // see map_tile
+};
+
+// grid = 8 * tiles_per_xcd workgroups; with chunking the per-XCD count is rounded up to whole chunks so that the
+// slot formula of map_tile is a bijection onto [0, 8 * tiles_per_xcd) (slots >= n_tiles exit at once)
+inline void set_tile_mapping(TileMap& tm) {
+  tm.xcd_chunk = g_tuning.xcd_chunk;
+  const int C = tm.xcd_chunk > 0 ? tm.xcd_chunk : 1;
+  const int per_round = GLA_XCDS * C;
+  tm.tiles_per_xcd = ((tm.n_tiles + per_round - 1) / per_round) * C;
+}
+
+__device__ __forceinline__ int map_tile(const TileMap& m) {
+  const int bid = blockIdx.x;
+  // Workgroups b and b+8 share an XCD (round-robin dispatch).  xcd_chunk = C > 0: XCD e takes C consecutive tiles,
+  // then the next XCD the next C, ... (C = 1 is the plain identity mapping); xcd_chunk = 0: each XCD walks one
+  // contiguous eighth of the tiles.  Measured (tools/ab_spmv.py): small chunks win -- all XCDs then stream one
+  // common region of HBM, and a tile's x window (a few grid lines) is re-fetched by neighbouring XCDs from the
+  // Infinity Cache rather than from DRAM.
+  int slot;
+  if (m.xcd_chunk > 0) {
+    const int C = m.xcd_chunk, xcd = bid % GLA_XCDS, j = bid / GLA_XCDS;
+    slot = (j / C) * (GLA_XCDS * C) + xcd * C + (j % C);
+  } else {
+    slot = (bid % GLA_XCDS) * m.tiles_per_xcd + bid / GLA_XCDS;
+  }
+  if (slot >= m.n_tiles) return -1;
+  return m.tile_list ? m.tile_list[slot] : slot;
+}
+
+// Branch-free tile loop: every lane runs every iteration with its index clamped into [0, len) (lanes past the end
+// redo the last element and rewrite the identical value), so the loads of a batch are issued back to back instead
+// of one exec-masked load + wait at a time.  BODY_LOAD(u, i) fills per-slot registers, BODY_STORE(u, i) consumes.
+#define GLA_TILE_LOOP(len, tid, BODY_LOAD, BODY_STORE)                                  \
+  for (int base_ = 0; base_ < (len); base_ += 4 * GLA_BLOCK) {                          \
+    int ii_[4];                                                                         \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                     \
+      ii_[u] = min(base_ + u * GLA_BLOCK + (tid), (len)-1);                             \
+      BODY_LOAD(u, ii_[u]);                                                             \
+    }                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) { BODY_STORE(u, ii_[u]); }            \
+  }
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+template <typename V, typename T>
+__device__ __forceinline__ V ldv(const T* p) { return *reinterpret_cast<const V*>(p); }
+template <typename V, typename T>
+__device__ __forceinline__ void stv(T* p, V v) { *reinterpret_cast<V*>(p) = v; }
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// Sum over aligned groups of KP (<= 16) lanes with DPP moves (full-rate VALU; ds_bpermute-based __shfl_xor runs
+// through the LDS pipe and was the bottleneck of gla_edge_dot).  quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror: after log2(KP) steps every lane of the group holds the group's sum (fixed order).
+template <int CTRL, typename T>
+__device__ __forceinline__ T dpp_move(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+  } else {
+    typedef int I2v __attribute__((ext_vector_type(2)));
+    I2v w = __builtin_bit_cast(I2v, v);
+    w.x = __builtin_amdgcn_update_dpp(0, w.x, CTRL, 0xF, 0xF, true);
+    w.y = __builtin_amdgcn_update_dpp(0, w.y, CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(T, w);
+  }
+}
+
+template <int KP, typename T>
+__device__ __forceinline__ T group_sum(T v) {
+  static_assert(KP == 1 || KP == 2 || KP == 4 || KP == 8 || KP == 16, "group of 1..16 lanes");
+  if constexpr (KP >= 2) v = v + dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+  if constexpr (KP >= 4) v = v + dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+  if constexpr (KP >= 8) v = v + dpp_move<0x141>(v);     // row_half_mirror
+  if constexpr (KP >= 16) v = v + dpp_move<0x140>(v);    // row_mirror
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = v + __shfl_down(v, off, 64);
+  return v;
+}
+
+inline int check_plan(gla_csr* A, int dtype, int K) {
+  if (!A || K < 1 || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
+  return GLA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column dots / scaling (global aggregations of the power method)
+// ------------------------------------------------------------------------------------------------
+constexpr int DOT_BLOCKS_MAX = 1024;
+
+template <typename T, int KP>
+__global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage1(const T* __restrict__ X, int64_t ldx,
+                                                            const T* __restrict__ Y, int64_t ldy, int64_t n,
+                                                            int K, T* __restrict__ partial) {
+  __shared__ T red[GLA_BLOCK];
+  constexpr int RPP = GLA_BLOCK / KP;
+  const int tid = threadIdx.x, k0 = tid % KP, rsub = tid / KP;
+  for (int kb = 0; kb < K; kb += KP) {
+    const int k = kb + k0;
+    T acc = T(0);
+    if (k < K)
+      for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n; r += (int64_t)gridDim.x * RPP)
+        acc = acc + (Y ? X[r * ldx + k] * Y[r * ldy + k] : X[r * ldx + k]);   // Y == nullptr: plain column sums
+    red[tid] = acc;
+    __syncthreads();
+    for (int st = GLA_BLOCK / 2; st >= KP; st >>= 1) {
+      if (tid < st) red[tid] = red[tid] + red[tid + st];
+      __syncthreads();
+    }
+    if (tid < KP && k < K) partial[(int64_t)blockIdx.x * K + k] = red[tid];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage2(const T* __restrict__ partial, int nblocks, int K,
+                                                            T* __restrict__ out) {
+  __shared__ T red[GLA_BLOCK];
+  const int tid = threadIdx.x;
+  for (int k = 0; k < K; ++k) {
+    T acc = T(0);
+    for (int b = tid; b < nblocks; b += GLA_BLOCK) acc = acc + partial[(int64_t)b * K + k];
+    red[tid] = acc;
+    __syncthreads();
+    for (int st = GLA_BLOCK / 2; st > 0; st >>= 1) {
+      if (tid < st) red[tid] = red[tid] + red[tid + st];
+      __syncthreads();
+    }
+    if (tid == 0) out[k] = red[0];
+    __syncthreads();
+  }
+}
+
+inline unsigned grid_for(int64_t work, int per_block = GLA_BLOCK, int cap = 256 * 8) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+inline TileMap all_tiles(gla_csr* A) {
+  TileMap tm;
+  tm.tile_row = A->tile_row;
+  tm.tile_info = reinterpret_cast<const int4*>(A->tile_info);
+  tm.tile_list = nullptr;
+  tm.n_tiles = A->n_tiles;
+  set_tile_mapping(tm);
+  return tm;
+}
+
+template <typename T>
+int launch_col_dot(int64_t n, int K, const T* x, int64_t ldx, const T* y, int64_t ldy, T* out, T* pw,
+                   hipStream_t st) {
+  int kp = 1;
+  while (kp < K && kp < 64) kp <<= 1;
+  const int rpp = GLA_BLOCK / kp;
+  const unsigned nb = grid_for(n, rpp * 8, DOT_BLOCKS_MAX);
+#define GLA_DOT_CASE(KP_) \
+  hipLaunchKernelGGL((col_dot_stage1<T, KP_>), dim3(nb), dim3(GLA_BLOCK), 0, st, x, ldx, y, ldy, n, K, pw)
+  switch (kp) {
+    case 1: GLA_DOT_CASE(1); break;
+    case 2: GLA_DOT_CASE(2); break;
+    case 4: GLA_DOT_CASE(4); break;
+    case 8: GLA_DOT_CASE(8); break;
+    case 16: GLA_DOT_CASE(16); break;
+    case 32: GLA_DOT_CASE(32); break;
+    default: GLA_DOT_CASE(64); break;
+  }
+#undef GLA_DOT_CASE
+  GLA_LAUNCH_CHECK();
+  hipLaunchKernelGGL((col_dot_stage2<T>), dim3(1), dim3(GLA_BLOCK), 0, st, pw, (int)nb, K, out);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+#define GLA_K_SWITCH(K, ...)                      \
+  switch (K) {                                    \
+    case 1: { constexpr int KC = 1; __VA_ARGS__; } break;   \
+    case 2: { constexpr int KC = 2; __VA_ARGS__; } break;   \
+    case 4: { constexpr int KC = 4; __VA_ARGS__; } break;   \
+    case 8: { constexpr int KC = 8; __VA_ARGS__; } break;   \
+    case 16: { constexpr int KC = 16; __VA_ARGS__; } break; \
+    case 32: { constexpr int KC = 32; __VA_ARGS__; } break; \
+    default: { constexpr int KC = 0; __VA_ARGS__; } break;  \
+  }
+
+}  // namespace
+
+#define GLA_DISPATCH(dtype, ...)                              \
+  if ((dtype) == GLA_F64) { using T = double; __VA_ARGS__; }  \
+  else { using T = float; __VA_ARGS__; }

@@ -1,0 +1,869 @@
+// libgla_hip.so -- row kernels: SpMV / SpMM with fused vertex updates (gfx950 / MI355X only; wave = 64 lanes).
+//
+// One CSR "row-tile" kernel family replaces the reference's per-layer
+//   gather x[col] -> multiply -> torch.cat -> torch_scatter.scatter(sum) -> vertex update -> torch.cat
+// (e.g. pytorch/JacobiGNN.py:52-123) with a single pass over HBM:
+//
+//   phase 1  the workgroup streams its tile's nnz (val f64/f32 + col int32, CSR order) with fully
+//            coalesced loads, gathers x[col] (served by the XCD's L2: a tile's column window is a few
+//            grid lines) and parks the products in LDS;
+//   phase 2  one lane per row adds its products IN EDGE ORDER (sequential, no FMA contraction, so the
+//            sum is bit-identical to the reference's CPU scatter-add) and applies the fused vertex
+//            update (residual / Jacobi / Chebyshev ...), reading and writing the dense vectors once.
+//
+// Tiles are contiguous row ranges holding ~tile_nnz nonzeros (CSR-adaptive "stream" binning computed at
+// plan creation); blockIdx is remapped so that the XCDs take turns of 64 consecutive tiles (gla_device.h,
+// map_tile): all of them stream one common region of HBM and a tile's x window stays in its XCD's L2.  Matrices with a row longer than the LDS tile fall back to a
+// wave-per-row (CSR-vector) kernel whose sums are tree-ordered (documented in DESIGN.md).
+//
+// Multi-RHS (K > 1, row-major [n, K]): val/col are staged in LDS instead of products, and the lanes
+// are (row, rhs) pairs so that every gather reads K contiguous values of one X row.
+#include "gla_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// fused vertex updates ("epilogues"): called once per (row, rhs) with the finished row sum
+// ------------------------------------------------------------------------------------------------
+// Each epilogue is split into load -- the row's dense operands, issued EARLY so their latency overlaps the
+// nnz stream -- and apply with the finished row sum.  Both are generic in the value type V: V = T for one
+// right-hand side per lane, V = T2 (16-byte accesses) for two adjacent right-hand sides per lane.
+// operator() = load + apply for kernels that do not prefetch.
+#define GLA_EPI_SCALAR_API                                                                            \
+  static constexpr int NRED = 0; /* no block-level reduction */                                       \
+  template <typename V> struct GxV {};                                                                \
+  template <typename V> __device__ __forceinline__ GxV<V> gx_load(int) const { return GxV<V>{}; }     \
+  template <typename V> __device__ __forceinline__ V gx(V xv, const GxV<V>&) const { return xv; }     \
+  template <typename V> __device__ __forceinline__ V redv(V, const PreV<V>&) const { return V(); }    \
+  __device__ __forceinline__ T* partials_ptr() const { return nullptr; }                                                         \
+  GLA_EPI_SCALAR_CORE
+
+#define GLA_EPI_SCALAR_CORE                                                                           \
+  typedef PreV<T> Pre;                                                                                \
+  __device__ __forceinline__ Pre load(int64_t r, int k) const { return loadv<T>(r, k); }              \
+  __device__ __forceinline__ void apply(int64_t r, int k, T acc, const Pre& p) const {                \
+    applyv<T>(r, k, acc, p);                                                                          \
+  }                                                                                                   \
+  __device__ __forceinline__ void operator()(int64_t r, int k, T acc) const {                         \
+    applyv<T>(r, k, acc, loadv<T>(r, k));                                                             \
+  }
+
+template <typename T>
+struct EpiStore {                       // y = A x                       MatVecGNN.py:95-114
+  T* y; int64_t ldy;
+  template <typename V> struct PreV {};
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t, int) const { return PreV<V>{}; }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>&) const {
+    stv<V>(y + r * ldy + k, acc);
+  }
+  bool vec_ok(int w) const { return al16(y) && ldy % w == 0; }
+  GLA_EPI_SCALAR_API
+};
+
+template <typename T>
+struct EpiResidual {                    // r = b - A x                   GNNResidual.py:97-118
+  const T* b; int64_t ldb; T* res; int64_t ldr;
+  template <typename V> struct PreV { V b; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{ldv<V>(b + r * ldb + k)};
+  }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& p) const {
+    stv<V>(res + r * ldr + k, p.b - acc);
+  }
+  bool vec_ok(int w) const { return al16(b) && al16(res) && ldb % w == 0 && ldr % w == 0; }
+  GLA_EPI_SCALAR_API
+};
+
+template <typename T>
+struct EpiJacobi {                      // x + (w*(b - A x))/A_ii        JacobiGNN.py:100-123 (:119)
+  const T* diag; const T* b; int64_t ldb; const T* x; int64_t ldx; T* xo; int64_t ldxo; T w;
+  template <typename V> struct PreV { T d; V b, x; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{diag[r], ldv<V>(b + r * ldb + k), ldv<V>(x + r * ldx + k)};
+  }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& p) const {
+    stv<V>(xo + r * ldxo + k, p.x + (w * (p.b - acc)) / p.d);
+  }
+  bool vec_ok(int w) const {
+    return al16(b) && al16(x) && al16(xo) && ldb % w == 0 && ldx % w == 0 && ldxo % w == 0;
+  }
+  GLA_EPI_SCALAR_API
+};
+
+template <typename T>
+struct EpiChebyFirst {                  // r = b - A x; p = r; x += alpha p    ChebyGNN.py:91-163
+  const T* b; int64_t ldb; const T* x; int64_t ldx; T* res; int64_t ldr; T* p; int64_t ldp;
+  T* xo; int64_t ldxo; T alpha;
+  template <typename V> struct PreV { V b, x; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{ldv<V>(b + r * ldb + k), ldv<V>(x + r * ldx + k)};
+  }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& q) const {
+    const V ri = q.b - acc;
+    stv<V>(res + r * ldr + k, ri);
+    stv<V>(p + r * ldp + k, ri);
+    stv<V>(xo + r * ldxo + k, q.x + alpha * ri);
+  }
+  bool vec_ok(int w) const {
+    return al16(b) && al16(x) && al16(res) && al16(p) && al16(xo) && ldb % w == 0 && ldx % w == 0 &&
+           ldr % w == 0 && ldp % w == 0 && ldxo % w == 0;
+  }
+  GLA_EPI_SCALAR_API
+};
+
+template <typename T>
+struct EpiChebyNext {                   // r -= a_old*(A p); p = r + beta p; x += a_new p   ChebyGNN.py:186-243
+  const T* p; int64_t ldp; T* po; int64_t ldpo; T* res; int64_t ldr; T* x; int64_t ldx;
+  T a_old, a_new, beta;
+  template <typename V> struct PreV { V r, p, x; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{ldv<V>(res + r * ldr + k), ldv<V>(p + r * ldp + k), ldv<V>(x + r * ldx + k)};
+  }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& q) const {
+    const V ri = q.r - a_old * acc;
+    stv<V>(res + r * ldr + k, ri);
+    const V pn = ri + beta * q.p;
+    stv<V>(po + r * ldpo + k, pn);
+    stv<V>(x + r * ldx + k, q.x + a_new * pn);
+  }
+  bool vec_ok(int w) const {
+    return al16(p) && al16(po) && al16(res) && al16(x) && ldp % w == 0 && ldpo % w == 0 && ldr % w == 0 &&
+           ldx % w == 0;
+  }
+  GLA_EPI_SCALAR_API
+};
+
+// Fused power-method step (PowerMethodGNN.py:86-207, three MetaLayers): the gathered operand is normalised on
+// the fly (b_j = y_j / n, rounded like the reference's Layer 3), y_i = sum_j A_ij b_j is stored, and the workgroup
+// leaves sum_i y_i^2 of its tile in partials[tile * K + k] for the deterministic second-stage reduction.
+template <typename T>
+__device__ __forceinline__ T div_by(T a, T b, T rb) {
+  // a / b from the correctly rounded reciprocal rb = RN(1/b) with one Markstein correction step: q = RN(a*rb),
+  // r = a - q*b (exact in an FMA), q' = RN(q + r*rb) -- the correctly rounded quotient except for rare
+  // last-place cases, at 3 instructions instead of the ~30 of an IEEE fp64 division per gathered value.
+  const T q = a * rb;
+  const T r = fma_t(-q, b, a);
+  return fma_t(r, rb, q);
+}
+
+template <typename T>
+struct EpiPower {
+  T* y; int64_t ldy; const T* nrm; const T* rnrm; T* partials;
+  template <typename V> struct PreV {};
+  static constexpr int NRED = 1;
+  template <typename V> struct GxV { V n, rn; };                // this lane's divisor(s), loaded once per kernel
+  template <typename V> __device__ __forceinline__ GxV<V> gx_load(int k) const {
+    GxV<V> g;
+    if constexpr (sizeof(V) == sizeof(T)) { g.n = nrm ? nrm[k] : T(1); g.rn = nrm ? rnrm[k] : T(1); }
+    else {
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(V) / sizeof(T)); ++i) {
+        g.n[i] = nrm ? nrm[k + i] : T(1);
+        g.rn[i] = nrm ? rnrm[k + i] : T(1);
+      }
+    }
+    return g;
+  }
+  template <typename V> __device__ __forceinline__ V gx(V xv, const GxV<V>& g) const {
+    if (!nrm) return xv;
+    if constexpr (sizeof(V) == sizeof(T)) return div_by(xv, g.n, g.rn);
+    else {
+      V o;
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(V) / sizeof(T)); ++i) o[i] = div_by(xv[i], g.n[i], g.rn[i]);
+      return o;
+    }
+  }
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t, int) const { return PreV<V>{}; }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>&) const {
+    stv<V>(y + r * ldy + k, acc);
+  }
+  template <typename V> __device__ __forceinline__ V redv(V acc, const PreV<V>&) const { return acc * acc; }
+  __device__ __forceinline__ T* partials_ptr() const { return partials; }
+  bool vec_ok(int w) const { return al16(y) && ldy % w == 0; }
+  GLA_EPI_SCALAR_CORE
+};
+
+// ------------------------------------------------------------------------------------------------
+// K = 1: products staged in LDS
+// ------------------------------------------------------------------------------------------------
+template <bool NT, typename U>
+__device__ __forceinline__ U ld_stream(const U* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
+// Main K = 1 kernel: 16-byte val loads / 8-byte col loads -- each lane owns PAIRS of consecutive nnz; the tile's
+// nnz window is aligned down to an even index (the extra element is staged but never summed).
+// PF: the row lane's rowptr / dense operands are requested before the nnz stream so that the block runs through
+// three dependent memory round trips (tile record -> streams -> x gather) instead of five.
+template <typename T, class Epi, int PPT, bool NT, bool PF, bool COL16 = false, int MINW = 1>
+__global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ x, TileMap tm, Epi epi, const int16_t* __restrict__ col16 = nullptr,
+    const uint32_t* __restrict__ wide_mask = nullptr, unsigned n_cols = 0,
+    const uint16_t* __restrict__ rowoff16 = nullptr) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* prod = reinterpret_cast<T*>(smem_raw);
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef int I2 __attribute__((ext_vector_type(2)));
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, e = ti.w;
+  if (r0 >= r1) return;
+  const int tid = threadIdx.x;
+  const int r = r0 + tid;
+  int ra = 0, rb = 0;
+  typename Epi::Pre pre;
+  // COL16: row offsets are read as uint16 relative to the tile's first nonzero, entry r + t (2 B per row, not 4)
+  auto row_range = [&](int row, int& a, int& b) {
+    if constexpr (COL16) {
+      a = s + (int)rowoff16[row + t];
+      b = s + (int)rowoff16[row + t + 1];
+    } else {
+      a = rowptr[row];
+      b = rowptr[row + 1];
+    }
+  };
+  if (PF && r < r1) {
+    row_range(r, ra, rb);
+    pre = epi.load((int64_t)r, 0);
+  }
+  const auto gxs = epi.template gx_load<T>(0);
+  const int sa = s & ~1;                       // even -> val+sa is 16-byte aligned, col+sa 8-byte aligned
+  const int npairs = (e - sa + 1) >> 1;
+  const T2* val2 = reinterpret_cast<const T2*>(val + sa);
+  const I2* col2 = reinterpret_cast<const I2*>(col + sa);
+  // COL16: columns are read as int16 offsets from the tile's first row (2 B instead of 4 B per nonzero); tiles
+  // with a column out of that range (halo columns of a row-block partition) are flagged in wide_mask and read int32
+  const unsigned* colp = reinterpret_cast<const unsigned*>(COL16 ? col16 + sa : nullptr);
+  bool wide = false;
+  if constexpr (COL16) wide = (wide_mask[t >> 5] >> (t & 31)) & 1u;
+  T2* prod2 = reinterpret_cast<T2*>(prod);
+
+  auto stream_tile = [&](auto c16_tag) {
+  constexpr bool C16 = decltype(c16_tag)::value;
+  for (int base = 0; base < npairs; base += GLA_BLOCK * PPT) {
+    T2 v[PPT];
+    I2 c[PPT];
+    // Branch-free batch: indices are clamped into the tile, so every lane issues every load and every LDS
+    // write (lanes past the end recompute the tile's last pair and store the identical value again).  A
+    // predicated load or store makes hipcc sink the loads into exec-mask branches with a full s_waitcnt each,
+    // which serialises the batch and halves the bytes in flight.
+    int qc[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      qc[u] = min(base + u * GLA_BLOCK + tid, npairs - 1);
+      if constexpr (C16) {
+        const unsigned pk = ld_stream<NT>(colp + qc[u]);
+        // the alignment-slack element belongs to a neighbouring tile and may decode out of range: clamp (never summed)
+        c[u].x = (int)min((unsigned)(r0 + (int)(short)(pk & 0xFFFFu)), n_cols - 1);
+        c[u].y = (int)min((unsigned)(r0 + (int)(short)(pk >> 16)), n_cols - 1);
+      } else {
+        c[u] = ld_stream<NT>(col2 + qc[u]);
+      }
+      v[u] = ld_stream<NT>(val2 + qc[u]);
+    }
+    T2 xv[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      xv[u].x = epi.gx(x[c[u].x], gxs);
+      xv[u].y = epi.gx(x[c[u].y], gxs);
+    }
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      T2 p;
+      p.x = v[u].x * xv[u].x;
+      p.y = v[u].y * xv[u].y;
+      prod2[qc[u]] = p;
+    }
+  }
+  };
+  if constexpr (COL16) {
+    if (wide) stream_tile(std::false_type{}); else stream_tile(std::true_type{});
+  } else {
+    stream_tile(std::false_type{});
+  }
+  __syncthreads();
+
+  T red = T(0);
+  if (r < r1) {
+    if (!PF) {
+      row_range(r, ra, rb);
+      pre = epi.load((int64_t)r, 0);
+    }
+    T acc = T(0);
+    int j = ra - sa;
+    const int jend = rb - sa;
+    for (; j + 4 <= jend; j += 4) {              // LDS reads issued together, added strictly in edge order
+      const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
+      acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+    }
+    for (; j < jend; ++j) acc = acc + prod[j];
+    epi.apply((int64_t)r, 0, acc, pre);
+    if constexpr (Epi::NRED > 0) red = epi.redv(acc, pre);
+  }
+  for (int r2 = r + GLA_BLOCK; r2 < r1; r2 += GLA_BLOCK) {       // tiles with more than 256 (short) rows
+    int a, b;
+    row_range(r2, a, b);
+    a -= sa;
+    b -= sa;
+    T acc = T(0);
+    for (int j = a; j < b; ++j) acc = acc + prod[j];
+    const auto pre2 = epi.load((int64_t)r2, 0);
+    epi.apply((int64_t)r2, 0, acc, pre2);
+    if constexpr (Epi::NRED > 0) red = red + epi.redv(acc, pre2);
+  }
+  if constexpr (Epi::NRED > 0) {                                  // fixed-order workgroup sum -> partials[tile]
+    __shared__ T wred[GLA_BLOCK / 64];
+    red = wave_sum(red);
+    if ((tid & 63) == 0) wred[tid >> 6] = red;
+    __syncthreads();
+    if (tid == 0) epi.partials_ptr()[t] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
+  }
+}
+
+// Packed-stream K = 1 kernel (option "compress"): the matrix is read as 1-byte value codes + 2-byte tile-relative
+// columns (3 B per nonzero instead of 12).  Each lane owns 8 consecutive nonzeros: one 8-byte code load and one
+// 16-byte delta load, 8 gathers in flight; values come from the <= 256-entry dictionary staged in LDS.  Products,
+// in-order row sums and the fused vertex update are exactly those of spmv_stream_vec2_kernel (bit-identical).
+template <typename T, class Epi>
+__global__ __launch_bounds__(GLA_BLOCK) void spmv_packed_kernel(
+    const int32_t* __restrict__ rowptr, const int16_t* __restrict__ col16, const uint8_t* __restrict__ vcode,
+    const T* __restrict__ vdict, const T* __restrict__ x, unsigned n_cols, TileMap tm, Epi epi) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sdict = reinterpret_cast<T*>(smem_raw);               // [256]
+  T* prod = sdict + 256;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, e = ti.w;
+  if (r0 >= r1) return;
+  const int tid = threadIdx.x;
+  // packed tiles hold ~2040 nonzeros = up to 2 rows per lane for 5-point rows: both rows' offsets and dense
+  // operands are requested before the nonzero stream (rows past the tile are clamped to its last row, not stored)
+  constexpr int RPL = 2;
+  int rr[RPL], ra[RPL], rb[RPL];
+  typename Epi::Pre pre[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    rr[i] = r0 + i * GLA_BLOCK + tid;
+    const int rc = min(rr[i], r1 - 1);
+    ra[i] = rowptr[rc];
+    rb[i] = rowptr[rc + 1];
+    pre[i] = epi.load((int64_t)rc, 0);
+  }
+  const auto gxs = epi.template gx_load<T>(0);
+  const int sa = s & ~7;                       // multiple of 8 -> 8-byte aligned codes, 16-byte aligned deltas
+  const int ngrp = (e - sa + 7) >> 3;
+  const uint2* code8 = reinterpret_cast<const uint2*>(vcode + sa);
+  const int4* delta8 = reinterpret_cast<const int4*>(col16 + sa);
+  sdict[tid] = vdict[tid];
+  bool first = true;
+  for (int base = 0; base < ngrp; base += GLA_BLOCK) {
+    const int q = min(base + tid, ngrp - 1);   // branch-free: surplus lanes redo the last group
+    const uint2 cw = code8[q];
+    const int4 dw = delta8[q];
+    if (first) { __syncthreads(); first = false; }          // dictionary visible (loads above are in flight)
+    unsigned cc[8];
+    T v[8], xv[8];
+    const unsigned dd[4] = {(unsigned)dw.x, (unsigned)dw.y, (unsigned)dw.z, (unsigned)dw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lo = (int)(short)(dd[i] & 0xFFFFu), hi = (int)(short)(dd[i] >> 16);
+      cc[2 * i] = min((unsigned)(r0 + lo), n_cols - 1);      // elements of neighbouring tiles (alignment slack)
+      cc[2 * i + 1] = min((unsigned)(r0 + hi), n_cols - 1);  // may decode out of range: clamp, never summed
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xv[i] = epi.gx(x[cc[i]], gxs);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = sdict[((i < 4 ? cw.x : cw.y) >> (8 * (i & 3))) & 0xFFu];
+    T2* dst = reinterpret_cast<T2*>(prod + 8 * q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      T2 pp;
+      pp.x = v[2 * i] * xv[2 * i];
+      pp.y = v[2 * i + 1] * xv[2 * i + 1];
+      dst[i] = pp;
+    }
+  }
+  __syncthreads();
+
+  T red = T(0);
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) {
+    if (rr[i] < r1) {
+      T acc = T(0);
+      int j = ra[i] - sa;
+      const int jend = rb[i] - sa;
+      for (; j + 4 <= jend; j += 4) {
+        const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
+        acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+      }
+      for (; j < jend; ++j) acc = acc + prod[j];
+      epi.apply((int64_t)rr[i], 0, acc, pre[i]);
+      if constexpr (Epi::NRED > 0) red = red + epi.redv(acc, pre[i]);
+    }
+  }
+  for (int r2 = r0 + RPL * GLA_BLOCK + tid; r2 < r1; r2 += GLA_BLOCK) {
+    const int a = rowptr[r2] - sa, b = rowptr[r2 + 1] - sa;
+    T acc = T(0);
+    for (int j = a; j < b; ++j) acc = acc + prod[j];
+    const auto pre2 = epi.load((int64_t)r2, 0);
+    epi.apply((int64_t)r2, 0, acc, pre2);
+    if constexpr (Epi::NRED > 0) red = red + epi.redv(acc, pre2);
+  }
+  if constexpr (Epi::NRED > 0) {
+    __shared__ T wred[GLA_BLOCK / 64];
+    red = wave_sum(red);
+    if ((tid & 63) == 0) wred[tid >> 6] = red;
+    __syncthreads();
+    if (tid == 0) epi.partials_ptr()[t] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K > 1: val/col staged in LDS, lanes = (row, rhs)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KP, class Epi>
+__global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ X, int64_t ldx, int K, int lds_elems, TileMap tm, Epi epi) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sval = reinterpret_cast<T*>(smem_raw);
+  int32_t* scol = reinterpret_cast<int32_t*>(sval + lds_elems);
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int r0 = tm.tile_row[t], r1 = tm.tile_row[t + 1];
+  if (r0 >= r1) return;
+  const int s = rowptr[r0];
+  const int len = rowptr[r1] - s;
+  const int tid = threadIdx.x;
+  {
+    T v_[4];
+    int c_[4];
+#define MM_LD(u, i) { v_[u] = val[s + (i)]; c_[u] = col[s + (i)]; }
+#define MM_ST(u, i) { sval[i] = v_[u]; scol[i] = c_[u]; }
+    GLA_TILE_LOOP(len, tid, MM_LD, MM_ST)
+#undef MM_LD
+#undef MM_ST
+  }
+  __syncthreads();
+  constexpr int RPP = GLA_BLOCK / KP;          // rows per pass
+  const int k0 = tid % KP, rsub = tid / KP;
+  for (int r = r0 + rsub; r < r1; r += RPP) {
+    const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
+    for (int k = k0; k < K; k += KP) {
+      T acc = T(0);
+#pragma unroll 4
+      for (int j = a; j < b; ++j) acc = acc + sval[j] * X[(int64_t)scol[j] * ldx + k];
+      epi((int64_t)r, k, acc);
+    }
+  }
+}
+
+// K even: lanes = (row, PAIR of adjacent rhs) with 16-byte X / epilogue accesses.  val, col AND the tile's row
+// offsets are staged in LDS, so phase 2 touches global memory only for the X gathers and the epilogue vectors.
+// A row's gathers are issued four at a time (independent 16-byte loads), its sum stays in edge order.
+// LPR = lanes per row (power of two >= K/2).  MODE 0: exact trip counts (4-batches + scalar tail);
+// MODE 1: branch-free clamped batches (surplus lanes re-read the last entry and are masked out of the sum).
+constexpr int SPMM_ROWCAP = 1024;               // row offsets staged per tile (more rows -> read rowptr directly)
+
+template <typename T, int LPR, int MODE, class Epi, int VW = 2, bool FLAT = false>
+__global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ X, int64_t ldx, int K, int lds_elems, TileMap tm, Epi epi) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  typedef T T2 __attribute__((ext_vector_type(VW)));      // VW adjacent right-hand sides per lane (2, or 4 for fp32)
+  T* sval = reinterpret_cast<T*>(smem_raw);
+  int32_t* scol = reinterpret_cast<int32_t*>(sval + lds_elems);
+  int32_t* srow = scol + lds_elems;             // [SPMM_ROWCAP + 1] offsets relative to the tile's first nnz
+  const int t = map_tile(tm);
+  if (t < 0) return;
+  const int4 ti = tm.tile_info[t];
+  const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
+  if (r0 >= r1) return;
+  const int tid = threadIdx.x;
+  const int nrow_staged = min(r1 - r0, SPMM_ROWCAP);
+  for (int i = tid; i <= nrow_staged; i += GLA_BLOCK) srow[i] = rowptr[r0 + i] - s;
+  {
+    T v_[4];
+    int c_[4];
+#define MM_LD(u, i) { v_[u] = val[s + (i)]; c_[u] = col[s + (i)]; }
+#define MM_ST(u, i) { sval[i] = v_[u]; scol[i] = c_[u]; }
+    GLA_TILE_LOOP(len, tid, MM_LD, MM_ST)
+#undef MM_LD
+#undef MM_ST
+  }
+  __syncthreads();
+  T2 red = T2(T(0));
+  // one (row, vector of VW right-hand sides) unit: gather the row's X vectors, in-order sum, fused vertex update
+  auto row_vec = [&](int r, int k, int a, int b, const auto& gxs) {
+    const auto pre = epi.template loadv<T2>((int64_t)r, k);
+    T2 acc = T2(T(0));
+    const T* Xk = X + k;
+    if constexpr (MODE == 0) {
+      int j = a;
+      for (; j + 4 <= b; j += 4) {
+        T2 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + u] * ldx), gxs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = acc + sval[j + u] * xv[u];
+      }
+      if (j + 2 <= b) {
+        const T2 x0 = epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
+        const T2 x1 = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + 1] * ldx), gxs);
+        acc = acc + sval[j] * x0;
+        acc = acc + sval[j + 1] * x1;
+        j += 2;
+      }
+      if (j < b) acc = acc + sval[j] * epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
+    } else {
+      for (int j = a; j < b; j += 4) {
+        T v[4];
+        T2 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jj = min(j + u, b - 1);
+          v[u] = sval[jj];
+          xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[jj] * ldx), gxs);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const T2 nxt = acc + v[u] * xv[u];
+          acc = (j + u < b) ? nxt : acc;
+        }
+      }
+    }
+    epi.template applyv<T2>((int64_t)r, k, acc, pre);
+    if constexpr (Epi::NRED > 0) red = red + epi.template redv<T2>(acc, pre);
+  };
+  auto row_bounds = [&](int r, int& a, int& b) {
+    if (r - r0 < SPMM_ROWCAP) { a = srow[r - r0]; b = srow[r - r0 + 1]; }
+    else { a = rowptr[r] - s; b = rowptr[r + 1] - s; }
+  };
+  const int k0 = (tid % LPR) * VW;
+  if constexpr (FLAT) {
+    // K / VW is not a power of two (e.g. K = 20): lanes walk the flattened (row, vector) index space of the tile, so
+    // every lane of a wave-level gather is busy (with LPR = 16 lane groups only 10 of 16 would be at K = 20)
+    static_assert(Epi::NRED == 0, "the block reduction assumes the lane-group layout");
+    const int nvec = K / VW;
+    const int total = (r1 - r0) * nvec;
+    const auto gxs = epi.template gx_load<T2>(0);
+    for (int f = tid; f < total; f += GLA_BLOCK) {
+      const int rr = f / nvec;
+      int a, b;
+      row_bounds(r0 + rr, a, b);
+      row_vec(r0 + rr, (f - rr * nvec) * VW, a, b, gxs);
+    }
+  } else {
+    constexpr int RPP = GLA_BLOCK / LPR;          // rows per pass
+    const int rsub = tid / LPR;
+    const auto gxs0 = epi.template gx_load<T2>(min(k0, max(K - VW, 0)));
+    for (int r = r0 + rsub; r < r1; r += RPP) {
+      int a, b;
+      row_bounds(r, a, b);
+      for (int k = k0; k < K; k += VW * LPR) {
+        if (k == k0) row_vec(r, k, a, b, gxs0);
+        else row_vec(r, k, a, b, epi.template gx_load<T2>(k));
+      }
+    }
+  }
+  if constexpr (Epi::NRED > 0) {       // lanes with the same rhs pair are LPR apart: fixed-order tree over the rows
+    __syncthreads();
+    T2* sred = reinterpret_cast<T2*>(smem_raw);
+    sred[tid] = red;
+    __syncthreads();
+    for (int st = GLA_BLOCK / 2; st >= LPR; st >>= 1) {
+      if (tid < st) sred[tid] = sred[tid] + sred[tid + st];
+      __syncthreads();
+    }
+    if (tid < LPR) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i)
+        if (k0 + i < K) epi.partials_ptr()[(int64_t)t * K + k0 + i] = sred[tid][i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fallback for plans with a row longer than the LDS tile: one wave per row, tree-ordered sum
+// ------------------------------------------------------------------------------------------------
+template <typename T, class Epi>
+__global__ __launch_bounds__(GLA_BLOCK) void spmm_vector_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
+    const T* __restrict__ X, int64_t ldx, int K, int64_t n_rows, Epi epi) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * GLA_BLOCK) >> 6;
+  for (int64_t r = wave; r < n_rows; r += n_waves) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    for (int k = 0; k < K; ++k) {
+      T acc = T(0);
+      for (int j = a + lane; j < b; j += 64) acc = acc + val[j] * X[(int64_t)col[j] * ldx + k];
+      acc = wave_sum(acc);
+      if (lane == 0) epi(r, k, acc);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helper
+// ------------------------------------------------------------------------------------------------
+template <typename T, class Epi>
+int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int which, hipStream_t st) {
+  if (A->n_rows == 0) return GLA_OK;
+  const T* val = static_cast<const T*>(A->val);
+  if (Epi::NRED > 0 && (A->long_rows || (K > 1 && !((K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec_ok(2)))))
+    return GLA_ERR_UNSUPPORTED;           // reducing epilogues exist for the K = 1 and paired-rhs kernels only
+  if (A->long_rows) {
+    if (which == 1) return GLA_OK;        // nothing is "interior" for the fallback: all rows run after the halo
+    const int64_t waves_needed = A->n_rows;
+    int64_t blocks = (waves_needed * 64 + GLA_BLOCK - 1) / GLA_BLOCK;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((spmm_vector_kernel<T, Epi>), dim3((unsigned)blocks), dim3(GLA_BLOCK), 0, st,
+                       A->rowptr, A->col, val, X, ldx, K, A->n_rows, epi);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  }
+  TileMap tm;
+  tm.tile_row = A->tile_row;
+  tm.tile_info = reinterpret_cast<const int4*>(A->tile_info);
+  if (which == 0) { tm.tile_list = nullptr; tm.n_tiles = A->n_tiles; }
+  else if (which == 1) { tm.tile_list = A->tile_lists; tm.n_tiles = A->n_interior; }
+  else if (which == 2) { tm.tile_list = A->tile_lists + A->n_tiles; tm.n_tiles = A->n_boundary; }
+  else return GLA_ERR_INVALID_ARG;
+  if (which != 0 && A->tile_lists == nullptr) return GLA_ERR_INVALID_ARG;
+  if (tm.n_tiles == 0) return GLA_OK;
+  set_tile_mapping(tm);
+  const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
+  if (K == 1 && A->packed && g_tuning.compress && A->n_cols * (int64_t)sizeof(T) < ((int64_t)1 << 32)) {
+    const size_t ldsp = (size_t)(256 + A->lds_elems + 16) * sizeof(T);
+    hipLaunchKernelGGL((spmv_packed_kernel<T, Epi>), grid, block, ldsp, st, A->rowptr, A->col16, A->vcode,
+                       (const T*)A->vdict, X, (unsigned)A->n_cols, tm, epi);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  }
+  if (K == 1) {
+    const size_t lds = (size_t)(A->lds_elems + 2) * sizeof(T);
+#define GLA_SPMV2(N_, NT_, PF_) \
+  hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
+                     X, tm, epi)
+#define GLA_SPMV2(N_, NT_, PF_) \
+  hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
+                     X, tm, epi)
+    if (A->col16_state == 1 && g_tuning.col16 && (g_tuning.spmv_variant == 0 || g_tuning.spmv_variant == 5)) {
+      // MINW = 6 caps the kernel at 80 VGPRs (it takes 83 unconstrained): 7 instead of 5 waves per SIMD, +1.5 %
+      if (g_tuning.spmv_variant == 5)
+        hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, true, 1>), grid, block, lds, st, A->rowptr,
+                           A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols, A->rowoff16);
+      else
+        hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, true, 6>), grid, block, lds, st, A->rowptr,
+                           A->col, val, X, tm, epi, A->col16, A->col16_wide, (unsigned)A->n_cols, A->rowoff16);
+      GLA_LAUNCH_CHECK();
+      return GLA_OK;
+    }
+    switch (g_tuning.spmv_variant) {          // A/B knobs (tools/ab_spmv.py); 0 is the tuned default
+      case 1: GLA_SPMV2(3, false, false); break;
+      case 2: GLA_SPMV2(2, false, true); break;
+      case 3: GLA_SPMV2(4, false, true); break;
+      case 4: GLA_SPMV2(3, true, true); break;
+      default:
+        hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, 3, false, true, false, 6>), grid, block, lds, st,
+                           A->rowptr, A->col, val, X, tm, epi);
+        break;
+    }
+#undef GLA_SPMV2
+  } else {
+    const size_t lds = (size_t)A->lds_elems * (sizeof(T) + sizeof(int32_t));
+    const bool vec2 = (K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec_ok(2) &&
+                      (g_tuning.spmm_variant != 1 || Epi::NRED > 0);
+#define GLA_SPMM_CASE(KP_)                                                                              \
+  hipLaunchKernelGGL((spmm_stream_kernel<T, KP_, Epi>), grid, block, lds, st, A->rowptr, A->col, val, X, \
+                     ldx, K, A->lds_elems, tm, epi)
+#define GLA_SPMM2_CASE(LPR_)                                                                                   \
+  do {                                                                                                         \
+    const size_t lds2 = lds + (SPMM_ROWCAP + 1) * sizeof(int32_t);                                             \
+    if (g_tuning.spmm_variant == 2)                                                                            \
+      hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, LPR_, 1, Epi>), grid, block, lds2, st, A->rowptr, A->col, \
+                         val, X, ldx, K, A->lds_elems, tm, epi);                                               \
+    else                                                                                                       \
+      hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, LPR_, 0, Epi>), grid, block, lds2, st, A->rowptr, A->col, \
+                         val, X, ldx, K, A->lds_elems, tm, epi);                                               \
+  } while (0)
+    const bool vec4 = sizeof(T) == 4 && vec2 && (K % 4 == 0) && (ldx % 4 == 0) && epi.vec_ok(4) &&
+                      g_tuning.spmm_variant != 3;      // fp32: four right-hand sides (16 bytes) per lane
+    {
+      const int vw = vec4 ? 4 : 2;
+      const int nvec = K / vw;
+      if constexpr (Epi::NRED == 0) {
+        if ((vec4 || vec2) && (nvec & (nvec - 1)) != 0 && g_tuning.spmm_variant != 4) {   // 4: lane groups (A/B)
+          const size_t ldsf = lds + (SPMM_ROWCAP + 1) * sizeof(int32_t);
+          if (vec4)
+            hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, 1, 0, Epi, (sizeof(T) == 4 ? 4 : 2), true>), grid, block, ldsf,
+                               st, A->rowptr, A->col, val, X, ldx, K, A->lds_elems, tm, epi);
+          else
+            hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, 1, 0, Epi, 2, true>), grid, block, ldsf, st, A->rowptr, A->col,
+                               val, X, ldx, K, A->lds_elems, tm, epi);
+          GLA_LAUNCH_CHECK();
+          return GLA_OK;
+        }
+      }
+    }
+    if (vec4) {
+#define GLA_SPMM4_CASE(LPR_)                                                                                      \
+  hipLaunchKernelGGL((spmm_stream_vec2_kernel<T, LPR_, 0, Epi, 4>), grid, block,                                  \
+                     lds + (SPMM_ROWCAP + 1) * sizeof(int32_t), st, A->rowptr, A->col, val, X, ldx, K,            \
+                     A->lds_elems, tm, epi)
+      if (K <= 4) GLA_SPMM4_CASE(1);
+      else if (K <= 8) GLA_SPMM4_CASE(2);
+      else if (K <= 16) GLA_SPMM4_CASE(4);
+      else if (K <= 32) GLA_SPMM4_CASE(8);
+      else if (K <= 64) GLA_SPMM4_CASE(16);
+      else GLA_SPMM4_CASE(32);
+#undef GLA_SPMM4_CASE
+    } else if (vec2) {
+      if (K <= 2) GLA_SPMM2_CASE(1);
+      else if (K <= 4) GLA_SPMM2_CASE(2);
+      else if (K <= 8) GLA_SPMM2_CASE(4);
+      else if (K <= 16) GLA_SPMM2_CASE(8);
+      else if (K <= 32) GLA_SPMM2_CASE(16);
+      else GLA_SPMM2_CASE(32);
+    } else if (K <= 2) GLA_SPMM_CASE(2);
+    else if (K <= 4) GLA_SPMM_CASE(4);
+    else if (K <= 8) GLA_SPMM_CASE(8);
+    else if (K <= 16) GLA_SPMM_CASE(16);
+    else if (K <= 32) GLA_SPMM_CASE(32);
+    else GLA_SPMM_CASE(64);
+#undef GLA_SPMM_CASE
+#undef GLA_SPMM2_CASE
+  }
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int gla_spmm(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* Y, int64_t ldy, int which,
+             gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
+  if (!X || !Y || ldx < K || ldy < K) return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiStore<T> epi{(T*)Y, ldy};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_residual(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, const void* X, int64_t ldx, void* R,
+                 int64_t ldr, int which, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
+  if (!B || !X || !R || ldb < K || ldx < K || ldr < K) return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiResidual<T> epi{(const T*)B, ldb, (T*)R, ldr};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X,
+                     int64_t ldx, void* Xout, int64_t ldxo, double w, int which, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
+  if (!diag || !B || !X || !Xout || X == Xout || ldb < K || ldx < K || ldxo < K) return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiJacobi<T> epi{(const T*)diag, (const T*)B, ldb, (const T*)X, ldx, (T*)Xout, ldxo, (T)w};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X0,
+                      int64_t ldx0, void* Xout, void* Xtmp, int64_t ldw, double w, int n_iters,
+                      gla_stream_t stream) {
+  if (!A || n_iters < 0) return GLA_ERR_INVALID_ARG;
+  if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
+  if (n_iters == 0) return GLA_OK;
+  if (!Xout || (n_iters > 1 && !Xtmp) || Xout == Xtmp) return GLA_ERR_INVALID_ARG;
+  const void* src = X0;
+  int64_t lds_ = ldx0;
+  for (int i = 1; i <= n_iters; ++i) {
+    void* dst = ((n_iters - i) % 2 == 0) ? Xout : Xtmp;
+    int rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, src, lds_, dst, ldw, w, 0, stream);
+    if (rc) return rc;
+    src = dst;
+    lds_ = ldw;
+  }
+  return GLA_OK;
+}
+
+int gla_cheby_first(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, const void* X, int64_t ldx, void* R,
+                    int64_t ldr, void* P, int64_t ldp, void* Xout, int64_t ldxo, double alpha, int which,
+                    gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
+  if (!B || !X || !R || !P || !Xout || X == Xout || ldb < K || ldx < K || ldr < K || ldp < K || ldxo < K)
+    return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiChebyFirst<T> epi{(const T*)B, ldb, (const T*)X, ldx, (T*)R, ldr, (T*)P, ldp, (T*)Xout, ldxo, (T)alpha};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, void* Pout, int64_t ldpo, void* R,
+                   int64_t ldr, void* X, int64_t ldx, double alpha_old, double alpha_new, double beta, int which,
+                   gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
+  if (!P || !Pout || !R || !X || P == Pout || ldp < K || ldpo < K || ldr < K || ldx < K)
+    return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiChebyNext<T> epi{(const T*)P, ldp, (T*)Pout, ldpo, (T*)R, ldr, (T*)X, ldx,
+                        (T)alpha_old, (T)alpha_new, (T)beta};
+    return launch_rows<T>(A, K, (const T*)P, ldp, epi, which, (hipStream_t)stream);
+  })
+}
+
+int64_t gla_power_work_bytes(gla_csr_t A, int K, int dtype) {
+  if (!A || K < 1) return -1;      // tile partials [n_tiles, K] + second-stage partials [DOT_BLOCKS_MAX, K]
+  return ((int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) + DOT_BLOCKS_MAX) * K * (dtype == GLA_F64 ? 8 : 4);
+}
+
+int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, const void* nrm_in,
+                   const void* rnrm_in, void* Y, int64_t ldy, void* sumsq_out, void* work, int which,
+                   gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
+  if (!X || !Y || !work || ldx < K || ldy < K || ((nrm_in == nullptr) != (rnrm_in == nullptr)))
+    return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = dtype == GLA_F64 ? 8 : 4;
+  if (which != 2)          // boundary launches add to the partials the interior launch already zeroed
+    GLA_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)(A->n_tiles > 0 ? A->n_tiles : 1) * K * esz, st));
+  GLA_DISPATCH(dtype, {
+    EpiPower<T> epi{(T*)Y, ldy, (const T*)nrm_in, (const T*)rnrm_in, (T*)work};
+    rc = launch_rows<T>(A, K, (const T*)X, ldx, epi, which, st);
+    if (rc) return rc;
+    if (sumsq_out && which != 1) {     // column sums of the tile partials once every tile has contributed
+      T* tile_part = (T*)work;
+      return launch_col_dot<T>(A->n_tiles, K, tile_part, K, (const T*)nullptr, K, (T*)sumsq_out,
+                               tile_part + (int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) * K, st);
+    }
+    return GLA_OK;
+  })
+}
+
+}  // extern "C"
