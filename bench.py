@@ -246,7 +246,7 @@ def main():
         if args.compress and world == 1 and bool(plan.info.packed):
             # the packed layout moves 3 B per nonzero instead of the 12 B of SURVEY's CSR model: `achieved` keeps the
             # SURVEY byte model as prescribed (it can exceed what HBM delivers), `layout_*` is what is really moved
-            Bl = 3 * nnz_local + 4 * (n_local + 1) + 32 * n_local
+            Bl = 3 * nnz_local + 2 * (n_local + int(plan.info.n_tiles)) + 32 * n_local
             roof.update({"kernel": "spmv_packed_kernel<double,EpiJacobi>", "traffic": None,
                          "layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
                          "layout_frac": round(Bl / t_launch / 8e12, 4)})
@@ -271,7 +271,7 @@ def main():
                     jac(args.sweeps, vertex_attr, ei_p, edge_attr, g)
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t1
-                Bl = 3 * nnz_local + 4 * (n_local + 1) + 32 * n_local
+                Bl = 3 * nnz_local + 2 * (n_local + int(plan_p.info.n_tiles)) + 32 * n_local
                 optin = {"option": "compress", "value": round(total_sweeps / el, 2), "unit": "sweeps/s",
                          "us_per_sweep_whole_step": round(1e6 * el / total_sweeps, 2),
                          "bit_identical_to_default": same, "layout_bytes_per_launch": Bl}

@@ -331,7 +331,8 @@ __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
 template <typename T, class Epi>
 __global__ __launch_bounds__(GLA_BLOCK) void spmv_packed_kernel(
     const int32_t* __restrict__ rowptr, const int16_t* __restrict__ col16, const uint8_t* __restrict__ vcode,
-    const T* __restrict__ vdict, const T* __restrict__ x, unsigned n_cols, TileMap tm, Epi epi) {
+    const T* __restrict__ vdict, const T* __restrict__ x, unsigned n_cols, TileMap tm, Epi epi,
+    const uint16_t* __restrict__ rowoff16) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* sdict = reinterpret_cast<T*>(smem_raw);               // [256]
   T* prod = sdict + 256;
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_packed_kernel(
   for (int i = 0; i < RPL; ++i) {
     rr[i] = r0 + i * GLA_BLOCK + tid;
     const int rc = min(rr[i], r1 - 1);
-    ra[i] = rowptr[rc];
-    rb[i] = rowptr[rc + 1];
+    ra[i] = s + (int)rowoff16[rc + t];           // uint16 offsets relative to the tile's first nonzero
+    rb[i] = s + (int)rowoff16[rc + t + 1];
     pre[i] = epi.load((int64_t)rc, 0);
   }
   const auto gxs = epi.template gx_load<T>(0);
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_packed_kernel(
     }
   }
   for (int r2 = r0 + RPL * GLA_BLOCK + tid; r2 < r1; r2 += GLA_BLOCK) {
-    const int a = rowptr[r2] - sa, b = rowptr[r2 + 1] - sa;
+    const int a = s + (int)rowoff16[r2 + t] - sa, b = s + (int)rowoff16[r2 + t + 1] - sa;
     T acc = T(0);
     for (int j = a; j < b; ++j) acc = acc + prod[j];
     const auto pre2 = epi.load((int64_t)r2, 0);
@@ -643,7 +644,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   if (K == 1 && A->packed && g_tuning.compress && A->n_cols * (int64_t)sizeof(T) < ((int64_t)1 << 32)) {
     const size_t ldsp = (size_t)(256 + A->lds_elems + 16) * sizeof(T);
     hipLaunchKernelGGL((spmv_packed_kernel<T, Epi>), grid, block, ldsp, st, A->rowptr, A->col16, A->vcode,
-                       (const T*)A->vdict, X, (unsigned)A->n_cols, tm, epi);
+                       (const T*)A->vdict, X, (unsigned)A->n_cols, tm, epi, A->rowoff16);
     GLA_LAUNCH_CHECK();
     return GLA_OK;
   }
