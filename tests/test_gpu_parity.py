@@ -447,6 +447,33 @@ def test_full_size_20_sweeps_and_cheby_vs_c_oracle():
     eq(g, gw)
 
 
+def test_full_size_soc_and_direct_interp_vs_c_oracle():
+    """The AMG setup kernels at 4096^2 (67 M off-diagonal edges, random negative couplings): strength values AND the
+    S_ij > 0 classification of SOCClassicGNN, then the DirectInterpGNN weights, bit-exact against the C restatement."""
+    import c_oracle
+    N = 4096
+    n = N * N
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    eio, _ = gla.UtilsGNN.remove_diag_entries(ei, ev)
+    del ei, ev
+    gen = torch.Generator().manual_seed(99)
+    evr = -(torch.rand(eio.shape[1], 1, generator=gen, dtype=torch.float64) + 0.05)
+    A = c_oracle.Csr(eio.cpu().numpy(), evr.numpy(), n)
+    theta = 0.25
+    S = gla.SOCClassicGNN.SOCClassicGNN(theta)(torch.zeros(n, 1, dtype=torch.float64, device=DEV), eio, d(evr))
+    v_want, S_want = A.soc_classic(theta)
+    eq(S, S_want)
+    eq(S > 0, S_want > 0)
+    diag = torch.full((n, 1), 4.0, dtype=torch.float64)
+    split = torch.zeros(n, 1, dtype=torch.float64)
+    split[0::2] = 1
+    flags = (S.reshape(-1, 1) > 0).to(torch.float64)
+    w = gla.DirectInterpGNN.DirectInterpGNN()(d(torch.hstack([diag, split])), eio, torch.hstack([d(evr), flags]), None)
+    w_want = A.direct_interp(flags.cpu().numpy(), diag.numpy(), split.numpy())
+    np.testing.assert_array_equal(np.nan_to_num(w.cpu().numpy(), nan=7.0, posinf=8.0, neginf=9.0),
+                                  np.nan_to_num(w_want, nan=7.0, posinf=8.0, neginf=9.0))
+
+
 # ---------------------------------------------------------------------------------------------------
 # V-cycle glue
 # ---------------------------------------------------------------------------------------------------
