@@ -12,6 +12,7 @@ import math
 import torch
 
 from ..autograd import SparseMatrix
+from ..plan import plan_for
 from ..sparse_ops import coalesce
 
 
@@ -28,6 +29,22 @@ def _as_sparse(A, device=None):
                 pass
         return cached
     raise TypeError("expected a SparseMatrix or a torch sparse COO tensor")
+
+
+class _RowGather(torch.autograd.Function):
+    """d[row_e] for every edge e of a matrix pattern.  Backward = the edge-to-vertex sum of the incoming gradient on
+    the pattern's CSR plan (gla_segment_reduce: edge order within a row, deterministic) instead of torch's generic
+    index_put accumulation, which radix-sorts the 2e7 indices on every call (1.5 ms of a 4.4 ms training step)."""
+
+    @staticmethod
+    def forward(ctx, d, edge_index, n_rows, n_cols):
+        ctx.edge_index, ctx.shape = edge_index, (n_rows, n_cols)
+        return d[edge_index[0]]
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = plan_for(ctx.edge_index, ctx.shape[0], ctx.shape[1])
+        return plan.segment_reduce(g.contiguous(), "sum"), None, None, None
 
 
 def damping_factor(A, omega, diagonal_value, xy=None, exact=False):
@@ -54,7 +71,7 @@ def build_error_matrix(A, diag, omega):
     A_ind, A_val = A.indices(), A.values()
     n = A.shape[0]
     diag = diag.to(dev)
-    T_val = -omega * (1 / diag[A_ind[0, :]].reshape(-1)) * A_val
+    T_val = -omega * (1 / _RowGather.apply(diag.reshape(-1), A_ind, n, A.shape[1])) * A_val
     pattern = getattr(A, "_error_pattern", None)
     if pattern is None:
         # pattern of A union I and the slot of every stacked entry in the coalesced list: integer work done once per
