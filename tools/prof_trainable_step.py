@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""torch.profiler breakdown of one damping-factor loss forward + backward (2048^2, m = 20, fp32): which kernels the
+3 ms go to (library kernels vs torch elementwise / autograd glue).  Usage: python tools/prof_trainable_step.py"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import gnn_applied_linear_algebra_amd as gla
