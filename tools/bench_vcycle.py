@@ -60,5 +60,19 @@ if "--graph" in sys.argv:
     torch.cuda.synchronize()
     t6 = time.perf_counter()
     print(f"captured cycle (HIP graph replay) {1e3 * (t6 - t5) / ncyc:.2f} ms  bit-identical to eager: {same}")
+for a in sys.argv:
+    if a.startswith("--rhs="):
+        Kr = int(a.split("=")[1])
+        Bk = torch.rand(n, Kr, generator=gen, dtype=torch.float64).to(dev)
+        Xk = H.cycle(Bk, torch.zeros_like(Bk))
+        torch.cuda.synchronize()
+        t7 = time.perf_counter()
+        for _ in range(3):
+            Xk = H.cycle(Bk, Xk)
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        print(f"cycle on {Kr} right-hand sides at once (SpMM smoothers / transfers): {1e3 * (t8 - t7) / 3:.2f} ms "
+              f"= {1e3 * (t8 - t7) / 3 / Kr:.2f} ms per right-hand side")
+        del Bk, Xk
 print(f"cycle {1e3 * (t4 - t3) / ncyc:.2f} ms  residual {r0:.3e} -> {r:.3e} after {ncyc + 1} cycles  "
       f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB (torch only)")
