@@ -59,3 +59,29 @@ def test_high_freq_vectors(tg, name):
     torch.manual_seed(77)
     Y = rp.trainable_high_freq(n, 20)
     assert torch.equal(Y, T(tg[f"{name}_Y_highfreq"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_host_logic_test_vectors(tg, name):
+    """Host-side logic of the product mirror that needs no GPU: the seeded test vectors of loss.py (CPU generator, the
+    reference's draw order and its (j-1)*n+i indexing quirk) equal the reference's."""
+    sys.path.insert(0, ROOT)
+    from gnn_applied_linear_algebra_amd.TrainableJacobiDiag import loss as L
+    n = tg[f"{name}_va"].shape[0]
+    torch.manual_seed(77)
+    assert torch.equal(L.get_random_high_freq(n, 20, None), T(tg[f"{name}_Y_highfreq"]))
+    torch.manual_seed(78)
+    assert torch.equal(L.get_random_on_sphere(n, 20), T(tg[f"{name}_Y_uniform"]))
+
+
+def test_product_refuses_cpu_operands_without_gpu():
+    """No CPU fallback: without a GPU the differentiable product and the aggregation raise instead of computing."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sys.path.insert(0, ROOT)
+    import gnn_applied_linear_algebra_amd as gla
+    ei = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(Exception):
+        gla.autograd.sparse_mm(ei, torch.ones(2), torch.ones(2, 1), 2)
+    with pytest.raises(Exception):
+        gla.TrainableJacobiDiag.TrainableJacobiGNN.edge_to_vertex_aggregation(ei, torch.ones(2, 1), 2)
