@@ -47,18 +47,20 @@ class _RowGather(torch.autograd.Function):
         return plan.segment_reduce(g.contiguous(), "sum"), None, None, None
 
 
+def _dense_jacobi_spectrum(A, omega, diagonal_value):
+    """Eigenvalues of I - omega D^-1 A from dense factorisations (validation only: O(n^2) memory, host eigen-solver)."""
+    M = A.to_dense()
+    scaled = torch.linalg.solve(torch.diagflat(diagonal_value).to(M.device), M)
+    J = torch.eye(A.shape[0], device=M.device, dtype=M.dtype) - omega * scaled
+    return torch.linalg.eigvals(J.cpu())
+
+
 def damping_factor(A, omega, diagonal_value, xy=None, exact=False):
-    """:43-90  max |eig| of I - omega * (D \\ A); `exact` converts to dense (no autograd), else Gelfand K=3, m=20."""
-    N = A.shape[0]
+    """:43-90  spectral radius of I - omega * (D \\ A).  exact=True: dense eigenvalues (no autograd, small matrices);
+    default: Gelfand's formula with K = 3 products on m = 20 high-frequency test vectors (sparse, differentiable)."""
     if exact:
-        Adense = A.to_dense()
-        D = torch.diagflat(diagonal_value).to(Adense.device)
-        J = torch.eye(N, device=Adense.device, dtype=Adense.dtype) - omega * (torch.linalg.solve(D, Adense))
-        return max(abs(torch.linalg.eigvals(J.cpu())))
-    K = 3
-    m = 20
-    T = build_error_matrix(A, diagonal_value, omega)
-    return eigval_approx(K, m, T, xy=xy, method='high_freq')
+        return max(abs(_dense_jacobi_spectrum(A, omega, diagonal_value)))
+    return eigval_approx(3, 20, build_error_matrix(A, diagonal_value, omega), xy=xy, method='high_freq')
 
 
 def build_error_matrix(A, diag, omega):
@@ -109,79 +111,71 @@ def eigval_approx(K, m, A, xy=None, method='uniform', Y=None):
 
 
 def get_random_on_sphere(N, m):
-    """:130-137  (drawn with the CPU generator, like the reference, so seeds reproduce its vectors)"""
-    Y = torch.randn((N, m), dtype=torch.float)
-    return normalize_vectors(Y)
+    """:130-137  m Gaussian directions, normalised (CPU generator, like the reference, so seeds reproduce its vectors)."""
+    return normalize_vectors(torch.randn((N, m), dtype=torch.float))
+
+
+def _grid_coordinates(n):
+    """The reference's default coordinates (:143-151): entry (j-1)*n + i holds ((i+1)/(n+1), (j+1)/(n+1)) for 0-based
+    i, j -- the negative indices of j = 0 wrap to the end, which is reproduced, not corrected."""
+    j, i = torch.meshgrid(torch.arange(n), torch.arange(n), indexing='ij')
+    slot = ((j - 1) * n + i).reshape(-1)
+    xx, yy = torch.zeros(n * n, 1), torch.zeros(n * n, 1)
+    xx[slot, 0] = ((i + 1).double() / (n + 1)).reshape(-1).to(xx.dtype)      # Python-float quotient, then fp32
+    yy[slot, 0] = ((j + 1).double() / (n + 1)).reshape(-1).to(yy.dtype)
+    return xx, yy
 
 
 def get_random_high_freq(N, m, xy=None):
-    """:139-170  m random high-frequency sine modes on the sqrt(N) x sqrt(N) grid (CPU generator, same draw order)."""
+    """:139-170  m random high-frequency sine modes sin(pi tx x) sin(pi ty y) on the sqrt(N) x sqrt(N) grid, normalised.
+    Frequencies are drawn two at a time from the CPU generator and rejected unless one of them exceeds n/2 -- the
+    reference's draw order, so a seed gives the reference's vectors."""
     n = int(math.sqrt(N))
     if xy is None:
-        xx = torch.zeros(n * n, 1)
-        yy = torch.zeros(n * n, 1)
-        # the reference fills index (j-1)*n + i with 0-based i, j (:147-151): negative indices wrap around
-        j, i = torch.meshgrid(torch.arange(n), torch.arange(n), indexing='ij')
-        me = ((j - 1) * n + i).reshape(-1)
-        xx[me, 0] = ((i + 1).double() / (n + 1)).reshape(-1).to(xx.dtype)      # Python-float quotient, then fp32
-        yy[me, 0] = ((j + 1).double() / (n + 1)).reshape(-1).to(yy.dtype)
+        xx, yy = _grid_coordinates(n)
     else:
-        xy = xy.cpu() if isinstance(xy, torch.Tensor) else torch.as_tensor(xy)
-        xx = xy[:, 0]
-        yy = xy[:, 1]
-    Y = torch.zeros(N, m)
-    nHigh = 0
-    while nHigh < m:
-        thetax, thetay = (n - 1) * torch.rand(2) + 1
-        if thetax > n / 2 or thetay > n / 2:
-            t = torch.sin(thetax * torch.pi * xx) * torch.sin(thetay * torch.pi * yy)
-            Y[:, nHigh] = t.squeeze()
-            nHigh += 1
-    return normalize_vectors(Y)
+        pts = xy.cpu() if isinstance(xy, torch.Tensor) else torch.as_tensor(xy)
+        xx, yy = pts[:, 0], pts[:, 1]
+    modes = []
+    while len(modes) < m:
+        tx, ty = (n - 1) * torch.rand(2) + 1
+        if tx > n / 2 or ty > n / 2:
+            modes.append((torch.sin(tx * torch.pi * xx) * torch.sin(ty * torch.pi * yy)).reshape(-1))
+    return normalize_vectors(torch.stack(modes, 1).to(torch.float).reshape(N, m))
 
 
 def normalize_vectors(Y):
-    """:172-176"""
-    col_norm = torch.linalg.vector_norm(Y, dim=0)
-    col_scale = torch.diagflat(1 / col_norm)
-    return Y @ col_scale
+    """:172-176  unit columns (multiplication by the reciprocal norms, as the reference's Y @ diag(1/norm))."""
+    return Y * (1 / torch.linalg.vector_norm(Y, dim=0))
 
 
 def jacobi_dl(dvals, omega, A, x):
     """:179-183  one damped-Jacobi error propagation x - omega D^-1 A x"""
-    Ax = _as_sparse(A) @ x
-    DinvA = Ax / dvals
-    return x - omega * DinvA
+    return x - omega * ((_as_sparse(A) @ x) / dvals)
 
 
 def loss_batch(model, batch):
     """:185-204  mean damping factor over the graphs of a (PyG-style) batch: batch.x, .edgeij_pair, .edge_attr,
-    .batch, .num_graphs, .matrix[i], .coords[i]."""
-    vertex_attr, _, _ = model(batch.x, batch.edgeij_pair, batch.edge_attr, [], batch.batch)
-    omega = 2. / 3.
-    loss = 0.
-    for i in range(batch.num_graphs):
-        A = batch.matrix[i]
-        xy = batch.coords[i]
-        dvals = vertex_attr[batch.batch.to(vertex_attr.device) == i]
-        loss = loss + damping_factor(A, omega, dvals, xy=xy, exact=False)
-    return loss / batch.num_graphs
-
-
-def loss_optimal_jacobi(batch):
-    """:206-220  (dense)"""
-    loss = 0
-    for i in range(batch.num_graphs):
-        A = batch.matrix[i]
-        dvals = torch.diag(A.to_dense())
-        omega = optimal_omega(A, dvals)
-        loss += damping_factor(A, omega, dvals, exact=True)
-    return loss / batch.num_graphs
+    .batch, .num_graphs, .matrix[i], .coords[i]; the model's output are the learned diagonals."""
+    learned, _, _ = model(batch.x, batch.edgeij_pair, batch.edge_attr, [], batch.batch)
+    owner = batch.batch.to(learned.device)
+    total = 0.
+    for g in range(batch.num_graphs):
+        total = total + damping_factor(batch.matrix[g], 2. / 3., learned[owner == g], xy=batch.coords[g])
+    return total / batch.num_graphs
 
 
 def optimal_omega(A, dvals):
-    """:222-233  2 / (lmax + lmin) of D^-1 A (dense)"""
-    D = torch.diagflat(dvals)
-    DinvA = torch.linalg.solve(D, A.to_dense().to(D.device))
-    EVals = torch.linalg.eigvals(DinvA.cpu())
-    return 2 / (max(abs(EVals)) + min(abs(EVals)))
+    """:222-233  2 / (lmax + lmin) of |eig(D^-1 A)| (dense)"""
+    dense = A.to_dense()
+    spectrum = abs(torch.linalg.eigvals(torch.linalg.solve(torch.diagflat(dvals).to(dense.device), dense).cpu()))
+    return 2 / (max(spectrum) + min(spectrum))
+
+
+def loss_optimal_jacobi(batch):
+    """:206-220  mean exact damping factor with the matrix' own diagonal and its optimal omega (dense)"""
+    total = 0
+    for A in batch.matrix[:batch.num_graphs]:
+        own_diag = torch.diag(A.to_dense())
+        total += damping_factor(A, optimal_omega(A, own_diag), own_diag, exact=True)
+    return total / batch.num_graphs
