@@ -48,7 +48,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void mlp_pack_kernel(int in_dim, int h1,
   if (tid == 0) sb3[0] = b3[0];
 }
 
-template <typename T>
+template <typename T, int H2P>        // H2P: second hidden width rounded up to a multiple of 8 (register accumulators)
 __global__ __launch_bounds__(GLA_BLOCK) void mlp_relu3_kernel(int64_t n, int in_dim, int h1, const T* __restrict__ X,
                                                              int64_t ldx, const T* __restrict__ wk,
                                                              T* __restrict__ out) {
@@ -65,20 +65,20 @@ __global__ __launch_bounds__(GLA_BLOCK) void mlp_relu3_kernel(int64_t n, int in_
       const T v = X[r * ldx + min(c, in_dim - 1)];           // every lane issues every load (no exec-mask branches)
       x[c] = c < in_dim ? v : T(0);
     }
-    T acc[MLP_H2_MAX];
+    T acc[H2P];
 #pragma unroll
-    for (int k = 0; k < MLP_H2_MAX; ++k) acc[k] = sb2[k];
+    for (int k = 0; k < H2P; ++k) acc[k] = sb2[k];
     for (int j = 0; j < h1; ++j) {
       T s = sb1[j];
 #pragma unroll
       for (int c = 0; c < MLP_IN_MAX; ++c) s = fma_t(sW1[j * MLP_IN_MAX + c], x[c], s);
       s = s > T(0) ? s : T(0);
 #pragma unroll
-      for (int k = 0; k < MLP_H2_MAX; ++k) acc[k] = fma_t(sW2[j * MLP_H2_MAX + k], s, acc[k]);
+      for (int k = 0; k < H2P; ++k) acc[k] = fma_t(sW2[j * MLP_H2_MAX + k], s, acc[k]);
     }
     T o = sb3[0];
 #pragma unroll
-    for (int k = 0; k < MLP_H2_MAX; ++k) o = fma_t(sW3[k], acc[k] > T(0) ? acc[k] : T(0), o);
+    for (int k = 0; k < H2P; ++k) o = fma_t(sW3[k], acc[k] > T(0) ? acc[k] : T(0), o);
     out[r] = o;
   }
 }
@@ -91,8 +91,14 @@ int launch_mlp(int64_t n, int in_dim, int h1, int h2, const void* X, int64_t ldx
   GLA_LAUNCH_CHECK();
   int64_t blocks = (n + GLA_BLOCK - 1) / GLA_BLOCK;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL((mlp_relu3_kernel<T>), dim3((unsigned)blocks), dim3(GLA_BLOCK), 0, st, n, in_dim, h1,
-                     (const T*)X, ldx, (const T*)work, (T*)out);
+#define GLA_MLP(H2P_)                                                                                         \
+  hipLaunchKernelGGL((mlp_relu3_kernel<T, H2P_>), dim3((unsigned)blocks), dim3(GLA_BLOCK), 0, st, n, in_dim, h1, \
+                     (const T*)X, ldx, (const T*)work, (T*)out)
+  if (h2 <= 8) GLA_MLP(8);
+  else if (h2 <= 16) GLA_MLP(16);
+  else if (h2 <= 24) GLA_MLP(24);
+  else GLA_MLP(32);
+#undef GLA_MLP
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }
