@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the row-block partition, column renumbering, send lists and the all-gather halo
+"""CPU, world_size 2 and 4, gloo: the row-block partition, column renumbering, send lists and the all-gather halo
 exchange of gnn_applied_linear_algebra_amd/dist.py.  The local arithmetic is supplied by the oracle
 (test infrastructure) so that the HOST LOGIC of the N > 1 path is what is under test; the HIP kernels behind the
 same partition are covered by tests/test_gpu_dist.py on the GPU box."""
@@ -36,13 +36,13 @@ def _worker(rank, world, port, kind, q):
             Nx, Ny = 6, 9
             ei, ev = rp.laplacianfun_torch(Nx, Ny)
             n = Nx * Ny
-            cuts = [0, 4 * Nx, n]                         # uneven blocks: 4 and 5 grid lines
+            cuts = [0, 4 * Nx, n] if world == 2 else [0, 2 * Nx, 5 * Nx, 6 * Nx, n]   # uneven blocks of grid lines
         else:                                             # random sparse, ragged rows, far couplings
             n = 57
             ei = torch.randint(0, n, (2, 400), generator=gen)
             ei = ei[:, torch.argsort(ei[0], stable=True)]
             ev = torch.rand(400, 1, generator=gen, dtype=torch.float64) - 0.5
-            cuts = [0, 20, n]
+            cuts = [0, 20, n] if world == 2 else [0, 11, 20, 43, n]
         K = 3
         X = torch.rand(n, K, generator=gen, dtype=torch.float64)
         B = torch.rand(n, K, generator=gen, dtype=torch.float64)
@@ -76,7 +76,7 @@ def _worker(rank, world, port, kind, q):
         # rectangular operator (prolongation-like, 57 x 23): rows by `cuts`, input vector by its own partition
         if kind == "random":
             nc = 23
-            ccuts = [0, 9, nc]
+            ccuts = [0, 9, nc] if world == 2 else [0, 4, 9, 17, nc]
             ei_r = torch.stack([torch.randint(0, n, (300,), generator=gen), torch.randint(0, nc, (300,), generator=gen)])
             ei_r = ei_r[:, torch.argsort(ei_r[0], stable=True)]
             ev_r = torch.rand(300, 1, generator=gen, dtype=torch.float64)
@@ -100,9 +100,8 @@ def _worker(rank, world, port, kind, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["laplacian", "random"])
-def test_row_block_partition_world2(kind):
-    world = 2
+@pytest.mark.parametrize("kind,world", [("laplacian", 2), ("random", 2), ("laplacian", 4), ("random", 4)])
+def test_row_block_partition_world2(kind, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -114,8 +113,11 @@ def test_row_block_partition_world2(kind):
         p.join(timeout=60)
     for rank, status, S, n_send in sorted(res):
         assert status == "ok", f"rank {rank}: {status}"
-    if kind == "laplacian":
+    if kind == "laplacian" and world == 2:
         assert all(r[2] == 6 and r[3] == 6 for r in res)          # one grid line of 6 vertices each way
+    if kind == "laplacian" and world == 4:                        # interior blocks send their first and last grid line
+        assert all(r[2] == 12 for r in res)                       # (the one-line block sends its only line once: 6)
+        assert sorted(r[3] for r in res) == [6, 6, 6, 12]
 
 
 def test_single_process_partition_is_identity():
