@@ -30,7 +30,7 @@ def _worker(rank, world, port, overlap, q):
         dev = torch.device("cuda:0")
         Nx, Ny, K = 96, 130, 2
         n = Nx * Ny
-        lines = [0, 70, Ny]                                     # uneven blocks
+        lines = [0, 70, Ny] if world == 2 else [0, 30, 31, 90, Ny]   # uneven blocks (world 4: one single-line block)
         lo, hi = lines[rank] * Nx, lines[rank + 1] * Nx
         gen = torch.Generator().manual_seed(3)
         B = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
@@ -50,8 +50,8 @@ def _worker(rank, world, port, overlap, q):
         jac = RowBlockJacobi(ei_l, ev_l, n, lo, hi, overlap=overlap)
         x_loc = jac.forward(6, torch.stack([diag[lo:hi], B[lo:hi], X[lo:hi]], 1), g)[:, 0, :]
         assert torch.equal(x_loc, x_ref[lo:hi]), "jacobi"
-        if overlap:
-            assert jac.plan.n_interior > 0 and jac.plan.n_boundary > 0
+        if overlap:                                            # a one-line block has boundary tiles only
+            assert jac.plan.n_boundary > 0 and (jac.plan.n_interior > 0 or lines[rank + 1] - lines[rank] <= 2)
         ch = RowBlockCheby(ei_l, ev_l, n, lo, hi, overlap=overlap)
         x, r, p, g_out = ch.forward(4, B[lo:hi].contiguous(), X[lo:hi].contiguous(), gch)
         assert torch.equal(x, v_ref[lo:hi, 1]) and torch.equal(r, v_ref[lo:hi, 2]) and torch.equal(p, v_ref[lo:hi, 3])
@@ -68,9 +68,10 @@ def _worker(rank, world, port, overlap, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_ranks_one_gpu(overlap):
-    world = 2
+@pytest.mark.parametrize("overlap,world", [(False, 2), (True, 2), (True, 4)])
+def test_two_ranks_one_gpu(overlap, world):
+    """2 (and 4) ranks sharing the one GPU of the box drive the HIP kernels through the row-block drivers; results are
+    bit-exact against the single-rank modules (SURVEY 8e equivalence test; gloo moves the halos through the host)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
