@@ -641,18 +641,18 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   if (tm.n_tiles == 0) return GLA_OK;
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
-  if (K == 1 && A->packed && g_tuning.compress && A->n_cols * (int64_t)sizeof(T) < ((int64_t)1 << 32)) {
+  if (K == 1 && ldx == 1 && A->packed && g_tuning.compress && A->n_cols * (int64_t)sizeof(T) < ((int64_t)1 << 32)) {
     const size_t ldsp = (size_t)(256 + A->lds_elems + 16) * sizeof(T);
     hipLaunchKernelGGL((spmv_packed_kernel<T, Epi>), grid, block, ldsp, st, A->rowptr, A->col16, A->vcode,
                        (const T*)A->vdict, X, (unsigned)A->n_cols, tm, epi, A->rowoff16);
     GLA_LAUNCH_CHECK();
     return GLA_OK;
   }
-  if (K == 1) {
+  // the K = 1 kernels gather x[col] from a CONTIGUOUS vector; a strided single column (ldx > 1, e.g. a column view of
+  // an AoS attribute tensor) takes the general (row, rhs)-lane kernel below, which honours the leading dimension
+  if (K == 1 && ldx != 1 && Epi::NRED > 0) return GLA_ERR_UNSUPPORTED;
+  if (K == 1 && ldx == 1) {
     const size_t lds = (size_t)(A->lds_elems + 2) * sizeof(T);
-#define GLA_SPMV2(N_, NT_, PF_) \
-  hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
-                     X, tm, epi)
 #define GLA_SPMV2(N_, NT_, PF_) \
   hipLaunchKernelGGL((spmv_stream_vec2_kernel<T, Epi, N_, NT_, PF_>), grid, block, lds, st, A->rowptr, A->col, val, \
                      X, tm, epi)

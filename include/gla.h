@@ -14,7 +14,8 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued there, nothing synchronises
  *     except plan creation (gla_csr_create_from_coo) which returns sizes to the host;
  *   - dense operands are row-major [rows, K] with a leading dimension in ELEMENTS (ld >= K);
- *     K is the number of right-hand sides (1 = SpMV);
+ *     K is the number of right-hand sides (1 = SpMV; the fastest K = 1 kernels need the gathered
+ *     vector contiguous, ld = 1 -- a strided single column is served by the general kernel);
  *   - "edge order" = the order of the caller's COO edge list (reference tensors edgeij_pair /
  *     edge_attr); "CSR order" = stable sort of the edges by row (edge order kept inside a row, so
  *     in-order row sums equal the reference's sequential scatter-add bit for bit);

@@ -943,6 +943,32 @@ def test_unfused_l3_modules_golden(golden, N):
     eq(ea[:, 2], golden[f"N{N}_di_rnd_w"])
 
 
+def test_single_column_with_leading_dimension():
+    """C-ABI contract: dense operands carry a leading dimension.  A single right-hand side handed over as a strided
+    column of an AoS tensor (K = 1, ld = 3) must give the contiguous result bit for bit (the contiguous-x fast kernels
+    do not apply; the general kernel does)."""
+    N = 150
+    n = N * N
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    plan = gla.CsrPlan(ei, n)
+    plan.set_values(ev)
+    gen = torch.Generator().manual_seed(21)
+    aos = d(torch.rand(n, 3, generator=gen, dtype=torch.float64))
+    diag = torch.full((n,), -4.0, dtype=torch.float64, device=DEV)
+    b_s, x_s = aos[:, 1:2], aos[:, 2:3]                       # strided [n, 1] views, stride(0) = 3
+    b_c, x_c = b_s.contiguous(), x_s.contiguous()
+    assert x_s.stride(0) == 3
+    eq(plan.spmm(x_s), plan.spmm(x_c))
+    eq(plan.residual(b_s, x_s), plan.residual(b_c, x_c))
+    out_s, out_c = torch.empty(n, 1, dtype=torch.float64, device=DEV), torch.empty(n, 1, dtype=torch.float64, device=DEV)
+    plan.jacobi_sweep(diag, b_s, x_s, out_s, 0.7)
+    plan.jacobi_sweep(diag, b_c, x_c, out_c, 0.7)
+    eq(out_s, out_c)
+    eq(plan.edge_products(x_s), plan.edge_products(x_c))
+    with pytest.raises(gla._lib.GlaError):                    # the fused power step needs the contiguous kernels
+        plan.power_step(x_s)
+
+
 def test_c_abi_host_without_torch(tmp_path):
     """examples/c_host_jacobi.cpp: a C++ host with hipMalloc buffers and no torch / Python on include/gla.h -- builds
     the Laplacian with the library's builder, runs fused Jacobi sweeps, compares bit for bit with a host loop."""
