@@ -46,6 +46,8 @@ enum {
   GLA_ERR_NO_DEVICE = -6
 };
 
+/* 100 * major + minor; entry points are only ever added within a major version (110: + gla_edge_attr,
+ * gla_segment_stats, gla_edge_dot, gla_mlp_relu3 / gla_mlp_work_bytes). */
 int gla_version(void);
 /* Tuning knobs (process-wide): "spmv_variant" (kernel flavour for K = 1), "tile_nnz" (target nnz per row
  * tile for plans created afterwards; 0 = automatic), "compress" (1: gla_csr_set_values additionally builds a packed
