@@ -969,6 +969,44 @@ def test_single_column_with_leading_dimension():
         plan.power_step(x_s)
 
 
+@pytest.mark.parametrize("K,pad", [(2, 2), (6, 2), (16, 4), (20, 4), (4, 1), (6, 3), (3, 2), (5, 0)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_leading_dimensions_all_row_ops(K, pad, dtype):
+    """Every row op with operands embedded in wider buffers (ld = K + pad): vector-width-aligned and misaligned
+    leading dimensions, K a power of two / not (flattened lanes) / odd (scalar lanes) -- all equal the contiguous
+    call bit for bit."""
+    N = 90
+    n = N * N
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    plan = gla.CsrPlan(ei, n)
+    plan.set_values(ev.to(dtype))
+    gen = torch.Generator().manual_seed(100 + K + pad)
+
+    def wide():
+        w = d(torch.rand(n, K + pad, generator=gen, dtype=torch.float64).to(dtype))
+        return w[:, :K], w[:, :K].contiguous()
+    (xs, xc), (bs, bc) = wide(), wide()
+    diag = torch.full((n,), -4.0, dtype=dtype, device=DEV)
+    eq(plan.spmm(xs), plan.spmm(xc))
+    eq(plan.residual(bs, xs), plan.residual(bc, xc))
+    (os_, _), oc = wide(), torch.empty(n, K, dtype=dtype, device=DEV)
+    plan.jacobi_sweep(diag, bs, xs, os_, 0.7)
+    plan.jacobi_sweep(diag, bc, xc, oc, 0.7)
+    eq(os_, oc)
+    # Chebyshev first + next step with every operand strided
+    outs = []
+    for strided in (True, False):
+        r, p, xo, p2 = ((wide()[0] if strided else torch.empty(n, K, dtype=dtype, device=DEV)) for _ in range(4))
+        b_, x_ = (bs, xs) if strided else (bc, xc)
+        plan.cheby_first(b_, x_, r, p, xo, -0.25)
+        plan.cheby_next(p, p2, r, xo, -0.25, -0.26, 0.1)
+        outs.append([t_.contiguous() for t_ in (r, p2, xo)])
+    for a, b_ in zip(*outs):
+        eq(a, b_)
+    eq(plan.edge_products(xs), plan.edge_products(xc))
+    eq(plan.edge_attr(xs), plan.edge_attr(xc))
+
+
 def test_c_abi_host_without_torch(tmp_path):
     """examples/c_host_jacobi.cpp: a C++ host with hipMalloc buffers and no torch / Python on include/gla.h -- builds
     the Laplacian with the library's builder, runs fused Jacobi sweeps, compares bit for bit with a host loop."""
