@@ -65,3 +65,25 @@ def test_missing_gpu_fails_loudly():
                                   torch.tensor([0.7]))
     with pytest.raises(gla._lib.GlaError):
         gla.UtilsGNN.laplacianfun_torch(4)
+
+
+def test_header_is_valid_c(tmp_path):
+    """include/gla.h is a C header (the boundary is a C ABI): a C11 translation unit that includes it and takes the
+    address of every declared entry point compiles with gcc -std=c11 -Wall -Werror."""
+    import re
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "gla.h")).read()
+    names = sorted(set(re.findall(r"\b(gla_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 40
+    src = tmp_path / "use_gla.c"
+    src.write_text('#include "gla.h"\n#include <stddef.h>\n'
+                   + "typedef void (*fn_t)(void);\n"
+                   + "fn_t table[] = {" + ", ".join(f"(fn_t){n}" for n in names) + "};\n"
+                   + "size_t n_entries(void) { return sizeof(table) / sizeof(table[0]); }\n")
+    subprocess.run([gcc, "-std=c11", "-Wall", "-Werror", "-c", str(src),
+                    "-I" + os.path.join(root, "include"), "-o", str(tmp_path / "use_gla.o")], check=True)
