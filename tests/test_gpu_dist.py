@@ -178,10 +178,11 @@ def _amg_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_distributed_vcycle_two_ranks():
-    """BASELINE config 5 shape with 2 ranks sharing the GPU: row-block distributed V-cycle == single-rank V-cycle,
-    bit for bit (rectangular partitions for P / P^T, replicated coarsest solve)."""
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_vcycle_two_ranks(world):
+    """BASELINE config 5 shape with 2 (and 3: blocks that do not divide the levels evenly) ranks sharing the GPU:
+    row-block distributed V-cycle == single-rank V-cycle, bit for bit (rectangular partitions for P / P^T, replicated
+    coarsest solve)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
