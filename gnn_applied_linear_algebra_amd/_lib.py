@@ -25,7 +25,8 @@ class CsrInfo(ctypes.Structure):
                 ("sorted_input", ctypes.c_int32), ("max_row_len", ctypes.c_int32),
                 ("n_tiles", ctypes.c_int32), ("tile_nnz", ctypes.c_int32), ("lds_elems", ctypes.c_int32),
                 ("long_rows", ctypes.c_int32), ("val_dtype", ctypes.c_int32), ("packed", ctypes.c_int32),
-                ("col16", ctypes.c_int32), ("col16_wide_tiles", ctypes.c_int32)]
+                ("col16", ctypes.c_int32), ("col16_wide_tiles", ctypes.c_int32), ("dia", ctypes.c_int32),
+                ("reserved_", ctypes.c_int32), ("dia_row_lo", ctypes.c_int64), ("dia_row_hi", ctypes.c_int64)]
 
 
 _P = ctypes.c_void_p

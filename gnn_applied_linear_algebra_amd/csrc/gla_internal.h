@@ -16,7 +16,8 @@ constexpr int GLA_BLOCK = 256;          // 4 wavefronts of 64 lanes
 constexpr int GLA_XCDS = 8;             // MI355X: 8 XCDs, each with a private L2
 constexpr int GLA_LDS_ELEMS_MAX = 4096; // staged nnz per workgroup (32 KiB of f64 products)
 constexpr int GLA_TILE_NNZ_MIN = 1024;
-constexpr int GLA_PAD = 8;              // over-read slack (elements) behind val/col
+constexpr int GLA_PAD = 8;
+constexpr int GLA_DIA_MAX = 16;              // over-read slack (elements) behind val/col
 
 struct gla_csr {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
@@ -39,6 +40,15 @@ struct gla_csr {
   uint32_t* col16_wide = nullptr; // bit t set: tile t has a column outside int16 range of its first row (reads col)
   int32_t packed = 0, col16_state = 0;   // col16_state: 0 not tried, 1 built, -1 most tiles do not fit int16
   int32_t col16_wide_tiles = 0;
+  // optional diagonal (stencil) layout for the K = 1 kernels (option "dia"): every nonzero lies on one of D <= 15
+  // diagonals col - row = dia_off[d], rows hold them in ascending order.  No column indices are streamed at all.
+  int32_t dia_state = 0;         // 0 not tried, 1 built, -1 the matrix is not a stencil
+  int32_t dia_D = 0;
+  int32_t dia_off[16] = {0};     // ascending offsets (host copy; passed to the kernels by value)
+  uint16_t* dia_mask = nullptr;  // [n_rows] bit d set: row has an entry on diagonal d
+  void* dia_val = nullptr;       // [dia_D][n_rows] values, diagonal-major (0 where the row has no entry)
+  int64_t dia_row_lo = 0, dia_row_hi = 0;   // rows [lo, hi) fit the diagonal set (halo rows of a row block do not)
+  int64_t int_row_lo = -1, int_row_hi = -1; // rows of the interior tiles when they form one contiguous run
 };
 
 struct gla_tuning {
@@ -48,6 +58,7 @@ struct gla_tuning {
   int xcd_chunk = 64;       // consecutive tiles per XCD turn (1 = identity mapping, 0 = one contiguous span per XCD)
   int col16 = 1;            // K = 1 kernels read int16 tile-relative columns when the plan could build them
   int compress = 0;         // 1: gla_csr_set_values also builds the packed stream when the matrix allows it
+  int dia = 1;              // stencil matrices (<= 16 diagonals): K = 1 kernels use the diagonal layout
 };
 extern gla_tuning g_tuning;
 

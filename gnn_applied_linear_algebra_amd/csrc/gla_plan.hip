@@ -14,6 +14,13 @@ namespace {
 
 constexpr int FLAG_UNSORTED = 1, FLAG_RANGE = 2;
 
+inline unsigned grid_for(int64_t work, int64_t per_block = GLA_BLOCK, int64_t cap = 256 * 16) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
 __global__ __launch_bounds__(GLA_BLOCK) void validate_kernel(const int64_t* __restrict__ row,
                                                              const int64_t* __restrict__ col, int64_t nnz,
                                                              int64_t n_rows, int64_t n_cols, int* flags) {
@@ -289,6 +296,128 @@ __global__ __launch_bounds__(GLA_BLOCK) void val_code_kernel(const T* __restrict
   }
 }
 
+// ---- diagonal (stencil) layout (option "dia") ------------------------------------------------------------------
+struct DiaOffsets { int32_t off[GLA_DIA_MAX]; int32_t D; };
+
+// first row whose length equals max_len at or after `from` (the candidate that should hold every diagonal; searched
+// from the middle so that the halo rows at either end of a row block are not picked) and first such row anywhere
+__global__ __launch_bounds__(GLA_BLOCK) void dia_first_full_row_kernel(const int32_t* __restrict__ rowptr, int64_t n_rows,
+                                                                       int max_len, int64_t from,
+                                                                       unsigned long long* first) {
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK)
+    if (rowptr[r + 1] - rowptr[r] == max_len) atomicMin(first + (r >= from ? 0 : 1), (unsigned long long)r);
+}
+
+__device__ __forceinline__ int dia_slot(const DiaOffsets& o, int off) {
+  int d = -1;
+#pragma unroll
+  for (int i = 0; i < GLA_DIA_MAX; ++i) d = (i < o.D && o.off[i] == off) ? i : d;
+  return d;
+}
+
+// every row: its offsets col - row must be diagonals of the candidate set, in strictly ascending order.  Rows that
+// do not fit (the halo rows of a row block) get mask 0xFFFF and shrink the valid range [range[0], range[1]).
+__global__ __launch_bounds__(GLA_BLOCK) void dia_verify_kernel(const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ col, int64_t n_rows,
+                                                               DiaOffsets o, uint16_t* __restrict__ mask,
+                                                               unsigned long long* range) {
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK) {
+    unsigned m = 0;
+    int last = -1, bad = 0;
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+      const int d = dia_slot(o, (int)((int64_t)col[p] - r));
+      if (d <= last) bad = 1;              // not a diagonal of the set (-1) or out of order / duplicate
+      last = d;
+      m |= d >= 0 ? 1u << d : 0u;
+    }
+    mask[r] = bad ? (uint16_t)0xFFFF : (uint16_t)m;
+    if (bad) {
+      if (r < n_rows / 2) atomicMax(range, (unsigned long long)(r + 1));
+      else atomicMin(range + 1, (unsigned long long)r);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void dia_scatter_kernel(const int32_t* __restrict__ rowptr,
+                                                                const int32_t* __restrict__ col,
+                                                                const T* __restrict__ val, int64_t n_rows, DiaOffsets o,
+                                                                T* __restrict__ dia_val) {
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK)
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+      const int d = dia_slot(o, (int)((int64_t)col[p] - r));
+      if (d >= 0) dia_val[(int64_t)d * n_rows + r] = val[p];        // rows outside the valid range are never read
+    }
+}
+
+DiaOffsets dia_offsets_of(const gla_csr* p) {
+  DiaOffsets o;
+  for (int i = 0; i < GLA_DIA_MAX; ++i) o.off[i] = i < p->dia_D ? p->dia_off[i] : 0;
+  o.D = p->dia_D;
+  return o;
+}
+
+// Structure side, at plan creation: does every nonzero lie on one of <= 16 diagonals, rows in ascending order?
+int build_dia(gla_csr* p, hipStream_t st) {
+  p->dia_state = -1;
+  if (!p->sorted_input || p->long_rows || p->n_rows == 0 || p->max_row_len < 1 || p->max_row_len >= GLA_DIA_MAX)
+    return GLA_OK;
+  hipError_t e;
+#define DK(expr) do { e = (expr); if (e != hipSuccess) return -(1000 + (int)e); } while (0)
+  unsigned long long* d_u = nullptr;          // [0..1] candidate rows, [2..3] valid row range
+  DK(hipMalloc(&d_u, 4 * sizeof(unsigned long long)));
+  unsigned long long h_u[4] = {~0ull, ~0ull, 0ull, (unsigned long long)p->n_rows};
+  DK(hipMemcpyAsync(d_u, h_u, sizeof(h_u), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(dia_first_full_row_kernel, dim3(grid_for(p->n_rows)), dim3(GLA_BLOCK), 0, st, p->rowptr, p->n_rows,
+                     p->max_row_len, p->n_rows / 2, d_u);
+  DK(hipMemcpyAsync(h_u, d_u, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  DK(hipStreamSynchronize(st));
+  const unsigned long long h_first = h_u[0] != ~0ull ? h_u[0] : h_u[1];
+  if (h_first >= (unsigned long long)p->n_rows) { (void)hipFree(d_u); return GLA_OK; }
+  int32_t h_ptr[2], h_cols[GLA_DIA_MAX];
+  DK(hipMemcpy(h_ptr, p->rowptr + h_first, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  const int D = h_ptr[1] - h_ptr[0];
+  DK(hipMemcpy(h_cols, p->col + h_ptr[0], D * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int i = 0; i < D; ++i) {
+    p->dia_off[i] = (int32_t)((int64_t)h_cols[i] - (int64_t)h_first);
+    if (i > 0 && p->dia_off[i] <= p->dia_off[i - 1]) { (void)hipFree(d_u); return GLA_OK; }   // columns not ascending
+  }
+  p->dia_D = D;
+  DK(hipMalloc(&p->dia_mask, (size_t)p->n_rows * sizeof(uint16_t)));
+  hipLaunchKernelGGL(dia_verify_kernel, dim3(grid_for(p->n_rows)), dim3(GLA_BLOCK), 0, st, p->rowptr, p->col, p->n_rows,
+                     dia_offsets_of(p), p->dia_mask, d_u + 2);
+  DK(hipMemcpyAsync(h_u + 2, d_u + 2, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  DK(hipStreamSynchronize(st));
+  (void)hipFree(d_u);
+  p->dia_row_lo = (int64_t)h_u[2];
+  p->dia_row_hi = (int64_t)h_u[3];
+  if (p->dia_row_hi <= p->dia_row_lo || 2 * (p->dia_row_hi - p->dia_row_lo) < p->n_rows) {   // mostly not a stencil
+    (void)hipFree(p->dia_mask);
+    p->dia_mask = nullptr;
+    return GLA_OK;
+  }
+  p->dia_state = 1;
+  return GLA_OK;
+#undef DK
+}
+
+// Value side, at gla_csr_set_values: scatter the CSR values onto their diagonals (absent entries stay 0)
+template <typename T>
+int fill_dia(gla_csr* p, hipStream_t st) {
+  if (p->dia_state != 1) return GLA_OK;
+  if (!p->dia_val) {
+    const size_t bytes = (size_t)p->dia_D * (size_t)p->n_rows * sizeof(double);
+    hipError_t e = hipMalloc(&p->dia_val, bytes);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    e = hipMemsetAsync(p->dia_val, 0, bytes, st);
+    if (e != hipSuccess) return -(1000 + (int)e);
+  }
+  hipLaunchKernelGGL((dia_scatter_kernel<T>), dim3(grid_for(p->n_rows)), dim3(GLA_BLOCK), 0, st, p->rowptr, p->col,
+                     (const T*)p->val, p->n_rows, dia_offsets_of(p), (T*)p->dia_val);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
 // rowoff16[r + t] = rowptr[r] - (first nonzero of tile t) for the rows r0 .. r1 (inclusive) of tile t
 __global__ __launch_bounds__(GLA_BLOCK) void rowoff16_kernel(const int32_t* __restrict__ rowptr,
                                                              const int4* __restrict__ tile_info, int n_tiles,
@@ -394,13 +523,6 @@ done:
 #undef PKG
 }
 
-inline unsigned grid_for(int64_t work, int64_t per_block = GLA_BLOCK, int64_t cap = 256 * 16) {
-  int64_t b = (work + per_block - 1) / per_block;
-  if (b < 1) b = 1;
-  if (b > cap) b = cap;
-  return (unsigned)b;
-}
-
 }  // namespace
 
 int gla_sort_rows_stable(int64_t nnz, int64_t n_rows, const int64_t* row, int32_t* perm_out, uint32_t* keys_sorted,
@@ -443,6 +565,7 @@ int gla_set_option(const char* name, int64_t value) {
   if (!strcmp(name, "spmv_variant")) { g_tuning.spmv_variant = (int)value; return GLA_OK; }
   if (!strcmp(name, "xcd_chunk")) { if (value < 0) return GLA_ERR_INVALID_ARG; g_tuning.xcd_chunk = (int)value; return GLA_OK; }
   if (!strcmp(name, "col16")) { g_tuning.col16 = value ? 1 : 0; return GLA_OK; }
+  if (!strcmp(name, "dia")) { g_tuning.dia = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "compress")) { g_tuning.compress = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "spmm_variant")) { g_tuning.spmm_variant = (int)value; return GLA_OK; }
   if (!strcmp(name, "tile_nnz")) {
@@ -479,6 +602,8 @@ int gla_csr_destroy(gla_csr_t p) {
   if (p->col16) (void)hipFree(p->col16);
   if (p->col16_wide) (void)hipFree(p->col16_wide);
   if (p->rowoff16) (void)hipFree(p->rowoff16);
+  if (p->dia_mask) (void)hipFree(p->dia_mask);
+  if (p->dia_val) (void)hipFree(p->dia_val);
   if (p->vcode) (void)hipFree(p->vcode);
   if (p->vdict) (void)hipFree(p->vdict);
   delete p;
@@ -566,6 +691,10 @@ int gla_csr_create_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const i
     rc = build_col16(p, st);              // int16 tile-relative columns for the K = 1 kernels (when the band fits)
     if (rc) goto fail;
   }
+  if (g_tuning.dia) {
+    rc = build_dia(p, st);                // stencil matrices: diagonal layout for the K = 1 kernels
+    if (rc) goto fail;
+  }
   (void)hipFree(d_flags);
   if (keys_sorted) (void)hipFree(keys_sorted);
   *out = p;
@@ -591,6 +720,10 @@ int gla_csr_set_values(gla_csr_t p, const void* edge_val, int64_t stride, int dt
   GLA_LAUNCH_CHECK();
   p->val_dtype = dtype;
   p->packed = 0;
+  {
+    const int rc = dtype == GLA_F64 ? fill_dia<double>(p, st) : fill_dia<float>(p, st);
+    if (rc) return rc;
+  }
   if (g_tuning.compress)
     return dtype == GLA_F64 ? build_packed<double, uint64_t>(p, st) : build_packed<float, uint32_t>(p, st);
   return GLA_OK;
@@ -603,6 +736,10 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->n_tiles = p->n_tiles; info->tile_nnz = p->tile_nnz; info->lds_elems = p->lds_elems;
   info->long_rows = p->long_rows; info->val_dtype = p->val_dtype; info->packed = p->packed;
   info->col16 = (p->col16_state == 1 && g_tuning.col16) ? 1 : 0; info->col16_wide_tiles = p->col16_wide_tiles;
+  info->dia = (p->dia_state == 1 && g_tuning.dia) ? p->dia_D : 0;
+  info->reserved_ = 0;
+  info->dia_row_lo = info->dia ? p->dia_row_lo : 0;
+  info->dia_row_hi = info->dia ? p->dia_row_hi : 0;
   return GLA_OK;
 }
 
@@ -657,8 +794,19 @@ int gla_csr_classify_tiles(gla_csr_t p, int64_t col_limit, gla_stream_t stream, 
     e = hipMemcpyAsync(p->tile_lists, h_list, 2 * (size_t)nt * sizeof(int32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) rc = -(1000 + (int)e);
-    delete[] h_list;
     p->n_interior = ni; p->n_boundary = nb;
+    p->int_row_lo = p->int_row_hi = -1;             // rows of the interior tiles when they are one contiguous run
+    if (ni > 0 && h_list[ni - 1] - h_list[0] + 1 == ni && rc == GLA_OK && p->tile_row && p->dia_state == 1) {
+      int32_t r_lo = 0, r_hi = 0;
+      if (hipMemcpy(&r_lo, p->tile_row + h_list[0], sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess &&
+          hipMemcpy(&r_hi, p->tile_row + h_list[ni - 1] + 1, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+        p->int_row_lo = r_lo;
+        p->int_row_hi = r_hi;
+      } else {
+        (void)hipGetLastError();                    // leave no pending error behind: the CSR kernels take the tiles
+      }
+    }
+    delete[] h_list;
     if (n_interior) *n_interior = ni;
     if (n_boundary) *n_boundary = nb;
   }

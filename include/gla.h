@@ -56,7 +56,10 @@ int gla_version(void);
  * default: plans created afterwards also keep the columns as int16 offsets from the first row of the nonzero's row
  * tile (and the row offsets as uint16 relative to the tile's first nonzero), and the K = 1 kernels read those 2 bytes
  * instead of the 4-byte column / row pointer; tiles with a column outside that range -- halo columns of a row-block
- * partition -- are read as int32; results are bit-identical), "xcd_chunk",
+ * partition -- are read as int32; results are bit-identical), "dia" (1, the default: when every nonzero of a
+ * row-sorted matrix lies on one of <= 16 diagonals col - row -- 5-point, 9-point stencils -- the values are also kept
+ * diagonal-major and the K = 1 kernels stream them with NO index stream at all, x[row + offset] being a coalesced
+ * load; same products, same summation order: bit-identical), "xcd_chunk",
  * "spmm_variant" (A/B knobs). */
 int gla_set_option(const char* name, int64_t value);
 const char* gla_error_string(int code);
@@ -86,6 +89,10 @@ typedef struct {
   int32_t packed;           /* 1: the 3-byte-per-nonzero packed stream is in use for K = 1 (option "compress") */
   int32_t col16;            /* 1: int16 tile-relative columns are in use for K = 1 (option "col16") */
   int32_t col16_wide_tiles; /* row tiles that keep int32 columns (a column out of int16 range) */
+  int32_t dia;              /* > 0: the diagonal (stencil) layout with this many diagonals is in use for K = 1 */
+  int32_t reserved_;
+  int64_t dia_row_lo, dia_row_hi;   /* rows [lo, hi) that fit the diagonal set (all rows on one GPU; a row block's
+                                     * halo rows at either end do not and stay on the CSR kernels) */
 } gla_csr_info_t;
 int gla_csr_info(gla_csr_t plan, gla_csr_info_t* info_host);
 

@@ -50,6 +50,16 @@ def _worker(rank, world, port, overlap, q):
         jac = RowBlockJacobi(ei_l, ev_l, n, lo, hi, overlap=overlap)
         x_loc = jac.forward(6, torch.stack([diag[lo:hi], B[lo:hi], X[lo:hi]], 1), g)[:, 0, :]
         assert torch.equal(x_loc, x_ref[lo:hi]), "jacobi"
+        # K = 1 (the bench configuration): interior tiles may run on the diagonal (stencil) kernel, boundary tiles on
+        # the CSR kernel -- together still the single-rank result, bit for bit
+        x1_ref = gla.JacobiGNN.JacobiGNN()(6, torch.stack([diag[:, 0], B[:, 0], X[:, 0]], 1), ei, ea, g)
+        x1_loc = jac.forward(6, torch.stack([diag[lo:hi, 0], B[lo:hi, 0], X[lo:hi, 0]], 1), g)
+        assert torch.equal(x1_loc, x1_ref[lo:hi]), "jacobi K=1"
+        info = jac.plan.info                                   # the block's own rows are stencil rows, its halo rows not
+        assert info.dia == 5 or hi - lo <= 2 * Nx, info.dia
+        if info.dia:
+            assert info.dia_row_lo == (Nx if rank > 0 else 0), (rank, info.dia_row_lo)
+            assert info.dia_row_hi == (hi - lo) - (Nx if rank < world - 1 else 0), (rank, info.dia_row_hi)
         if overlap:                                            # a one-line block has boundary tiles only
             assert jac.plan.n_boundary > 0 and (jac.plan.n_interior > 0 or lines[rank + 1] - lines[rank] <= 2)
         ch = RowBlockCheby(ei_l, ev_l, n, lo, hi, overlap=overlap)

@@ -709,6 +709,57 @@ def test_full_size_config4_8192():
     eq(r, b.numpy() - A.spmm(want))
 
 
+def test_dia_layout_bit_identical():
+    """Stencil matrices (every nonzero on one of <= 15 diagonals, rows in ascending order) get the diagonal layout
+    (option "dia", default): no index stream at all.  Same products in the same order: every fused K = 1 op equals the
+    CSR kernels bit for bit; matrices that are not stencils keep CSR."""
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+
+    def run_all(ei, ev, n, dtype):
+        ei_d, ev_d = d(ei), d(ev.to(dtype))
+        x = d(torch.rand(n, 1, generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(dtype))
+        b = d(torch.rand(n, 1, generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(dtype))
+        plan = gla.CsrPlan(ei_d, n)
+        plan.set_values(ev_d)
+        diag = torch.full((n,), -4.0, dtype=dtype, device=DEV)
+        outs = [plan.spmm(x), plan.residual(b, x), plan.jacobi_sweeps(diag, b, x, 0.7, 5)]
+        r, p, xo, p2 = (torch.empty_like(x) for _ in range(4))
+        plan.cheby_first(b, x, r, p, xo, -0.25)
+        plan.cheby_next(p, p2, r, xo, -0.25, -0.26, 0.1)
+        y, ss, _ = plan.power_step(x, nrm=torch.tensor([1.7], dtype=dtype, device=DEV))      # NRED: stays CSR
+        return plan, outs + [r, p2, xo, y, ss]
+
+    gen = torch.Generator().manual_seed(5)
+    cases = []
+    ei, ev = rp.laplacianfun_torch(300)
+    cases.append(("laplacian 300^2", ei, ev, 90000, 5))
+    ei, ev = rp.laplacianfun_torch(7, 400)                                    # narrow grid: offsets -7, -1, 0, 1, 7
+    cases.append(("laplacian 7 x 400", ei, ev, 2800, 5))
+    ei, ev = rp.heateqnfem2dfun([71, 59], [1.0, 4.0])
+    cases.append(("fem 9-point", ei, ev, 70 * 58, 9))
+    ei, ev = rp.laplacianfun_torch(40)
+    cases.append(("random values on the stencil", ei, torch.rand(ei.shape[1], 1, generator=gen, dtype=torch.float64), 1600, 5))
+    n = 5000                                                                  # not a stencil: random columns
+    k = torch.arange(n).repeat_interleave(3)
+    ei = torch.stack([k, torch.randint(0, n, (3 * n,), generator=gen)])
+    cases.append(("random graph", ei, torch.rand(3 * n, 1, generator=gen, dtype=torch.float64), n, 0))
+    ei, ev = rp.laplacianfun_torch(30)                                        # stencil, but columns descending in a row
+    flip = torch.argsort(ei[0] * 1000 - ei[1], stable=True)
+    cases.append(("descending columns", ei[:, flip], ev[flip], 900, 0))
+    for name, ei, ev, n, want_D in cases:
+        for dtype in (torch.float64, torch.float32):
+            try:
+                check(lib().gla_set_option(b"dia", 0))
+                plan_csr, ref_out = run_all(ei, ev, n, dtype)
+                assert plan_csr.info.dia == 0
+            finally:
+                check(lib().gla_set_option(b"dia", 1))
+            plan, out = run_all(ei, ev, n, dtype)
+            assert plan.info.dia == want_D, (name, plan.info.dia)
+            for a, b_ in zip(out, ref_out):
+                eq(a, b_)
+
+
 def test_col16_columns_bit_identical():
     """The default K = 1 kernels read int16 tile-relative columns (option "col16"); tiles with a far column keep
     int32.  Every fused op must give exactly the int32-column result, tile partition unchanged (also the partials)."""

@@ -54,7 +54,8 @@ def main():
             for v in variants:
                 check(lib().gla_set_option(b"spmv_variant", 0 if v >= 1000 else v))
                 check(lib().gla_set_option(b"xcd_chunk", v - 1000 if 1000 <= v < 2000 else 64))   # 1000+C: XCD chunk C
-                check(lib().gla_set_option(b"col16", 0 if v == 2000 else 1))     # 2000: default kernel, int32 columns
+                check(lib().gla_set_option(b"col16", 0 if v == 2000 else 1))     # 2000: CSR kernel, int32 columns
+                check(lib().gla_set_option(b"dia", 0 if v in (2000, 3000) else 1))   # 3000: compact CSR kernel, no DIA
                 check(lib().gla_set_option(b"compress", 1 if tnz < 0 else 0))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
