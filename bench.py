@@ -86,6 +86,8 @@ def main():
                     help="strong scaling instead of the default weak scaling: a FIXED (grid x grid) Laplacian "
                          "(BASELINE config 4: --grid 8192) is cut into N row blocks; reports scaling=strong")
     ap.add_argument("--no-optin", action="store_true", help="skip the side measurement of the opt-in packed stream")
+    ap.add_argument("--no-dia", action="store_true",
+                    help="keep the CSR kernels (compact index streams) instead of the diagonal layout for stencils")
     ap.add_argument("--no-col16", action="store_true",
                     help="read 4-byte columns (the plain CSR stream of SURVEY's byte model) instead of int16 "
                          "tile-relative columns")
@@ -124,6 +126,8 @@ def main():
         gla._lib.check(gla._lib.lib().gla_set_option(b"compress", 1))
     if args.no_col16:
         gla._lib.check(gla._lib.lib().gla_set_option(b"col16", 0))
+    if args.no_dia or args.no_col16:
+        gla._lib.check(gla._lib.lib().gla_set_option(b"dia", 0))
 
     Nx = args.n
     if args.strong:
@@ -240,7 +244,7 @@ def main():
             try:
                 tj = json.load(open(tp))
                 if tj.get("n") == args.n and int(tj.get("col16", 0)) == int(plan.info.col16) \
-                        and not bool(plan.info.packed):
+                        and int(tj.get("dia", 0)) == int(plan.info.dia) and not bool(plan.info.packed):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -249,7 +253,15 @@ def main():
                 "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "algorithmic_bytes_per_launch": B,
                 "avg_launch_us": round(t_launch * 1e6, 2)}
         info = plan.info if world == 1 else None
-        if info is not None and bool(info.col16) and not bool(info.packed):
+        if info is not None and int(info.dia) > 0 and not bool(info.packed):
+            # default layout for stencil matrices: values diagonal-major, NO index stream (a 2-byte row mask instead).
+            # `achieved` / `frac` keep SURVEY 8(d)'s CSR byte model as prescribed; `layout_*` is what the kernel really
+            # has to move: 8 D bytes of values + 2 per row + the vectors
+            Bl = (8 * int(info.dia) + 2 + 32) * n_local
+            roof.update({"kernel": "spmv_dia_kernel<double,EpiJacobi>", "layout": f"dia{int(info.dia)}",
+                         "layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
+                         "layout_frac": round(Bl / t_launch / 8e12, 4)})
+        elif info is not None and bool(info.col16) and not bool(info.packed):
             # default layout: 2-byte tile-relative columns.  `achieved` / `frac` keep SURVEY 8(d)'s CSR byte model
             # (12 B per nonzero, 4 B per row offset) as prescribed; `layout_*` is what the kernel really has to move
             # (10 B per nonzero, 2-byte tile-relative row offsets)
@@ -268,7 +280,7 @@ def main():
     # (gla_set_option("compress", 1): int16 columns + <= 256-entry value dictionary, 3 B per nonzero, bit-identical
     # results).  Reported next to the headline, never as `value`: it depends on the matrix having few distinct values.
     optin = None
-    if rank == 0 and world == 1 and not args.compress and not args.no_col16 and not args.no_optin:
+    if rank == 0 and world == 1 and not args.compress and not args.no_col16 and not args.no_dia and not args.no_optin:
         check, L = gla._lib.check, gla._lib.lib()
         try:
             check(L.gla_set_option(b"compress", 1))

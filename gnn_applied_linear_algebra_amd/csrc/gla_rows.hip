@@ -676,7 +676,8 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   }
   if constexpr (Epi::NRED == 0) {
     int64_t d_lo = -1, d_hi = -1;                 // rows the diagonal kernel may take for this launch
-    if (K == 1 && ldx == 1 && A->dia_state == 1 && A->dia_val && g_tuning.dia && g_tuning.spmv_variant == 0) {
+    if (K == 1 && ldx == 1 && A->dia_state == 1 && A->dia_val && g_tuning.dia && g_tuning.spmv_variant == 0 &&
+        !(A->packed && g_tuning.compress)) {        // an opted-in packed stream takes precedence
       if (which == 0 && A->dia_row_lo == 0 && A->dia_row_hi == A->n_rows) { d_lo = 0; d_hi = A->n_rows; }
       if (which == 1 && A->int_row_lo >= A->dia_row_lo && A->int_row_hi <= A->dia_row_hi && A->int_row_lo >= 0) {
         d_lo = A->int_row_lo;                       // interior tiles of a row block: one contiguous run of stencil rows

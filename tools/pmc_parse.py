@@ -15,6 +15,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pm
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
 col16 = int(sys.argv[4]) if len(sys.argv) > 4 else 1      # the workload ran with int16 tile-relative columns
+dia = int(sys.argv[5]) if len(sys.argv) > 5 else 5          # diagonals of the stencil layout (0: CSR kernels)
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
@@ -30,9 +31,12 @@ write_factor = 512 * 1024 / mean(c["WRITE_SIZE"])
 n, nnz = N * N, 5 * N * N - 4 * N
 alg = 12 * nnz + 4 * (n + 1) + 32 * n
 layout = (10 * nnz + 2 * (n + n // 256) + 32 * n) if col16 else alg      # int16 columns + uint16 row offsets
+if dia:
+    layout = (8 * dia + 2 + 32) * n                                        # diagonal-major values + row mask
 rd = mean(j["FETCH_SIZE"]) * 1024 * 2.0
 wr = mean(j["WRITE_SIZE"]) * 1024
-out = {"n": N, "col16": col16, "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "launches": len(j["FETCH_SIZE"]),
+out = {"n": N, "col16": col16, "dia": dia,
+       "kernel": "spmv_dia_kernel<double,EpiJacobi>" if dia else "spmv_stream_vec2_kernel<double,EpiJacobi>", "launches": len(j["FETCH_SIZE"]),
        "FETCH_SIZE_KiB": mean(j["FETCH_SIZE"]), "WRITE_SIZE_KiB": mean(j["WRITE_SIZE"]),
        "fetch_correction": 2.0, "calibration_fetch_factor_measured": round(fetch_factor, 4),
        "calibration_write_factor_measured": round(write_factor, 4),
