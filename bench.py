@@ -277,8 +277,9 @@ def main():
                          "layout_frac": round(Bl / t_launch / 8e12, 4)})
 
     # Side measurement (N = 1, default run only): the same step with the opt-in packed matrix stream
-    # (gla_set_option("compress", 1): int16 columns + <= 256-entry value dictionary, 3 B per nonzero, bit-identical
-    # results).  Reported next to the headline, never as `value`: it depends on the matrix having few distinct values.
+    # (gla_set_option("compress", 1): constant diagonals of a stencil are not streamed at all; otherwise int16 columns +
+    # <= 256-entry value dictionary, 3 B per nonzero; bit-identical results).  Reported next to the headline, never as
+    # `value`: it depends on the VALUES of the matrix (few distinct ones), not only on its structure.
     optin = None
     if rank == 0 and world == 1 and not args.compress and not args.no_col16 and not args.no_dia and not args.no_optin:
         check, L = gla._lib.check, gla._lib.lib()
@@ -297,7 +298,11 @@ def main():
                 torch.cuda.synchronize()
                 el = time.perf_counter() - t1
                 Bl = 3 * nnz_local + 2 * (n_local + int(plan_p.info.n_tiles)) + 32 * n_local
-                optin = {"option": "compress", "value": round(total_sweeps / el, 2), "unit": "sweeps/s",
+                mode = "packed CSR stream: int16 columns + value dictionary"
+                if int(plan_p.info.packed) == 2:           # stencil with constant diagonals: only the row mask is left
+                    Bl = (2 + 32) * n_local
+                    mode = "constant-diagonal stencil: no matrix stream besides a 2-byte row mask"
+                optin = {"option": "compress", "mode": mode, "value": round(total_sweeps / el, 2), "unit": "sweeps/s",
                          "us_per_sweep_whole_step": round(1e6 * el / total_sweeps, 2),
                          "bit_identical_to_default": same, "layout_bytes_per_launch": Bl}
             del plan_p, ei_p

@@ -47,6 +47,8 @@ struct gla_csr {
   int32_t dia_off[16] = {0};     // ascending offsets (host copy; passed to the kernels by value)
   uint16_t* dia_mask = nullptr;  // [n_rows] bit d set: row has an entry on diagonal d
   void* dia_val = nullptr;       // [dia_D][n_rows] values, diagonal-major (0 where the row has no entry)
+  int32_t dia_const = 0;         // 1 (option "compress"): every diagonal holds ONE value -> no value stream either
+  double dia_cval[16] = {0};     // that value per diagonal
   int64_t dia_row_lo = 0, dia_row_hi = 0;   // rows [lo, hi) fit the diagonal set (halo rows of a row block do not)
   int64_t int_row_lo = -1, int_row_hi = -1; // rows of the interior tiles when they form one contiguous run
 };

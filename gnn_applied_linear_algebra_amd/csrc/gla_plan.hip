@@ -401,6 +401,48 @@ int build_dia(gla_csr* p, hipStream_t st) {
 #undef DK
 }
 
+// Option "compress" on a stencil plan: is every diagonal constant (bit pattern) over the rows that have it?
+template <typename T, typename U>
+__global__ __launch_bounds__(GLA_BLOCK) void dia_minmax_kernel(const T* __restrict__ dia_val,
+                                                               const uint16_t* __restrict__ mask, int64_t n_rows, int D,
+                                                               unsigned long long* __restrict__ mm) {   // [D][2]
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK) {
+    const unsigned m = mask[r];
+    for (int d = 0; d < D; ++d) {
+      if (!((m >> d) & 1u)) continue;
+      const unsigned long long b = (unsigned long long)__builtin_bit_cast(U, dia_val[(int64_t)d * n_rows + r]);
+      if (b < mm[2 * d]) atomicMin(mm + 2 * d, b);
+      if (b > mm[2 * d + 1]) atomicMax(mm + 2 * d + 1, b);
+    }
+  }
+}
+
+template <typename T, typename U>
+int detect_dia_const(gla_csr* p, hipStream_t st) {
+  p->dia_const = 0;
+  if (p->dia_state != 1 || !p->dia_val || p->dia_row_lo != 0 || p->dia_row_hi != p->n_rows) return GLA_OK;
+  unsigned long long h_mm[2 * GLA_DIA_MAX];
+  for (int d = 0; d < GLA_DIA_MAX; ++d) { h_mm[2 * d] = ~0ull; h_mm[2 * d + 1] = 0ull; }
+  unsigned long long* d_mm = nullptr;
+  hipError_t e = hipMalloc(&d_mm, sizeof(h_mm));
+  if (e != hipSuccess) return -(1000 + (int)e);
+  e = hipMemcpyAsync(d_mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((dia_minmax_kernel<T, U>), dim3(grid_for(p->n_rows)), dim3(GLA_BLOCK), 0, st,
+                       (const T*)p->dia_val, p->dia_mask, p->n_rows, p->dia_D, d_mm);
+    e = hipMemcpyAsync(h_mm, d_mm, sizeof(h_mm), hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_mm);
+  if (e != hipSuccess) return -(1000 + (int)e);
+  for (int d = 0; d < p->dia_D; ++d) {
+    if (h_mm[2 * d] != h_mm[2 * d + 1]) return GLA_OK;            // varies along the diagonal (or diagonal empty)
+    p->dia_cval[d] = (double)__builtin_bit_cast(T, (U)h_mm[2 * d]);
+  }
+  p->dia_const = 1;
+  return GLA_OK;
+}
+
 // Value side, at gla_csr_set_values: scatter the CSR values onto their diagonals (absent entries stay 0)
 template <typename T>
 int fill_dia(gla_csr* p, hipStream_t st) {
@@ -724,8 +766,13 @@ int gla_csr_set_values(gla_csr_t p, const void* edge_val, int64_t stride, int dt
     const int rc = dtype == GLA_F64 ? fill_dia<double>(p, st) : fill_dia<float>(p, st);
     if (rc) return rc;
   }
-  if (g_tuning.compress)
+  p->dia_const = 0;
+  if (g_tuning.compress) {
+    const int rc = dtype == GLA_F64 ? detect_dia_const<double, uint64_t>(p, st) : detect_dia_const<float, uint32_t>(p, st);
+    if (rc) return rc;
+    if (p->dia_const) return GLA_OK;                  // matrix-free stencil: nothing else to build
     return dtype == GLA_F64 ? build_packed<double, uint64_t>(p, st) : build_packed<float, uint32_t>(p, st);
+  }
   return GLA_OK;
 }
 
@@ -734,7 +781,7 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->n_rows = p->n_rows; info->n_cols = p->n_cols; info->nnz = p->nnz;
   info->sorted_input = p->sorted_input; info->max_row_len = p->max_row_len;
   info->n_tiles = p->n_tiles; info->tile_nnz = p->tile_nnz; info->lds_elems = p->lds_elems;
-  info->long_rows = p->long_rows; info->val_dtype = p->val_dtype; info->packed = p->packed;
+  info->long_rows = p->long_rows; info->val_dtype = p->val_dtype; info->packed = (p->dia_const && g_tuning.compress) ? 2 : p->packed;
   info->col16 = (p->col16_state == 1 && g_tuning.col16) ? 1 : 0; info->col16_wide_tiles = p->col16_wide_tiles;
   info->dia = (p->dia_state == 1 && g_tuning.dia) ? p->dia_D : 0;
   info->reserved_ = 0;

@@ -440,9 +440,10 @@ struct DiaView {
   int32_t D;
   int64_t n_rows, n_cols;
   int64_t row_lo, row_hi;     // rows handled by this launch
+  double cval[GLA_DIA_MAX];   // CONSTV kernels: the one value of each diagonal (option "compress")
 };
 
-template <typename T, class Epi, int DMAX>
+template <typename T, class Epi, int DMAX, bool CONSTV = false>
 __global__ __launch_bounds__(GLA_BLOCK) void spmv_dia_kernel(DiaView dv, const T* __restrict__ x, TileMap tm, Epi epi) {
   const int blk = map_tile(tm);                  // row blocks of 256 take the same XCD turns as the CSR tiles
   if (blk < 0) return;
@@ -456,7 +457,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_dia_kernel(DiaView dv, const T
 #pragma unroll
   for (int d = 0; d < DMAX; ++d) {               // every lane issues every load (absent diagonals: clamped, unused)
     const int dd = min(d, dv.D - 1);
-    v[d] = val[(int64_t)dd * dv.n_rows + r];
+    if constexpr (CONSTV) v[d] = (T)dv.cval[dd];            // constant diagonals: the stencil is matrix-free
+    else v[d] = val[(int64_t)dd * dv.n_rows + r];
     const int64_t c = min(max(r + (int64_t)dv.off[dd], (int64_t)0), dv.n_cols - 1);
     xv[d] = epi.gx(x[c], gxs);
   }
@@ -676,8 +678,9 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   }
   if constexpr (Epi::NRED == 0) {
     int64_t d_lo = -1, d_hi = -1;                 // rows the diagonal kernel may take for this launch
+    const bool constv = A->dia_const && g_tuning.compress;      // opted-in: constant diagonals, no value stream
     if (K == 1 && ldx == 1 && A->dia_state == 1 && A->dia_val && g_tuning.dia && g_tuning.spmv_variant == 0 &&
-        !(A->packed && g_tuning.compress)) {        // an opted-in packed stream takes precedence
+        (constv || !(A->packed && g_tuning.compress))) {        // an opted-in packed CSR stream takes precedence
       if (which == 0 && A->dia_row_lo == 0 && A->dia_row_hi == A->n_rows) { d_lo = 0; d_hi = A->n_rows; }
       if (which == 1 && A->int_row_lo >= A->dia_row_lo && A->int_row_hi <= A->dia_row_hi && A->int_row_lo >= 0) {
         d_lo = A->int_row_lo;                       // interior tiles of a row block: one contiguous run of stencil rows
@@ -701,7 +704,12 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
       bm.n_tiles = (int)((d_hi - d_lo + GLA_BLOCK - 1) / GLA_BLOCK);
       set_tile_mapping(bm);
       const dim3 dgrid((unsigned)(bm.tiles_per_xcd * GLA_XCDS)), dblock(GLA_BLOCK);
-      if (A->dia_D <= 5)
+      for (int i = 0; i < GLA_DIA_MAX; ++i) dv.cval[i] = A->dia_cval[i];
+      if (constv && which == 0 && A->dia_D <= 5)
+        hipLaunchKernelGGL((spmv_dia_kernel<T, Epi, 5, true>), dgrid, dblock, 0, st, dv, X, bm, epi);
+      else if (constv && which == 0 && A->dia_D <= 9)
+        hipLaunchKernelGGL((spmv_dia_kernel<T, Epi, 9, true>), dgrid, dblock, 0, st, dv, X, bm, epi);
+      else if (A->dia_D <= 5)
         hipLaunchKernelGGL((spmv_dia_kernel<T, Epi, 5>), dgrid, dblock, 0, st, dv, X, bm, epi);
       else if (A->dia_D <= 9)
         hipLaunchKernelGGL((spmv_dia_kernel<T, Epi, 9>), dgrid, dblock, 0, st, dv, X, bm, epi);

@@ -50,7 +50,8 @@ enum {
  * gla_segment_stats, gla_edge_dot, gla_mlp_relu3 / gla_mlp_work_bytes). */
 int gla_version(void);
 /* Tuning knobs (process-wide): "spmv_variant" (kernel flavour for K = 1), "tile_nnz" (target nnz per row
- * tile for plans created afterwards; 0 = automatic), "compress" (1: gla_csr_set_values additionally builds a packed
+ * tile for plans created afterwards; 0 = automatic), "compress" (1: value-dependent compression at gla_csr_set_values:
+ * a stencil plan whose diagonals are constant needs no value stream at all; otherwise it additionally builds a packed
  * stream -- int16 tile-relative columns + a <= 256-entry value dictionary -- when the matrix allows it; the K = 1
  * kernels then read 3 bytes per nonzero instead of 12, results are bit-identical; default 0), "col16" (1, the
  * default: plans created afterwards also keep the columns as int16 offsets from the first row of the nonzero's row
@@ -86,7 +87,8 @@ typedef struct {
   int32_t lds_elems;        /* staged nnz capacity per workgroup */
   int32_t long_rows;        /* 1: some row exceeds the LDS tile -> CSR-vector kernels are used */
   int32_t val_dtype;        /* GLA_F32 / GLA_F64 / -1 */
-  int32_t packed;           /* 1: the 3-byte-per-nonzero packed stream is in use for K = 1 (option "compress") */
+  int32_t packed;           /* option "compress": 1 = the 3-byte-per-nonzero packed CSR stream is in use for K = 1;
+                             * 2 = stencil with constant diagonals: no matrix stream at all besides a 2-byte row mask */
   int32_t col16;            /* 1: int16 tile-relative columns are in use for K = 1 (option "col16") */
   int32_t col16_wide_tiles; /* row tiles that keep int32 columns (a column out of int16 range) */
   int32_t dia;              /* > 0: the diagonal (stencil) layout with this many diagonals is in use for K = 1 */

@@ -860,18 +860,23 @@ def test_packed_stream_bit_identical():
     cases.append(("wide band", ei, torch.ones(2 * n, 1, dtype=torch.float64), n, False))
     for name, ei, ev, n, want_packed in cases:
         for dtype in (torch.float64, torch.float32):
-            check(lib().gla_set_option(b"compress", 0))
-            _, ref_out = run_all(ei, ev, n, dtype)
-            try:
-                check(lib().gla_set_option(b"compress", 1))
-                plan, out = run_all(ei, ev, n, dtype)
-            finally:
+            for dia in (1, 0):          # 1: stencils with constant diagonals go matrix-free (packed == 2); 0: packed CSR
                 check(lib().gla_set_option(b"compress", 0))
-            assert bool(plan.info.packed) == want_packed, (name, dtype)
-            for a, b_ in zip(out[:-1], ref_out[:-1]):
-                eq(a, b_)
-            # the sum of squares is grouped by row tile, and packed plans use other tiles: equal to rounding only
-            close(out[-1], ref_out[-1], rtol=1e-12 if dtype == torch.float64 else 1e-5)
+                check(lib().gla_set_option(b"dia", dia))
+                try:
+                    _, ref_out = run_all(ei, ev, n, dtype)
+                    check(lib().gla_set_option(b"compress", 1))
+                    plan, out = run_all(ei, ev, n, dtype)
+                finally:
+                    check(lib().gla_set_option(b"compress", 0))
+                    check(lib().gla_set_option(b"dia", 1))
+                assert bool(plan.info.packed) == want_packed, (name, dtype, dia)
+                if want_packed:
+                    assert plan.info.packed == (2 if dia else 1), (name, dtype, dia, plan.info.packed)
+                for a, b_ in zip(out[:-1], ref_out[:-1]):
+                    eq(a, b_)
+                # the sum of squares is grouped by row tile, and packed plans use other tiles: equal to rounding only
+                close(out[-1], ref_out[-1], rtol=1e-12 if dtype == torch.float64 else 1e-5)
 
 
 def test_reference_demo_self_checks():
