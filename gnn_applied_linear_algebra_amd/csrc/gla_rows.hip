@@ -679,6 +679,9 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   if constexpr (Epi::NRED == 0) {
     int64_t d_lo = -1, d_hi = -1;                 // rows the diagonal kernel may take for this launch
     const bool constv = A->dia_const && g_tuning.compress;      // opted-in: constant diagonals, no value stream
+    // (a (row, vector)-lane version of this kernel for K > 1 lost to the CSR tile kernel in a same-process A/B at
+    // K = 16 -- 1268 vs 1091 us per SpMM: with K-wide rows the tile's LDS-staged matrix and 256-row blocks matter more
+    // than the missing index stream -- so K > 1 stays on the CSR kernels)
     if (K == 1 && ldx == 1 && A->dia_state == 1 && A->dia_val && g_tuning.dia && g_tuning.spmv_variant == 0 &&
         (constv || !(A->packed && g_tuning.compress))) {        // an opted-in packed CSR stream takes precedence
       if (which == 0 && A->dia_row_lo == 0 && A->dia_row_hi == A->n_rows) { d_lo = 0; d_hi = A->n_rows; }

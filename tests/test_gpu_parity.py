@@ -746,18 +746,36 @@ def test_dia_layout_bit_identical():
     ei, ev = rp.laplacianfun_torch(30)                                        # stencil, but columns descending in a row
     flip = torch.argsort(ei[0] * 1000 - ei[1], stable=True)
     cases.append(("descending columns", ei[:, flip], ev[flip], 900, 0))
+    def run_multi(ei, ev, n, dtype, K):
+        """the K > 1 ops (they stay on the CSR kernels whatever the option says)"""
+        plan = gla.CsrPlan(d(ei), n)
+        plan.set_values(d(ev.to(dtype)))
+        g2 = torch.Generator().manual_seed(3 + K)
+        X = d(torch.rand(n, K, generator=g2, dtype=torch.float64).to(dtype))
+        B = d(torch.rand(n, K, generator=g2, dtype=torch.float64).to(dtype))
+        diag = torch.full((n,), -4.0, dtype=dtype, device=DEV)
+        outs = [plan.spmm(X), plan.residual(B, X), plan.jacobi_sweeps(diag, B, X, 0.7, 3)]
+        r, p, xo, p2 = (torch.empty_like(X) for _ in range(4))
+        plan.cheby_first(B, X, r, p, xo, -0.25)
+        plan.cheby_next(p, p2, r, xo, -0.25, -0.26, 0.1)
+        return outs + [r, p2, xo]
+
     for name, ei, ev, n, want_D in cases:
         for dtype in (torch.float64, torch.float32):
             try:
                 check(lib().gla_set_option(b"dia", 0))
                 plan_csr, ref_out = run_all(ei, ev, n, dtype)
                 assert plan_csr.info.dia == 0
+                ref_multi = {K: run_multi(ei, ev, n, dtype, K) for K in (2, 6, 16, 20)}
             finally:
                 check(lib().gla_set_option(b"dia", 1))
             plan, out = run_all(ei, ev, n, dtype)
             assert plan.info.dia == want_D, (name, plan.info.dia)
             for a, b_ in zip(out, ref_out):
                 eq(a, b_)
+            for K, ref in ref_multi.items():
+                for a, b_ in zip(run_multi(ei, ev, n, dtype, K), ref):
+                    eq(a, b_)
 
 
 def test_col16_columns_bit_identical():

@@ -33,12 +33,15 @@ ops = {
 }
 res = {}
 chunks = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [64]
+dias = [1, 0] if "--dia-ab" in sys.argv else [1]
 for rnd in range(6):
   for ch in chunks:
+   for dia in dias:
     check(lib().gla_set_option(b"xcd_chunk", ch))
+    check(lib().gla_set_option(b"dia", dia))
     for tnz in tiles:
         for name0, (fn, nb) in ops.items():
-            name = f"{name0}/C{ch}"
+            name = f"{name0}/C{ch}" + ("" if len(dias) == 1 else f"/dia{dia}")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(plans[tnz])
