@@ -304,8 +304,29 @@ struct DiaOffsets { int32_t off[GLA_DIA_MAX]; int32_t D; };
 __global__ __launch_bounds__(GLA_BLOCK) void dia_first_full_row_kernel(const int32_t* __restrict__ rowptr, int64_t n_rows,
                                                                        int max_len, int64_t from,
                                                                        unsigned long long* first) {
+  // per-thread minima, then ONE atomic pair per workgroup (an atomic per matching row serialises on two addresses:
+  // 190 ms at 16.8 M rows)
+  unsigned long long lo[2] = {~0ull, ~0ull};
   for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK)
-    if (rowptr[r + 1] - rowptr[r] == max_len) atomicMin(first + (r >= from ? 0 : 1), (unsigned long long)r);
+    if (rowptr[r + 1] - rowptr[r] == max_len) {
+      const int w = r >= from ? 0 : 1;
+      if ((unsigned long long)r < lo[w]) lo[w] = (unsigned long long)r;
+    }
+  __shared__ unsigned long long smin[2][GLA_BLOCK];
+  smin[0][threadIdx.x] = lo[0];
+  smin[1][threadIdx.x] = lo[1];
+  __syncthreads();
+  for (int st = GLA_BLOCK / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      smin[0][threadIdx.x] = min(smin[0][threadIdx.x], smin[0][threadIdx.x + st]);
+      smin[1][threadIdx.x] = min(smin[1][threadIdx.x], smin[1][threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (smin[0][0] != ~0ull) atomicMin(first, smin[0][0]);
+    if (smin[1][0] != ~0ull) atomicMin(first + 1, smin[1][0]);
+  }
 }
 
 __device__ __forceinline__ int dia_slot(const DiaOffsets& o, int off) {
