@@ -342,6 +342,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void dia_verify_kernel(const int32_t* __
                                                                const int32_t* __restrict__ col, int64_t n_rows,
                                                                DiaOffsets o, uint16_t* __restrict__ mask,
                                                                unsigned long long* range) {
+  unsigned long long lo = 0, hi = ~0ull;          // this thread's contribution to [range[0], range[1])
   for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK) {
     unsigned m = 0;
     int last = -1, bad = 0;
@@ -353,9 +354,25 @@ __global__ __launch_bounds__(GLA_BLOCK) void dia_verify_kernel(const int32_t* __
     }
     mask[r] = bad ? (uint16_t)0xFFFF : (uint16_t)m;
     if (bad) {
-      if (r < n_rows / 2) atomicMax(range, (unsigned long long)(r + 1));
-      else atomicMin(range + 1, (unsigned long long)r);
+      if (r < n_rows / 2) lo = max(lo, (unsigned long long)(r + 1));
+      else hi = min(hi, (unsigned long long)r);
     }
+  }
+  // one atomic pair per workgroup (a non-stencil matrix fails on almost every row)
+  __shared__ unsigned long long slo[GLA_BLOCK], shi[GLA_BLOCK];
+  slo[threadIdx.x] = lo;
+  shi[threadIdx.x] = hi;
+  __syncthreads();
+  for (int st = GLA_BLOCK / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      slo[threadIdx.x] = max(slo[threadIdx.x], slo[threadIdx.x + st]);
+      shi[threadIdx.x] = min(shi[threadIdx.x], shi[threadIdx.x + st]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (slo[0] != 0) atomicMax(range, slo[0]);
+    if (shi[0] != ~0ull) atomicMin(range + 1, shi[0]);
   }
 }
 
