@@ -441,14 +441,19 @@ struct DiaView {
   int64_t n_rows, n_cols;
   int64_t row_lo, row_hi;     // rows handled by this launch
   double cval[GLA_DIA_MAX];   // CONSTV kernels: the one value of each diagonal (option "compress")
+  int64_t part_off;           // reducing epilogues: this launch's row blocks write partials[part_off + block]
 };
 
 template <typename T, class Epi, int DMAX, bool CONSTV = false>
 __global__ __launch_bounds__(GLA_BLOCK) void spmv_dia_kernel(DiaView dv, const T* __restrict__ x, TileMap tm, Epi epi) {
   const int blk = map_tile(tm);                  // row blocks of 256 take the same XCD turns as the CSR tiles
   if (blk < 0) return;
-  const int64_t r = dv.row_lo + (int64_t)blk * GLA_BLOCK + threadIdx.x;
-  if (r >= dv.row_hi) return;
+  const int64_t r_raw = dv.row_lo + (int64_t)blk * GLA_BLOCK + threadIdx.x;
+  const bool live = r_raw < dv.row_hi;
+  if constexpr (Epi::NRED == 0) {
+    if (!live) return;
+  }
+  const int64_t r = live ? r_raw : dv.row_hi - 1;       // reducing epilogues keep every lane for the block sum
   const T* __restrict__ val = static_cast<const T*>(dv.val);
   const unsigned m = dv.mask[r];
   const auto pre = epi.load(r, 0);
@@ -468,7 +473,15 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_dia_kernel(DiaView dv, const T
     const T nxt = acc + v[d] * xv[d];
     acc = ((m >> d) & 1u) ? nxt : acc;
   }
-  epi.apply(r, 0, acc, pre);
+  if (live) epi.apply(r, 0, acc, pre);
+  if constexpr (Epi::NRED > 0) {                 // fixed-order workgroup sum -> partials[part_off + block]
+    __shared__ T wred[GLA_BLOCK / 64];
+    T red = live ? epi.redv(acc, pre) : T(0);
+    red = wave_sum(red);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = red;
+    __syncthreads();
+    if (threadIdx.x == 0) epi.partials_ptr()[dv.part_off + blk] = ((wred[0] + wred[1]) + wred[2]) + wred[3];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -676,7 +689,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
     GLA_LAUNCH_CHECK();
     return GLA_OK;
   }
-  if constexpr (Epi::NRED == 0) {
+  {
     int64_t d_lo = -1, d_hi = -1;                 // rows the diagonal kernel may take for this launch
     const bool constv = A->dia_const && g_tuning.compress;      // opted-in: constant diagonals, no value stream
     // (a (row, vector)-lane version of this kernel for K > 1 lost to the CSR tile kernel in a same-process A/B at
@@ -700,6 +713,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
       dv.n_cols = A->n_cols;
       dv.row_lo = d_lo;
       dv.row_hi = d_hi;
+      dv.part_off = A->n_tiles;                     // CSR tiles own partials [0, n_tiles), row blocks the rest
       TileMap bm;
       bm.tile_row = nullptr;
       bm.tile_info = nullptr;
@@ -929,9 +943,14 @@ int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, vo
   })
 }
 
+static inline int64_t power_partials(const gla_csr* A) {
+  return (int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) + (A->n_rows + GLA_BLOCK - 1) / GLA_BLOCK;
+}
+
 int64_t gla_power_work_bytes(gla_csr_t A, int K, int dtype) {
-  if (!A || K < 1) return -1;      // tile partials [n_tiles, K] + second-stage partials [DOT_BLOCKS_MAX, K]
-  return ((int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) + DOT_BLOCKS_MAX) * K * (dtype == GLA_F64 ? 8 : 4);
+  if (!A || K < 1) return -1;      // partials of the CSR tiles [n_tiles, K] and of the diagonal kernel's row blocks
+                                   // [ceil(n_rows / 256), K], then the second-stage partials [DOT_BLOCKS_MAX, K]
+  return (power_partials(A) + DOT_BLOCKS_MAX) * K * (dtype == GLA_F64 ? 8 : 4);
 }
 
 int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, const void* nrm_in,
@@ -945,15 +964,15 @@ int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, co
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = dtype == GLA_F64 ? 8 : 4;
   if (which != 2)          // boundary launches add to the partials the interior launch already zeroed
-    GLA_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)(A->n_tiles > 0 ? A->n_tiles : 1) * K * esz, st));
+    GLA_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)power_partials(A) * K * esz, st));
   GLA_DISPATCH(dtype, {
     EpiPower<T> epi{(T*)Y, ldy, (const T*)nrm_in, (const T*)rnrm_in, (T*)work};
     rc = launch_rows<T>(A, K, (const T*)X, ldx, epi, which, st);
     if (rc) return rc;
     if (sumsq_out && which != 1) {     // column sums of the tile partials once every tile has contributed
       T* tile_part = (T*)work;
-      return launch_col_dot<T>(A->n_tiles, K, tile_part, K, (const T*)nullptr, K, (T*)sumsq_out,
-                               tile_part + (int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) * K, st);
+      return launch_col_dot<T>(power_partials(A), K, tile_part, K, (const T*)nullptr, K, (T*)sumsq_out,
+                               tile_part + power_partials(A) * K, st);
     }
     return GLA_OK;
   })

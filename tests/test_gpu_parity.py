@@ -726,7 +726,7 @@ def test_dia_layout_bit_identical():
         r, p, xo, p2 = (torch.empty_like(x) for _ in range(4))
         plan.cheby_first(b, x, r, p, xo, -0.25)
         plan.cheby_next(p, p2, r, xo, -0.25, -0.26, 0.1)
-        y, ss, _ = plan.power_step(x, nrm=torch.tensor([1.7], dtype=dtype, device=DEV))      # NRED: stays CSR
+        y, ss, _ = plan.power_step(x, nrm=torch.tensor([1.7], dtype=dtype, device=DEV))
         return plan, outs + [r, p2, xo, y, ss]
 
     gen = torch.Generator().manual_seed(5)
@@ -771,8 +771,10 @@ def test_dia_layout_bit_identical():
                 check(lib().gla_set_option(b"dia", 1))
             plan, out = run_all(ei, ev, n, dtype)
             assert plan.info.dia == want_D, (name, plan.info.dia)
-            for a, b_ in zip(out, ref_out):
+            for a, b_ in zip(out[:-1], ref_out[:-1]):
                 eq(a, b_)
+            # the fused power step's sum of squares is grouped by 256-row blocks here and by row tiles there
+            close(out[-1], ref_out[-1], rtol=1e-12 if dtype == torch.float64 else 1e-5)
             for K, ref in ref_multi.items():
                 for a, b_ in zip(run_multi(ei, ev, n, dtype, K), ref):
                     eq(a, b_)
