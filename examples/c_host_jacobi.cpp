@@ -86,9 +86,10 @@ int main(int argc, char** argv) {
   for (int64_t k = 0; k < n; ++k) bad += std::memcmp(&cur[k], &got[k], sizeof(double)) != 0;
   gla_csr_info_t info;
   GLA_OK_(gla_csr_info(A, &info));
-  std::printf("N=%lld n=%lld nnz=%lld tiles=%d col16=%d  %d sweeps in %.3f ms (%.1f us/sweep)  mismatching values: %lld\n",
-              (long long)N, (long long)n, (long long)nnz, info.n_tiles, info.col16, sweeps, ms, 1e3 * ms / sweeps,
-              (long long)bad);
+  std::printf("N=%lld n=%lld nnz=%lld tiles=%d col16=%d diagonals=%d  %d sweeps in %.3f ms (%.1f us/sweep)  "
+              "mismatching values: %lld\n",
+              (long long)N, (long long)n, (long long)nnz, info.n_tiles, info.col16, info.dia, sweeps, ms,
+              1e3 * ms / sweeps, (long long)bad);
   gla_csr_destroy(A);
   for (void* q : {(void*)d_row, (void*)d_col, (void*)d_val, (void*)d_diag, (void*)d_b, (void*)d_x, (void*)d_out,
                   (void*)d_tmp})
