@@ -5,6 +5,7 @@
 // done once per graph: validate indices, stable-sort by row if needed (edge order is preserved inside a
 // row so that row sums keep the reference's summation order), build rowptr, measure the longest row and
 // cut the rows into tiles of ~tile_nnz nonzeros for the CSR-stream kernels.
+#include <cstdlib>
 #include <cstring>
 #include "gla_internal.h"
 #include <rocprim/device/device_radix_sort.hpp>
@@ -654,6 +655,31 @@ int gla_set_option(const char* name, int64_t value) {
   }
   return GLA_ERR_INVALID_ARG;
 }
+
+}  // extern "C"
+
+namespace {
+// GLA_OPTIONS="dia=0,col16=0,compress=1": initial option values from the environment (read once at load time), so a
+// whole application or test run can be put on another layout without code changes
+struct EnvOptions {
+  EnvOptions() {
+    const char* env = getenv("GLA_OPTIONS");
+    if (!env) return;
+    char buf[256];
+    strncpy(buf, env, sizeof(buf) - 1);
+    buf[sizeof(buf) - 1] = 0;
+    for (char* tok = strtok(buf, ","); tok; tok = strtok(nullptr, ",")) {
+      char* eq = strchr(tok, '=');
+      if (!eq) continue;
+      *eq = 0;
+      (void)gla_set_option(tok, atoll(eq + 1));        // unknown names are ignored
+    }
+  }
+};
+const EnvOptions g_env_options;
+}  // namespace
+
+extern "C" {
 
 const char* gla_error_string(int code) {
   switch (code) {

@@ -61,7 +61,8 @@ int gla_version(void);
  * row-sorted matrix lies on one of <= 16 diagonals col - row -- 5-point, 9-point stencils -- the values are also kept
  * diagonal-major and the K = 1 kernels stream them with NO index stream at all, x[row + offset] being a coalesced
  * load; same products, same summation order: bit-identical), "xcd_chunk",
- * "spmm_variant" (A/B knobs). */
+ * "spmm_variant" (A/B knobs).  The environment variable GLA_OPTIONS="name=value,name=value" sets initial values when
+ * the library is loaded. */
 int gla_set_option(const char* name, int64_t value);
 const char* gla_error_string(int code);
 
