@@ -1,32 +1,156 @@
 #!/usr/bin/env python3
 """bench.py -- JacobiGNN sweeps/s on the 2-D Laplacian (BASELINE.json metric), 1..8 MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 4096] [--sweeps 20] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 4096] [--sweeps 20] [--no-cpu-baseline] [--no-side]
 
 A "step" is one `JacobiGNN.forward(n_iters=20, ...)` call (BASELINE config 2: 20 sweeps, 4096 x 4096
 Laplacian, fp64) through the drop-in nn.Module surface with all inputs resident in HBM: the per-call AoS
-column split, the cached-plan lookup and the 20 fused CSR sweeps are inside the timed region; building the
+column split, the cached-plan lookup and the 20 fused sweeps are inside the timed region; building the
 graph / CSR plan (once per graph) is not.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): WEAK scaling.  Every rank owns a row block
-of `n` grid lines x `n` vertices of the (n*N_gpus) x n grid Laplacian (at N=1 exactly config 2); after each
-sweep the ranks exchange their boundary grid lines with one all-gather (gnn_applied_linear_algebra_amd/dist.py).
-`value` = (rank-block sweeps done by all ranks) / wall time = N_gpus * sweeps/s of the coupled system.
+`python bench.py --gpus N` works as typed: when no launcher has set WORLD_SIZE the process is only a PARENT -- it
+imports neither torch nor the library, touches no GPU, starts N fresh rank processes (one per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), relays rank 0's JSON line and
+exits with the worst child status.  Launched by `torch.distributed.run` (WORLD_SIZE already set) it is a rank.
+
+N > 1 (one rank per GPU, RCCL): the headline is WEAK scaling.  Every rank owns a row block of `n` grid lines x `n`
+vertices of the (n*N_gpus) x n grid Laplacian (at N=1 exactly config 2); after each sweep the ranks exchange their
+boundary grid lines with one all-gather (gnn_applied_linear_algebra_amd/dist.py).  `value` = (rank-block sweeps
+done by all ranks) / wall time = N_gpus * sweeps/s of the coupled system.  The same line carries `config4_strong`:
+BASELINE config 4 (FIXED 8192 x 8192 Laplacian cut into N row blocks) with its speed-up over the 1-GPU rate of the
+same matrix measured in the same run.  A failure of the overlapped exchange is a failure of the run (non-zero exit).
+
+N = 1 side records (never `value`): `csr_general` (the CSR-stream kernel every non-stencil matrix gets),
+`config3_k16` (BASELINE config 3: Chebyshev degree 4 + power method, 16 right-hand sides), `config4_1gpu`
+(8192 x 8192 on one GPU), `optin_packed_stream`.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+HBM_PEAK = 8e12          # B/s, MI355X_MICROARCH.md
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid lines per rank and vertices per line")
+    ap.add_argument("--sweeps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sweeps", type=int, default=4)
+    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: exchange, then compute (no overlap)")
+    ap.add_argument("--host-loop", action="store_true",
+                    help="multi-GPU: drive every sweep from Python (torch.distributed all-gather) instead of the "
+                         "library-side loop")
+    ap.add_argument("--strong", action="store_true",
+                    help="headline = strong scaling: a FIXED (grid x grid) Laplacian (BASELINE config 4: --grid 8192) "
+                         "is cut into N row blocks; reports scaling=strong")
+    ap.add_argument("--strong-grid", type=int, default=8192, help="grid of the config4_strong side record (N > 1)")
+    ap.add_argument("--no-side", action="store_true", help="skip every side record (csr_general, config3_k16, ...)")
+    ap.add_argument("--no-optin", action="store_true", help="skip the side measurement of the opt-in packed stream")
+    ap.add_argument("--no-dia", action="store_true",
+                    help="keep the CSR kernels (compact index streams) instead of the diagonal layout for stencils")
+    ap.add_argument("--no-col16", action="store_true",
+                    help="read 4-byte columns (the plain CSR stream of SURVEY's byte model) instead of int16 "
+                         "tile-relative columns")
+    ap.add_argument("--compress", action="store_true",
+                    help="opt-in packed matrix stream (int16 tile-relative columns + value dictionary, 3 B/nnz)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: all ranks share cuda:0 (needs --backend gloo)")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="parent only: print the child command lines + environment as JSON and exit")
+    ap.add_argument("--child-timeout", type=float, default=1500.0, help="parent: seconds before the ranks are killed")
+    return ap.parse_args(argv)
+
+
+# =====================================================================================================================
+# parent: start one fresh process per GPU.  No torch import, no HIP call in this process.
+# =====================================================================================================================
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def child_specs(args, argv):
+    port = int(os.environ.get("MASTER_PORT", 0)) or free_port()
+    specs = []
+    for r in range(args.gpus):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+               "GLA_BENCH_CHILD": "1"}
+        specs.append({"cmd": [sys.executable, os.path.abspath(__file__)] + list(argv), "env": env})
+    return specs
+
+
+def launch(args, argv):
+    """Spawn args.gpus rank processes, relay rank 0's stdout, return the worst exit status."""
+    specs = child_specs(args, argv)
+    if args.launch_dry_run:
+        print(json.dumps({"children": specs, "torch_imported_in_parent": "torch" in sys.modules}))
+        return 0
+    procs = []
+    for r, sp in enumerate(specs):
+        env = dict(os.environ)
+        env.update(sp["env"])
+        procs.append(subprocess.Popen(sp["cmd"], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    deadline = time.time() + args.child_timeout
+    rcs = [None] * len(procs)
+    out0 = None
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        failed = [rc for rc in rcs if rc not in (None, 0)]
+        if failed or time.time() > deadline:              # one rank died (or the run hangs): stop the others by PID
+            time.sleep(2.0)
+            for i, p in enumerate(procs):
+                if p.poll() is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+                rcs[i] = p.returncode
+            if not failed:
+                print("bench.py: ranks killed after --child-timeout", file=sys.stderr)
+                rcs = [rc if rc else 124 for rc in rcs]
+            break
+        time.sleep(0.05)
+    try:
+        out0 = procs[0].stdout.read()
+    except Exception:
+        out0 = ""
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    worst = 0
+    for rc in rcs:
+        if rc:
+            worst = rc if rc > 0 else 128 - rc
+            break
+    return worst
+
+
+# =====================================================================================================================
+# rank process
+# =====================================================================================================================
 def algorithmic_bytes_jacobi(n, nnz):
     """12*nnz (val f64 + col i32) + 4*(n+1) (rowptr) + 32*n (read x, b, A_ii; write x)."""
     return 12 * nnz + 4 * (n + 1) + 32 * n
@@ -35,6 +159,7 @@ def algorithmic_bytes_jacobi(n, nnz):
 def cpu_baseline(n_grid, sweeps):
     """Reference formulation (oracle/reference_port.py: gather -> mul -> cat -> scatter_add, torch CPU) timed on
     the host cores: a bounded sample (`sweeps` sweeps) of the same 4096^2 workload."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import reference_port as rp
     ei, ev = rp.laplacianfun_torch(n_grid)
@@ -62,52 +187,337 @@ def cpu_baseline(n_grid, sweeps):
         for _ in range(sweeps):
             xc = xc + 0.7 * (b - A_csr @ xc) / -4.0
         csr_value = sweeps / (time.perf_counter() - t1)
-    except Exception:
+    except Exception:                                          # the optional extra baseline only
         pass
-    return {"value": sweeps / dt, "unit": "sweeps/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(sweeps / dt, 4), "unit": "sweeps/s", "cores": torch.get_num_threads(), "kind": "port",
             "csr_spmv_sweeps_per_s": None if csr_value is None else round(csr_value, 3),
             "sample": f"{sweeps} sweeps of the {n_grid}x{n_grid} fp64 JacobiGNN in the reference's COO "
                       f"gather/cat/scatter_add formulation (oracle/reference_port.py), torch CPU, "
                       f"{torch.get_num_threads()} threads of {os.cpu_count()} logical cores",
-            "ms_per_sweep": 1e3 * dt / sweeps}
+            "ms_per_sweep": round(1e3 * dt / sweeps, 1)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid lines per rank and vertices per line")
-    ap.add_argument("--sweeps", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sweeps", type=int, default=4)
-    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: exchange, then compute (no overlap)")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling instead of the default weak scaling: a FIXED (grid x grid) Laplacian "
-                         "(BASELINE config 4: --grid 8192) is cut into N row blocks; reports scaling=strong")
-    ap.add_argument("--no-optin", action="store_true", help="skip the side measurement of the opt-in packed stream")
-    ap.add_argument("--no-dia", action="store_true",
-                    help="keep the CSR kernels (compact index streams) instead of the diagonal layout for stencils")
-    ap.add_argument("--no-col16", action="store_true",
-                    help="read 4-byte columns (the plain CSR stream of SURVEY's byte model) instead of int16 "
-                         "tile-relative columns")
-    ap.add_argument("--compress", action="store_true",
-                    help="opt-in packed matrix stream (int16 tile-relative columns + value dictionary, 3 B/nnz)")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal of the N>1 path)")
-    ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal only: all ranks share cuda:0 (needs --backend gloo)")
-    args = ap.parse_args()
+def median(xs):
+    xs = sorted(xs)
+    m = len(xs) // 2
+    return xs[m] if len(xs) % 2 else 0.5 * (xs[m - 1] + xs[m])
 
+
+class Problem:
+    """Synthetic inputs of SURVEY 8(d) for one rank's row block of the (Ny x Nx) grid Laplacian."""
+
+    def __init__(self, gla, Nx, Ny, lo, hi, dev, seed):
+        import torch
+        from gnn_applied_linear_algebra_amd import UtilsGNN
+        self.n_local = hi - lo
+        self.ei, ev = UtilsGNN.laplacianfun_torch(Nx, Ny=Ny, row_range=(lo, hi), device=dev)
+        self.nnz = self.ei.shape[1]
+        gen = torch.Generator().manual_seed(seed)
+        self.b = torch.rand(self.n_local, 1, generator=gen, dtype=torch.float64).to(dev)
+        self.x0 = torch.rand(self.n_local, 1, generator=gen, dtype=torch.float64).to(dev)
+        self.diag = torch.full((self.n_local, 1), -4.0, dtype=torch.float64, device=dev)
+        self.vertex_attr = torch.cat([self.diag, self.b, self.x0], 1)
+        self.edge_attr = torch.cat([ev, torch.zeros_like(ev)], 1)
+        self.g = torch.tensor([0.7], dtype=torch.float64, device=dev)
+        self.B = algorithmic_bytes_jacobi(self.n_local, self.nnz)
+
+
+def timed_steps(step, steps, warmup, barrier=None):
+    """W untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; also per-step HIP-event times
+    (recorded on the launch stream).  Returns (elapsed_s, [ms per step])."""
+    import torch
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+        torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    return elapsed, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def single_gpu(args, gla, dev):
+    import torch
+    check, L = gla._lib.check, gla._lib.lib()
+    Nx = args.n
+    pr = Problem(gla, Nx, Nx, 0, Nx * Nx, dev, 24601)
+    jac = gla.JacobiGNN.JacobiGNN()
+
+    def step():
+        return jac(args.sweeps, pr.vertex_attr, pr.ei, pr.edge_attr, pr.g)
+
+    plan = gla.plan_for(pr.ei, pr.n_local, edge_attr=pr.edge_attr)
+    # HIP events around the sweep launches INSIDE the timed steps (recorded on the launch stream = torch's current
+    # stream): the module calls plan.jacobi_sweeps, which is wrapped on this plan instance
+    sweep_events = []
+    _sweeps = plan.jacobi_sweeps
+
+    def _timed_sweeps(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = _sweeps(*a, **k)
+        e1.record()
+        sweep_events.append((e0, e1))
+        return out
+    plan.jacobi_sweeps = _timed_sweeps
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    del sweep_events[:]                                      # keep only the events of the timed steps
+    elapsed, step_ms = timed_steps(step, args.steps, 0)
+    plan.jacobi_sweeps = _sweeps
+    total_sweeps = args.steps * args.sweeps
+    per_launch = [e0.elapsed_time(e1) * 1e-3 / args.sweeps for e0, e1 in sweep_events]
+    t_launch = sum(per_launch) / len(per_launch)
+    info = plan.info
+    roof = {"bound": "hbm", "achieved": round(pr.B / t_launch / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(pr.B / t_launch / HBM_PEAK, 4), "traffic": None,
+            "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "algorithmic_bytes_per_launch": pr.B,
+            "avg_launch_us": round(t_launch * 1e6, 2), "median_launch_us": round(median(per_launch) * 1e6, 2)}
+    tp = os.path.join(ROOT, "profiles", "traffic_jacobi.json")
+    if os.path.exists(tp):                                   # PMC passes of the same kernel + layout (tools/pmc_*.py)
+        tj = json.load(open(tp))
+        if tj.get("n") == args.n and int(tj.get("col16", 0)) == int(info.col16) \
+                and int(tj.get("dia", 0)) == int(info.dia) and not bool(info.packed):
+            roof["traffic"] = tj.get("hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/traffic_jacobi.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes " \
+                                     "of this kernel and layout; not re-measured by this run)"
+            roof["hbm_utilisation_by_traffic"] = round(roof["traffic"] / t_launch / HBM_PEAK, 4)
+    if int(info.dia) > 0 and not bool(info.packed):
+        # default layout for stencil matrices: values diagonal-major, NO index stream (a 2-byte row mask instead).
+        # `achieved` / `frac` keep SURVEY 8(d)'s CSR byte model as prescribed; `layout_*` is what the kernel really
+        # has to move: 8 D bytes of values + 2 per row + the vectors
+        Bl = (8 * int(info.dia) + 2 + 32) * pr.n_local
+        roof.update({"kernel": "spmv_dia_kernel<double,EpiJacobi>", "layout": f"dia{int(info.dia)}",
+                     "layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
+                     "layout_frac": round(Bl / t_launch / HBM_PEAK, 4)})
+    elif bool(info.col16) and not bool(info.packed):
+        # 2-byte tile-relative columns: 10 B per nonzero, 2-byte tile-relative row offsets
+        Bl = 10 * pr.nnz + 2 * (pr.n_local + int(info.n_tiles)) + 32 * pr.n_local
+        roof.update({"layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
+                     "layout_frac": round(Bl / t_launch / HBM_PEAK, 4)})
+    if args.compress and bool(info.packed):
+        Bl = 3 * pr.nnz + 2 * (pr.n_local + int(info.n_tiles)) + 32 * pr.n_local
+        roof.update({"kernel": "spmv_packed_kernel<double,EpiJacobi>", "traffic": None,
+                     "layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
+                     "layout_frac": round(Bl / t_launch / HBM_PEAK, 4)})
+
+    out = {
+        "metric": "Jacobi-GNN sweeps/sec (2D Laplacian, fp64)", "value": round(total_sweeps / elapsed, 2),
+        "unit": "sweeps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_step_median": round(median(step_ms), 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"JacobiGNN.forward, {args.sweeps} sweeps/step, 5-pt Laplacian, "
+                               f"{Nx}x{Nx} vertices per GPU (global grid {Nx}x{Nx}), fp64, w=0.7",
+                   "N": Nx, "rows_per_gpu": pr.n_local, "nnz_per_gpu": pr.nnz, "sweeps_per_step": args.sweeps,
+                   "achieved_GBps_per_gpu_whole_step": round(pr.B * total_sweeps / elapsed / 1e9, 1)},
+        "roofline": roof,
+    }
+    default_layout = not (args.compress or args.no_col16 or args.no_dia)
+    side = default_layout and not args.no_side
+
+    # ---- side: the opt-in packed matrix stream (value-dependent; bit-identical) -------------------------------------
+    if side and not args.no_optin:
+        try:
+            check(L.gla_set_option(b"compress", 1))
+            ei_p = pr.ei.clone()                              # plans are cached per edge-index tensor: a fresh one
+            plan_p = gla.plan_for(ei_p, pr.n_local, edge_attr=pr.edge_attr)
+            if bool(plan_p.info.packed):
+                same = bool(torch.equal(step(), jac(args.sweeps, pr.vertex_attr, ei_p, pr.edge_attr, pr.g)))
+                el, _ = timed_steps(lambda: jac(args.sweeps, pr.vertex_attr, ei_p, pr.edge_attr, pr.g), args.steps, 1)
+                Bl = 3 * pr.nnz + 2 * (pr.n_local + int(plan_p.info.n_tiles)) + 32 * pr.n_local
+                mode = "packed CSR stream: int16 columns + value dictionary"
+                if int(plan_p.info.packed) == 2:            # stencil with constant diagonals: only the row mask is left
+                    Bl = (2 + 32) * pr.n_local
+                    mode = "constant-diagonal stencil: no matrix stream besides a 2-byte row mask"
+                out["optin_packed_stream"] = {
+                    "option": "compress", "mode": mode, "value": round(total_sweeps / el, 2), "unit": "sweeps/s",
+                    "us_per_sweep_whole_step": round(1e6 * el / total_sweeps, 2), "bit_identical_to_default": same,
+                    "layout_bytes_per_launch": Bl}
+            del plan_p, ei_p
+        finally:
+            check(L.gla_set_option(b"compress", 0))
+
+    # ---- side: the general CSR-stream kernel (what every non-stencil matrix gets): same step with dia = 0 -----------
+    if side:
+        try:
+            check(L.gla_set_option(b"dia", 0))
+            ei_c = pr.ei.clone()
+            plan_c = gla.plan_for(ei_c, pr.n_local, edge_attr=pr.edge_attr)
+            same = bool(torch.equal(step(), jac(args.sweeps, pr.vertex_attr, ei_c, pr.edge_attr, pr.g)))
+            el, _ = timed_steps(lambda: jac(args.sweeps, pr.vertex_attr, ei_c, pr.edge_attr, pr.g), args.steps, 1)
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                plan_c.jacobi_sweeps(pr.diag.reshape(-1), pr.b, pr.x0, 0.7, args.sweeps)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e-3 / args.sweeps)
+            tl = median(ts)
+            Bl = 10 * pr.nnz + 2 * (pr.n_local + int(plan_c.info.n_tiles)) + 32 * pr.n_local
+            out["csr_general"] = {
+                "what": "same step with option dia=0: spmv_stream_vec2_kernel (CSR-adaptive stream tiles, int16 "
+                        "tile-relative columns), the kernel non-stencil matrices run on",
+                "value": round(total_sweeps / el, 2), "unit": "sweeps/s", "launch_us": round(tl * 1e6, 2),
+                "achieved": round(pr.B / tl / 1e9, 1), "frac": round(pr.B / tl / HBM_PEAK, 4),
+                "layout_bytes_per_launch": Bl, "layout_frac": round(Bl / tl / HBM_PEAK, 4),
+                "bit_identical_to_default": same}
+            del plan_c, ei_c
+        finally:
+            check(L.gla_set_option(b"dia", 1))
+
+    # ---- side: BASELINE config 3 (Chebyshev degree 4 + power method 10 its, 16 right-hand sides, 4096^2) ------------
+    if side:
+        K = 16
+        n, nnz = pr.n_local, pr.nnz
+        gen = torch.Generator().manual_seed(24601)
+        b16 = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
+        x16 = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
+        ev = pr.edge_attr[:, :1].contiguous()
+        base = 12 * nnz + 4 * (n + 1)
+        va = torch.stack([b16, x16], 1)                       # [n, 2, K]
+        gc = torch.tensor([-3.4, -4.0], dtype=torch.float64)
+        cheb = gla.ChebyGNN.ChebyRelaxGNN(4, return_edge_attr=False)
+        el_c, ms_c = timed_steps(lambda: cheb(va, pr.ei, ev, gc), 5, 2)
+        Bc = (base + 40 * n * K) + 3 * (base + 48 * n * K)
+        del va
+        pw = gla.PowerMethodGNN.PowerMethodGNN(10, return_edge_attr=False)
+        vp = torch.stack([b16, torch.zeros_like(b16)], 1)
+        g3 = torch.zeros(3, K, dtype=torch.float64)
+        el_p, ms_p = timed_steps(lambda: pw(vp, pr.ei, pr.edge_attr, g3), 5, 2)
+        Bp = 11 * (base + 16 * n * K) + 6 * 8 * n * K
+        tc, tpw = median(ms_c) * 1e-3, median(ms_p) * 1e-3
+        out["config3_k16"] = {
+            "what": f"BASELINE config 3 through the module surface, {Nx}^2 Laplacian, K=16 right-hand sides, fp64",
+            "cheby_deg4_ms": round(tc * 1e3, 3), "cheby_GBps": round(Bc / tc / 1e9, 1),
+            "cheby_frac": round(Bc / tc / HBM_PEAK, 4), "cheby_algorithmic_bytes": Bc,
+            "power_10its_ms": round(tpw * 1e3, 3), "power_GBps": round(Bp / tpw / 1e9, 1),
+            "power_frac": round(Bp / tpw / HBM_PEAK, 4), "power_algorithmic_bytes": Bp}
+        del vp, b16, x16
+        torch.cuda.empty_cache()
+
+    # ---- side: BASELINE config 4's matrix on ONE GPU (8192^2) -------------------------------------------------------
+    if side and args.n == 4096:
+        free, _ = torch.cuda.mem_get_info()
+        if free > 40e9:
+            p4 = Problem(gla, 8192, 8192, 0, 8192 * 8192, dev, 24601)
+            el4, ms4 = timed_steps(lambda: jac(args.sweeps, p4.vertex_attr, p4.ei, p4.edge_attr, p4.g), 3, 1)
+            t4 = median(ms4) * 1e-3 / args.sweeps
+            out["config4_1gpu"] = {"what": "JacobiGNN.forward, 20 sweeps, 8192^2 Laplacian fp64 on one GPU",
+                                   "value": round(1.0 / t4, 2), "unit": "sweeps/s", "us_per_sweep": round(t4 * 1e6, 1),
+                                   "achieved": round(p4.B / t4 / 1e9, 1), "frac": round(p4.B / t4 / HBM_PEAK, 4)}
+            del p4
+            torch.cuda.empty_cache()
+
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.n, args.cpu_sweeps)
+    print(json.dumps(out), flush=True)
+
+
+def multi_gpu(args, gla, dev, world, rank):
+    import torch
+    import torch.distributed as dist
+    from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi
+    ranks_seen = dist.get_world_size()
+    on_dev = args.backend == "nccl"
+
+    def barrier():
+        dist.barrier()
+
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev if on_dev else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run_block(Nx, lines, steps, warmup):
+        """Row block of `lines` grid lines per rank of the (lines*world) x Nx grid; returns (elapsed, problem, drv)."""
+        Ny = lines * world
+        n_local = Nx * lines
+        pr = Problem(gla, Nx, Ny, rank * n_local, (rank + 1) * n_local, dev, 24601 + rank)
+        drv = RowBlockJacobi(pr.ei, pr.edge_attr, n_global=Nx * Ny, row_lo=rank * n_local, row_hi=(rank + 1) * n_local,
+                             overlap=not args.no_overlap, host_loop=args.host_loop)
+        elapsed, step_ms = timed_steps(lambda: drv.forward(args.sweeps, pr.vertex_attr, pr.g), steps, warmup, barrier)
+        return max_over_ranks(elapsed), pr, drv
+
+    Nx = args.n
+    if args.strong and args.n % world:
+        raise SystemExit("--strong needs --grid divisible by the number of GPUs")
+    lines = args.n // world if args.strong else args.n
+    elapsed, pr, drv = run_block(Nx, lines, args.steps, args.warmup)
+    total_sweeps = args.steps * args.sweeps
+    t_sweep = elapsed / total_sweeps
+    roof = {"bound": "hbm", "achieved": round(pr.B / t_sweep / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(pr.B / t_sweep / HBM_PEAK, 4), "traffic": None,
+            "kernel": "per-rank sweep incl. halo exchange (interior + boundary launch)",
+            "algorithmic_bytes_per_launch": pr.B, "avg_launch_us": round(t_sweep * 1e6, 2)}
+    out = {
+        "metric": "Jacobi-GNN sweeps/sec (2D Laplacian, fp64)",
+        "value": round((1 if args.strong else world) * total_sweeps / elapsed, 2), "unit": "sweeps/s",
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"JacobiGNN.forward, {args.sweeps} sweeps/step, 5-pt Laplacian, {lines}x{Nx} vertices "
+                               f"per GPU (global grid {lines * world}x{Nx}), fp64, w=0.7, row-block partition + RCCL "
+                               f"halo all-gather ({drv.mode})",
+                   "N": Nx, "rows_per_gpu": pr.n_local, "nnz_per_gpu": pr.nnz, "sweeps_per_step": args.sweeps,
+                   "backend": args.backend, "exchange": drv.mode,
+                   "aggregate_GBps": round(world * pr.B * total_sweeps / elapsed / 1e9, 1),
+                   "achieved_GBps_per_gpu_whole_step": round(pr.B * total_sweeps / elapsed / 1e9, 1)},
+        "roofline": roof,
+    }
+    del pr, drv
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE config 4: FIXED strong_grid^2 Laplacian cut into `world` row blocks, and the 1-GPU rate of the
+    #      same matrix measured by rank 0 alone in this run (the other ranks wait at the barrier) -------------------
+    G = args.strong_grid
+    if not args.no_side and not args.strong and G % world == 0:
+        steps4 = max(3, min(args.steps, 10))
+        el4, p4, d4 = run_block(G, G // world, steps4, 2)
+        t4 = el4 / (steps4 * args.sweeps)
+        B4_global = algorithmic_bytes_jacobi(G * G, 5 * G * G - 4 * G)
+        rec = {"what": f"BASELINE config 4: JacobiGNN {args.sweeps} sweeps/step on the FIXED {G}x{G} Laplacian, "
+                       f"{G // world} grid lines per GPU, halo all-gather per sweep ({d4.mode})",
+               "scaling": "strong", "n_gpus": world, "ranks_seen": ranks_seen, "value": round(1.0 / t4, 2),
+               "unit": "sweeps/s", "us_per_sweep": round(t4 * 1e6, 2),
+               "GBps_per_gpu": round(p4.B / t4 / 1e9, 1), "frac_per_gpu": round(p4.B / t4 / HBM_PEAK, 4),
+               "aggregate_GBps": round(B4_global / t4 / 1e9, 1)}
+        del p4, d4
+        torch.cuda.empty_cache()
+        t1 = None
+        if rank == 0 and not args.single_device:
+            jac = gla.JacobiGNN.JacobiGNN()
+            p1 = Problem(gla, G, G, 0, G * G, dev, 24601)
+            _, ms1 = timed_steps(lambda: jac(args.sweeps, p1.vertex_attr, p1.ei, p1.edge_attr, p1.g), 3, 1)
+            t1 = median(ms1) * 1e-3 / args.sweeps
+            del p1
+            torch.cuda.empty_cache()
+        barrier()
+        if rank == 0 and t1 is not None:
+            rec.update({"one_gpu_sweeps_per_s": round(1.0 / t1, 2), "speedup_vs_one_gpu": round(t1 / t4, 3),
+                        "parallel_efficiency": round(t1 / t4 / world, 3)})
+        out["config4_strong"] = rec
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def worker(args):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; before any HIP call
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    if args.single_device:
-        local_rank = 0
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -119,223 +529,44 @@ def main():
                 dist.init_process_group(backend="nccl")
         else:
             dist.init_process_group(backend=args.backend)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, WORLD_SIZE says {world}")
 
     import gnn_applied_linear_algebra_amd as gla
-    from gnn_applied_linear_algebra_amd import UtilsGNN
+    check, L = gla._lib.check, gla._lib.lib()
     if args.compress:
-        gla._lib.check(gla._lib.lib().gla_set_option(b"compress", 1))
+        check(L.gla_set_option(b"compress", 1))
     if args.no_col16:
-        gla._lib.check(gla._lib.lib().gla_set_option(b"col16", 0))
+        check(L.gla_set_option(b"col16", 0))
     if args.no_dia or args.no_col16:
-        gla._lib.check(gla._lib.lib().gla_set_option(b"dia", 0))
-
-    Nx = args.n
-    if args.strong:
-        if args.n % world:
-            raise SystemExit("--strong needs --grid divisible by the number of GPUs")
-        lines = args.n // world
-    else:
-        lines = args.n
-    Ny = lines * world
-    n_local = Nx * lines
-    lo, hi = rank * n_local, (rank + 1) * n_local
-    ei, ev = UtilsGNN.laplacianfun_torch(Nx, Ny=Ny, row_range=(lo, hi), device=dev)
-    nnz_local = ei.shape[1]
-    gen = torch.Generator().manual_seed(24601 + rank)
-    b = torch.rand(n_local, 1, generator=gen, dtype=torch.float64).to(dev)
-    x0 = torch.rand(n_local, 1, generator=gen, dtype=torch.float64).to(dev)
-    diag = torch.full((n_local, 1), -4.0, dtype=torch.float64, device=dev)
-    vertex_attr = torch.cat([diag, b, x0], 1)
-    edge_attr = torch.cat([ev, torch.zeros_like(ev)], 1)
-    g = torch.tensor([0.7], dtype=torch.float64, device=dev)
-
+        check(L.gla_set_option(b"dia", 0))
     if world == 1:
-        jac = gla.JacobiGNN.JacobiGNN()
-
-        def step():
-            return jac(args.sweeps, vertex_attr, ei, edge_attr, g)
-
-        plan = gla.plan_for(ei, n_local, edge_attr=edge_attr)
-
-        def kernel_only():
-            return plan.jacobi_sweeps(diag.reshape(-1), b, x0, 0.7, args.sweeps)
-
-        # HIP events around the sweep launches INSIDE the timed steps (recorded on the launch stream = torch's current
-        # stream): the module calls plan.jacobi_sweeps, which is wrapped on this plan instance
-        sweep_events = []
-        _sweeps = plan.jacobi_sweeps
-
-        def _timed_sweeps(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = _sweeps(*a, **k)
-            e1.record()
-            sweep_events.append((e0, e1))
-            return out
-        plan.jacobi_sweeps = _timed_sweeps
-    else:
-        from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi
-        drv = RowBlockJacobi(ei, edge_attr, n_global=Nx * Ny, row_lo=lo, row_hi=hi, overlap=not args.no_overlap)
-
-        def step():
-            return drv.forward(args.sweeps, vertex_attr, g)
-
-        kernel_only = None
-        sweep_events = []
-
-    notes = []
+        single_gpu(args, gla, dev)
+        return
     try:
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-    except Exception as exc:                                    # keep the scaling run alive: serialise the exchange
-        if world == 1 or args.no_overlap:
-            raise
-        notes.append(f"overlapped halo exchange failed ({type(exc).__name__}: {exc}); re-run without overlap")
-        drv = RowBlockJacobi(ei, edge_attr, n_global=Nx * Ny, row_lo=lo, row_hi=hi, overlap=False)
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    del sweep_events[:]                                      # keep only the events of the timed steps
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+        multi_gpu(args, gla, dev, world, rank)
+    except BaseException:
+        # a failed rank must not wait for its peers in destroy_process_group (they may sit in a collective): report
+        # and leave at once; the parent (or torchrun) stops the other ranks and the run exits non-zero
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
+    from gnn_applied_linear_algebra_amd.dist import LibComm
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    LibComm.release_all()
+    dist.destroy_process_group()
 
-    total_sweeps = args.steps * args.sweeps
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = (1 if args.strong else world) * total_sweeps / elapsed
-    B = algorithmic_bytes_jacobi(n_local, nnz_local)
 
-    # roofline of the dominant kernel (spmv_stream_vec2_kernel<double, EpiJacobi>): HIP events on the launch stream
-    roof = None
-    if rank == 0:
-        if sweep_events:                                     # N = 1: events recorded inside the timed region
-            t_launch = sum(e0.elapsed_time(e1) for e0, e1 in sweep_events) * 1e-3 / (len(sweep_events) * args.sweeps)
-            plan.jacobi_sweeps = _sweeps
-        elif kernel_only is not None:
-            kernel_only()
-            torch.cuda.synchronize()
-            reps = 5
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                kernel_only()
-            e1.record()
-            torch.cuda.synchronize()
-            t_launch = e0.elapsed_time(e1) * 1e-3 / (reps * args.sweeps)
-        else:
-            t_launch = elapsed / total_sweeps                # per-rank sweep incl. halo exchange
-        achieved = B / t_launch / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_jacobi.json")
-        if world == 1 and os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                if tj.get("n") == args.n and int(tj.get("col16", 0)) == int(plan.info.col16) \
-                        and int(tj.get("dia", 0)) == int(plan.info.dia) and not bool(plan.info.packed):
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "kernel": "spmv_stream_vec2_kernel<double,EpiJacobi>", "algorithmic_bytes_per_launch": B,
-                "avg_launch_us": round(t_launch * 1e6, 2)}
-        info = plan.info if world == 1 else None
-        if info is not None and int(info.dia) > 0 and not bool(info.packed):
-            # default layout for stencil matrices: values diagonal-major, NO index stream (a 2-byte row mask instead).
-            # `achieved` / `frac` keep SURVEY 8(d)'s CSR byte model as prescribed; `layout_*` is what the kernel really
-            # has to move: 8 D bytes of values + 2 per row + the vectors
-            Bl = (8 * int(info.dia) + 2 + 32) * n_local
-            roof.update({"kernel": "spmv_dia_kernel<double,EpiJacobi>", "layout": f"dia{int(info.dia)}",
-                         "layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
-                         "layout_frac": round(Bl / t_launch / 8e12, 4)})
-        elif info is not None and bool(info.col16) and not bool(info.packed):
-            # default layout: 2-byte tile-relative columns.  `achieved` / `frac` keep SURVEY 8(d)'s CSR byte model
-            # (12 B per nonzero, 4 B per row offset) as prescribed; `layout_*` is what the kernel really has to move
-            # (10 B per nonzero, 2-byte tile-relative row offsets)
-            Bl = 10 * nnz_local + 2 * (n_local + int(info.n_tiles)) + 32 * n_local
-            roof.update({"layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
-                         "layout_frac": round(Bl / t_launch / 8e12, 4)})
-        if args.compress and world == 1 and bool(plan.info.packed):
-            # the packed layout moves 3 B per nonzero instead of the 12 B of SURVEY's CSR model: `achieved` keeps the
-            # SURVEY byte model as prescribed (it can exceed what HBM delivers), `layout_*` is what is really moved
-            Bl = 3 * nnz_local + 2 * (n_local + int(plan.info.n_tiles)) + 32 * n_local
-            roof.update({"kernel": "spmv_packed_kernel<double,EpiJacobi>", "traffic": None,
-                         "layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
-                         "layout_frac": round(Bl / t_launch / 8e12, 4)})
-
-    # Side measurement (N = 1, default run only): the same step with the opt-in packed matrix stream
-    # (gla_set_option("compress", 1): constant diagonals of a stencil are not streamed at all; otherwise int16 columns +
-    # <= 256-entry value dictionary, 3 B per nonzero; bit-identical results).  Reported next to the headline, never as
-    # `value`: it depends on the VALUES of the matrix (few distinct ones), not only on its structure.
-    optin = None
-    if rank == 0 and world == 1 and not args.compress and not args.no_col16 and not args.no_dia and not args.no_optin:
-        check, L = gla._lib.check, gla._lib.lib()
-        try:
-            check(L.gla_set_option(b"compress", 1))
-            ei_p = ei.clone()                                   # plans are cached per edge-index tensor: a fresh one
-            plan_p = gla.plan_for(ei_p, n_local, edge_attr=edge_attr)
-            if bool(plan_p.info.packed):
-                ref_out = step()
-                out_p = jac(args.sweeps, vertex_attr, ei_p, edge_attr, g)
-                same = bool(torch.equal(ref_out, out_p))
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    jac(args.sweeps, vertex_attr, ei_p, edge_attr, g)
-                torch.cuda.synchronize()
-                el = time.perf_counter() - t1
-                Bl = 3 * nnz_local + 2 * (n_local + int(plan_p.info.n_tiles)) + 32 * n_local
-                mode = "packed CSR stream: int16 columns + value dictionary"
-                if int(plan_p.info.packed) == 2:           # stencil with constant diagonals: only the row mask is left
-                    Bl = (2 + 32) * n_local
-                    mode = "constant-diagonal stencil: no matrix stream besides a 2-byte row mask"
-                optin = {"option": "compress", "mode": mode, "value": round(total_sweeps / el, 2), "unit": "sweeps/s",
-                         "us_per_sweep_whole_step": round(1e6 * el / total_sweeps, 2),
-                         "bit_identical_to_default": same, "layout_bytes_per_launch": Bl}
-            del plan_p, ei_p
-        finally:
-            check(L.gla_set_option(b"compress", 0))
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.n, args.cpu_sweeps)
-        cpu["value"] = round(cpu["value"], 4)
-        cpu["ms_per_sweep"] = round(cpu["ms_per_sweep"], 1)
-
-    if rank == 0:
-        out = {
-            "metric": "Jacobi-GNN sweeps/sec (2D Laplacian, fp64)", "value": round(value, 2), "unit": "sweeps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"JacobiGNN.forward, {args.sweeps} sweeps/step, 5-pt Laplacian, "
-                                   f"{lines}x{Nx} vertices per GPU (global grid {Ny}x{Nx}), fp64, w=0.7"
-                                   + ("" if world == 1 else ", row-block partition + RCCL halo all-gather"),
-                       "N": Nx, "rows_per_gpu": n_local, "nnz_per_gpu": nnz_local, "sweeps_per_step": args.sweeps,
-                       "achieved_GBps_per_gpu_whole_step": round(B * total_sweeps / elapsed / 1e9, 1)},
-            "roofline": roof,
-        }
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-        if optin is not None:
-            out["optin_packed_stream"] = optin
-        if notes:
-            out["notes"] = notes
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus > 1 or args.launch_dry_run):
+        sys.exit(launch(args, argv))                            # parent: never touches torch or the GPU
+    if env_world is not None and int(env_world) != args.gpus:
+        args.gpus = int(env_world)                              # the launcher's world size wins
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -76,6 +76,14 @@ SIGNATURES = {
     "gla_release_scratch": (_I, []),
     "gla_spgemm_count": (_I, [_P, _P, ctypes.POINTER(_I64), _P]),
     "gla_spgemm": (_I, [_P, _P, _I, _I64, _P, _P, _P, ctypes.POINTER(_I64), _P]),
+    "gla_comm_unique_id": (_I, [_P]),
+    "gla_comm_create": (_I, [_P, _I, _I, ctypes.POINTER(_P)]),
+    "gla_comm_destroy": (_I, [_P]),
+    "gla_comm_ranks": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "gla_halo_begin": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _I64, _P, _P]),
+    "gla_halo_end": (_I, [_P, _P]),
+    "gla_comm_all_reduce_sum": (_I, [_P, _I, _P, _I64, _P]),
+    "gla_dist_jacobi_sweeps": (_I, [_P, _P, _I, _I, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _P, _D, _I, _I, _P]),
 }
 
 _lib = None

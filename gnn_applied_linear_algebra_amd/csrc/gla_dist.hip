@@ -1,0 +1,225 @@
+// libgla_hip.so -- multi-GPU halo exchange and the library-side distributed sweep loop (gfx950 / MI355X only).
+//
+// The reference has no distributed code; BASELINE.json defines this layer: contiguous row blocks, one
+// process per GPU, and ONE exchange step per SpMV -- an RCCL all-gather of every rank's send slots straight into the
+// tail of the X buffer the kernels gather from (layout in gnn_applied_linear_algebra_amd/dist.py).
+//
+// Why a library-side loop: driven from Python, a sweep costs index_select + all_gather + two ctypes launches +
+// work.wait() on the host -- more than the ~0.12 ms a rank's sweep takes at BASELINE config 4 on 8 GPUs.  Here a sweep
+// is eight runtime calls from C on two streams with event ordering, and nothing synchronises the host:
+//
+//   main stream   pack(t) ──ev_pack──┐  interior(t) ───────────── wait ev_halo ── boundary(t) ── pack(t+1) ...
+//   comm stream                      └─ wait ── ncclAllGather(t) ──ev_halo──┘
+//
+// RCCL is bound at run time (dlopen of librccl.so.1: the instance the process already has when torch is loaded), so
+// single-GPU hosts of libgla_hip.so carry no RCCL dependency.
+#include "gla_internal.h"
+
+#include <dlfcn.h>
+#include <mutex>
+#include <string.h>
+
+namespace {
+
+// the slice of the RCCL API used here (signatures of rccl.h; ncclUniqueId is a 128-byte opaque struct passed by value)
+struct UniqueId { char internal[128]; };
+typedef void* Comm;
+typedef int (*fn_get_unique_id)(UniqueId*);
+typedef int (*fn_comm_init_rank)(Comm*, int, UniqueId, int);
+typedef int (*fn_comm_destroy)(Comm);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, Comm, hipStream_t);
+typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, Comm, hipStream_t);
+typedef const char* (*fn_error_string)(int);
+constexpr int NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_SUM = 0;      // ncclDataType_t / ncclRedOp_t values of rccl.h
+
+struct Rccl {
+  void* handle = nullptr;
+  fn_get_unique_id get_unique_id = nullptr;
+  fn_comm_init_rank comm_init_rank = nullptr;
+  fn_comm_destroy comm_destroy = nullptr;
+  fn_all_gather all_gather = nullptr;
+  fn_all_reduce all_reduce = nullptr;
+  fn_error_string error_string = nullptr;
+  bool ok = false;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+void load_rccl() {
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* nm : names) {
+    g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.handle) break;
+  }
+  if (!g_rccl.handle) return;
+  g_rccl.get_unique_id = (fn_get_unique_id)dlsym(g_rccl.handle, "ncclGetUniqueId");
+  g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(g_rccl.handle, "ncclCommInitRank");
+  g_rccl.comm_destroy = (fn_comm_destroy)dlsym(g_rccl.handle, "ncclCommDestroy");
+  g_rccl.all_gather = (fn_all_gather)dlsym(g_rccl.handle, "ncclAllGather");
+  g_rccl.all_reduce = (fn_all_reduce)dlsym(g_rccl.handle, "ncclAllReduce");
+  g_rccl.error_string = (fn_error_string)dlsym(g_rccl.handle, "ncclGetErrorString");
+  g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.all_gather &&
+              g_rccl.all_reduce;
+}
+
+inline bool rccl_ready() {
+  std::call_once(g_rccl_once, load_rccl);
+  return g_rccl.ok;
+}
+
+#define GLA_RCCL_CHECK(expr)                     \
+  do {                                           \
+    int _r = (expr);                             \
+    if (_r != 0) return -(3000 + _r);            \
+  } while (0)
+
+// send[i, :] = X[send_idx[i], :] for the n_send send slots (K contiguous values each)
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void halo_pack_kernel(const T* __restrict__ X, int64_t ldx,
+                                                              const int32_t* __restrict__ send_idx, int64_t n_send,
+                                                              int K, T* __restrict__ send) {
+  const int64_t total = n_send * K;
+  for (int64_t i = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int64_t s = i / K;
+    const int k = (int)(i - s * K);
+    send[i] = X[(int64_t)send_idx[s] * ldx + k];
+  }
+}
+
+}  // namespace
+
+struct gla_comm {
+  Comm comm = nullptr;
+  int rank = 0, nranks = 1, device = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+};
+
+extern "C" {
+
+int gla_comm_unique_id(void* id_host) {
+  if (!id_host) return GLA_ERR_INVALID_ARG;
+  if (!rccl_ready()) return GLA_ERR_UNSUPPORTED;
+  UniqueId id;
+  GLA_RCCL_CHECK(g_rccl.get_unique_id(&id));
+  memcpy(id_host, &id, sizeof(id));
+  return GLA_OK;
+}
+
+int gla_comm_create(const void* id_host, int rank, int nranks, gla_comm_t* out) {
+  if (!id_host || !out || nranks < 1 || rank < 0 || rank >= nranks) return GLA_ERR_INVALID_ARG;
+  if (!rccl_ready()) return GLA_ERR_UNSUPPORTED;
+  gla_comm* c = new gla_comm();
+  c->rank = rank;
+  c->nranks = nranks;
+  GLA_HIP_CHECK(hipGetDevice(&c->device));
+  UniqueId id;
+  memcpy(&id, id_host, sizeof(id));
+  int rc = g_rccl.comm_init_rank(&c->comm, nranks, id, rank);
+  if (rc != 0) { delete c; return -(3000 + rc); }
+  GLA_HIP_CHECK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+  GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  *out = c;
+  return GLA_OK;
+}
+
+int gla_comm_destroy(gla_comm_t c) {
+  if (!c) return GLA_OK;
+  if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+  if (c->comm && g_rccl.ok) g_rccl.comm_destroy(c->comm);
+  if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
+  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  delete c;
+  return GLA_OK;
+}
+
+int gla_comm_ranks(gla_comm_t c, int* rank_host, int* nranks_host) {
+  if (!c) return GLA_ERR_INVALID_ARG;
+  if (rank_host) *rank_host = c->rank;
+  if (nranks_host) *nranks_host = c->nranks;
+  return GLA_OK;
+}
+
+// X: [n_in + nranks * S, K] row-major, leading dimension K.  Packs this rank's send slots (rows send_idx[0..n_send)
+// of X, padded to S) and starts the all-gather into X[n_in:] on the communicator's stream; returns at once.
+int gla_halo_begin(gla_comm_t c, int dtype, int K, void* X, int64_t n_in, const int32_t* send_idx, int64_t n_send,
+                   int64_t S, void* send_buf, gla_stream_t stream) {
+  if (!c || !X || K < 1 || n_in < 0 || n_send < 0 || S < n_send || (dtype != GLA_F32 && dtype != GLA_F64))
+    return GLA_ERR_INVALID_ARG;
+  if (S == 0) return GLA_OK;
+  if (!send_buf || (n_send > 0 && !send_idx)) return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t esz = dtype == GLA_F64 ? 8 : 4;
+  if (n_send > 0) {
+    int64_t blocks = (n_send * K + GLA_BLOCK - 1) / GLA_BLOCK;
+    if (blocks > 1024) blocks = 1024;
+    if (dtype == GLA_F64)
+      hipLaunchKernelGGL((halo_pack_kernel<double>), dim3((unsigned)blocks), dim3(GLA_BLOCK), 0, st, (const double*)X,
+                         (int64_t)K, send_idx, n_send, K, (double*)send_buf);
+    else
+      hipLaunchKernelGGL((halo_pack_kernel<float>), dim3((unsigned)blocks), dim3(GLA_BLOCK), 0, st, (const float*)X,
+                         (int64_t)K, send_idx, n_send, K, (float*)send_buf);
+    GLA_LAUNCH_CHECK();
+  }
+  GLA_HIP_CHECK(hipEventRecord(c->ev_pack, st));
+  GLA_HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+  GLA_RCCL_CHECK(g_rccl.all_gather(send_buf, (char*)X + (size_t)n_in * K * esz, (size_t)S * K,
+                                   dtype == GLA_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32, c->comm, c->comm_stream));
+  GLA_HIP_CHECK(hipEventRecord(c->ev_halo, c->comm_stream));
+  return GLA_OK;
+}
+
+// Makes `stream` wait for the all-gather started by the last gla_halo_begin (stream-ordered; the host does not block).
+int gla_halo_end(gla_comm_t c, gla_stream_t stream) {
+  if (!c) return GLA_ERR_INVALID_ARG;
+  GLA_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, c->ev_halo, 0));
+  return GLA_OK;
+}
+
+// Sum of `count` values over the ranks, in place, stream-ordered on `stream` (power method: K resp. 2K partial sums).
+int gla_comm_all_reduce_sum(gla_comm_t c, int dtype, void* buf, int64_t count, gla_stream_t stream) {
+  if (!c || !buf || count < 0 || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  if (count == 0) return GLA_OK;
+  GLA_RCCL_CHECK(g_rccl.all_reduce(buf, buf, (size_t)count, dtype == GLA_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32, NCCL_SUM,
+                                   c->comm, (hipStream_t)stream));
+  return GLA_OK;
+}
+
+// n_iters Jacobi sweeps of a row block (JacobiGNN.py:138-148 on this rank's rows) with the halo all-gather of every
+// sweep, all enqueued from here.  Xa / Xb: [n_in + nranks * S, K] buffers (ld = K); Xa[:n_rows] holds x0; the result
+// is in Xa[:n_rows] when n_iters is even, else in Xb[:n_rows].  overlap = 1: interior tiles run while the halo is in
+// flight (the plan must have been classified with gla_csr_classify_tiles(col_limit = n_in)); 0: exchange, then all tiles.
+int gla_dist_jacobi_sweeps(gla_csr_t A, gla_comm_t c, int dtype, int K, const void* diag, const void* B, int64_t ldb,
+                           void* Xa, void* Xb, int64_t n_in, const int32_t* send_idx, int64_t n_send, int64_t S,
+                           void* send_buf, double w, int n_iters, int overlap, gla_stream_t stream) {
+  if (!A || !c || !Xa || !Xb || Xa == Xb || n_iters < 0) return GLA_ERR_INVALID_ARG;
+  void* cur = Xa;
+  void* nxt = Xb;
+  const bool exchange = S > 0;      // (a 1-rank communicator with S > 0 gathers its own slots: the self-halo test)
+  for (int it = 0; it < n_iters; ++it) {
+    int rc;
+    if (!exchange) {
+      rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, cur, K, nxt, K, w, 0, stream);
+      if (rc) return rc;
+    } else {
+      rc = gla_halo_begin(c, dtype, K, cur, n_in, send_idx, n_send, S, send_buf, stream);
+      if (rc) return rc;
+      if (overlap) {
+        rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, cur, K, nxt, K, w, 1, stream);
+        if (rc) return rc;
+      }
+      rc = gla_halo_end(c, stream);
+      if (rc) return rc;
+      rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, cur, K, nxt, K, w, overlap ? 2 : 0, stream);
+      if (rc) return rc;
+    }
+    void* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  return GLA_OK;
+}
+
+}  // extern "C"

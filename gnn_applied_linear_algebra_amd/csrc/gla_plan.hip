@@ -691,6 +691,7 @@ const char* gla_error_string(int code) {
     case GLA_ERR_UNSUPPORTED: return "unsupported configuration";
     case GLA_ERR_NO_DEVICE: return "no HIP device";
     default:
+      if (code <= -3000) return "RCCL error (ncclResult_t = -code - 3000)";
       if (code <= -1000) return hipGetErrorString((hipError_t)(-code - 1000));
       return "unknown error";
   }

@@ -21,11 +21,66 @@ tests/test_dist_cpu.py covers it with world_size 2); `RowBlockJacobi` / `RowBloc
 import torch
 import torch.distributed as dist
 
-
 class _Done:
     def wait(self):
         return True
 
+class LibComm:
+    """An RCCL communicator owned by libgla_hip (gla_comm_t: ncclCommInitRank + a private communication stream and
+    two events, csrc/gla_dist.hip) spanning the ranks of a torch process group.  With it the halo exchange is two
+    C calls (gla_halo_begin / gla_halo_end, stream-ordered, no host wait) and JacobiGNN's whole sweep loop one
+    (gla_dist_jacobi_sweeps).  Only for GPU ranks of an RCCL ("nccl") group, or a single process."""
+
+    _cache = {}
+
+    def __init__(self, group=None):
+        import ctypes
+        from ._lib import check, lib
+        distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if distributed else 1
+        self.rank = dist.get_rank(group) if distributed else 0
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            check(lib().gla_comm_unique_id(ident))
+        if self.world > 1:
+            box = [bytes(ident.raw)]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group,
+                                       device=torch.device("cuda", torch.cuda.current_device()))
+            ident = ctypes.create_string_buffer(box[0], 128)
+        self._h = ctypes.c_void_p()
+        check(lib().gla_comm_create(ident, self.rank, self.world, ctypes.byref(self._h)))
+
+    @classmethod
+    def for_group(cls, group=None):
+        key = (id(group), torch.cuda.current_device())
+        c = cls._cache.get(key)
+        if c is None:
+            c = cls._cache[key] = cls(group)
+        return c
+
+    @classmethod
+    def release_all(cls):
+        from ._lib import lib
+        for c in cls._cache.values():
+            if c._h:
+                lib().gla_comm_destroy(c._h)
+                c._h = None
+        cls._cache.clear()
+
+    def all_reduce_sum(self, t):
+        from ._lib import check, dtype_code, lib, ptr, stream_ptr
+        assert t.is_cuda and t.is_contiguous()
+        check(lib().gla_comm_all_reduce_sum(self._h, dtype_code(t.dtype), ptr(t), t.numel(), stream_ptr(t.device)))
+        return t
+
+def _use_lib_comm(group, device, host_loop):
+    """The library-side exchange needs GPU operands and either a single process or an RCCL group."""
+    if host_loop or device.type != "cuda":
+        return False
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_backend(group) == "nccl"
 
 class RowBlockPartition:
     def __init__(self, edgeij_pair, n_global, row_lo, row_hi, group=None, col_blocks=None):
@@ -127,11 +182,11 @@ class RowBlockPartition:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-
 class RowBlockOps:
     """The partition bound to a libgla_hip CSR plan of the local block (rows local, columns local + halo)."""
 
-    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None):
+    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None,
+                 host_loop=False):
         from .plan import CsrPlan, ALL_TILES, INTERIOR_TILES, BOUNDARY_TILES
         self.ALL, self.INTERIOR, self.BOUNDARY = ALL_TILES, INTERIOR_TILES, BOUNDARY_TILES
         self.part = RowBlockPartition(edgeij_pair, n_global, row_lo, row_hi, group, col_blocks)
@@ -141,12 +196,39 @@ class RowBlockOps:
         self.overlap = bool(overlap) and p.world > 1 and p.S > 0
         if self.overlap:
             self.plan.classify_tiles(p.n_in)
+        # exchange route: libgla_hip's own RCCL communicator (stream-ordered, no host wait) for GPU ranks of an RCCL
+        # group; torch.distributed collectives driven from Python otherwise (gloo rehearsals, CPU index tests)
+        self.comm = None
+        if p.world > 1 and p.S > 0 and _use_lib_comm(group, edgeij_pair.device, host_loop):
+            self.comm = LibComm.for_group(group)
+            self.send_idx32 = p.send_idx.to(torch.int32).contiguous()
+        self._lib_send = {}
+        self.mode = ("no exchange" if p.world == 1 or p.S == 0 else
+                     ("library-side: gla_halo_begin/end on libgla_hip's RCCL communicator, event-ordered, "
+                      if self.comm is not None else "host-side: torch.distributed all_gather_into_tensor per sweep, ")
+                     + ("interior/boundary overlap" if self.overlap else "no overlap"))
+
+    def _send_buf(self, X):
+        key = (X.shape[1], X.dtype)
+        buf = self._lib_send.get(key)
+        if buf is None:
+            buf = self._lib_send[key] = torch.zeros((self.part.S, X.shape[1]), dtype=X.dtype, device=X.device)
+        return buf
 
     def run(self, X, launch):
         """Exchange X's halo and call launch(which_tiles) for all row tiles, overlapping when enabled."""
         p = self.part
-        if p.world == 1 or p.S == 0:
+        if p.S == 0 or (p.world == 1 and self.comm is None):
             launch(self.ALL)
+        elif self.comm is not None:
+            from ._lib import check, dtype_code, lib, ptr, stream_ptr
+            st = stream_ptr(X.device)
+            check(lib().gla_halo_begin(self.comm._h, dtype_code(X.dtype), X.shape[1], ptr(X), p.n_in,
+                                       ptr(self.send_idx32), p.n_send, p.S, ptr(self._send_buf(X)), st))
+            if self.overlap:
+                launch(self.INTERIOR)
+            check(lib().gla_halo_end(self.comm._h, st))
+            launch(self.BOUNDARY if self.overlap else self.ALL)
         elif self.overlap:
             work = p.exchange(X, async_op=True)
             launch(self.INTERIOR)
@@ -156,6 +238,12 @@ class RowBlockOps:
             p.exchange(X)
             launch(self.ALL)
 
+    def all_reduce_sum(self, t):
+        """Sum over the ranks (power method partial sums): stream-ordered on the library's communicator when there is
+        one, torch.distributed otherwise."""
+        if self.comm is not None and t.is_cuda:
+            return self.comm.all_reduce_sum(t)
+        return self.part.all_reduce_sum(t)
 
 class RowBlockJacobi(RowBlockOps):
     """JacobiGNN.forward on a row block: same arguments as the module, local rows only (JacobiGNN.py:138-148)."""
@@ -170,6 +258,18 @@ class RowBlockJacobi(RowBlockOps):
         cur = p.new_buffer(K, va.dtype, va.device)
         nxt = p.new_buffer(K, va.dtype, va.device)
         cur[:p.n_local] = va[:, 2].reshape(-1, 1) if va.dim() == 2 else va[:, 2, :]
+        if self.comm is not None:
+            # the whole loop -- pack, all-gather on the side stream, interior launch, event wait, boundary launch, per
+            # sweep -- is enqueued by ONE library call (csrc/gla_dist.hip); nothing waits on the host
+            from ._lib import dtype_code, lib, ptr, stream_ptr, check
+            if self.plan.nnz and self.plan.val_dtype != va.dtype:
+                raise ValueError(f"plan holds {self.plan.val_dtype} values, operands are {va.dtype}")
+            check(lib().gla_dist_jacobi_sweeps(self.plan._h, self.comm._h, dtype_code(va.dtype), K, ptr(diag), ptr(B), K,
+                                               ptr(cur), ptr(nxt), p.n_in, ptr(self.send_idx32), p.n_send, p.S,
+                                               ptr(self._send_buf(cur)), w, int(n_iters), int(self.overlap),
+                                               stream_ptr(va.device)))
+            x = (cur if int(n_iters) % 2 == 0 else nxt)[:p.n_local]
+            return x.clone() if va.dim() == 2 else x.unsqueeze(1).clone()
         # shapes are validated once (first sweep through the checked wrapper); the remaining sweeps call the C ABI
         # directly so that the per-sweep host cost stays far below the ~0.3 ms a sweep takes on the GPU
         from ._lib import dtype_code, lib, ptr, stream_ptr, check
@@ -189,7 +289,6 @@ class RowBlockJacobi(RowBlockOps):
             cur, nxt = nxt, cur
         x = cur[:p.n_local]
         return x.clone() if va.dim() == 2 else x.unsqueeze(1).clone()
-
 
 class RowBlockCheby(RowBlockOps):
     """ChebyRelaxGNN(deg).forward on a row block (ChebyGNN.py:324-353); returns (x, r, p, g_out) local rows."""
@@ -219,7 +318,6 @@ class RowBlockCheby(RowBlockOps):
         g_out = torch.hstack([c, d, alpha] if beta is None else [c, d, alpha, beta]).to(g.device)
         return x, r, pc[:p.n_local], g_out
 
-
 class RowBlockPower(RowBlockOps):
     """PowerMethodGNN(num_iter).forward on a row block (PowerMethodGNN.py:296-334): halo exchange per SpMV plus
     an all-reduce of the K (resp. 2K) partial sums per iteration."""
@@ -241,7 +339,7 @@ class RowBlockPower(RowBlockOps):
                 nonlocal work
                 _, _, work = self.plan.power_step(cur, nrm=nrm_in, out=nxt[:p.n_local], which=which, work=work, sumsq=ss)
             self.run(cur, launch)
-            p.all_reduce_sum(ss)
+            self.all_reduce_sum(ss)
             nrm_in = torch.sqrt(ss)
             nrm = nrm_in.clone()
             cur, nxt = nxt, cur
@@ -250,5 +348,5 @@ class RowBlockPower(RowBlockOps):
             buf[:p.n_local] = col_scale_rsqrt(cur[:p.n_local], ss)
         self.run(buf, lambda which: self.plan.spmm(buf, out=y, which=which))
         bl = buf[:p.n_local]
-        sums = p.all_reduce_sum(torch.stack([col_dot(bl, y), col_dot(bl, bl)]))
+        sums = self.all_reduce_sum(torch.stack([col_dot(bl, y), col_dot(bl, bl)]))
         return bl.clone(), torch.stack([nrm, sums[0], sums[0] / sums[1]])

@@ -19,7 +19,8 @@
  *   - "edge order" = the order of the caller's COO edge list (reference tensors edgeij_pair /
  *     edge_attr); "CSR order" = stable sort of the edges by row (edge order kept inside a row, so
  *     in-order row sums equal the reference's sequential scatter-add bit for bit);
- *   - return value: 0 on success, <0 = GLA_ERR_* below, <= -1000 = -(1000 + hipError_t).
+ *   - return value: 0 on success, <0 = GLA_ERR_* below, (-3000, -1000] = -(1000 + hipError_t),
+ *     <= -3000 = -(3000 + ncclResult_t).
  *   - inputs are never mutated unless documented (reference modules return new tensors).
  */
 #ifndef GLA_H
@@ -230,6 +231,38 @@ int gla_direct_interp(gla_csr_t A_od, int dtype, const void* diag, const void* c
 
 /* SA strength of connection, S_e = A_e^2 / (A_ii * A_jj) in edge order.  SOCSAGNN.py:49-71. */
 int gla_soc_sa(gla_csr_t A_od, int dtype, const void* diag, void* S_out, gla_stream_t stream);
+
+/* ---- multi-GPU: row-block partition, halo all-gather over RCCL / xGMI ------------------------------------- */
+/* The reference has no distributed code; BASELINE.json (north_star, configs 4-5) defines this
+ * layer: one process per GPU, contiguous row blocks, one all-gather of the halo vertices per SpMV.  A rank's X
+ * buffer is [n_in | nranks * S] x K (leading dimension K): its own n_in input entries, then the all-gathered send
+ * slots of every rank (S = longest send list; gnn_applied_linear_algebra_amd/dist.py builds the column
+ * renumbering).  RCCL is bound at run time (dlopen librccl.so.1); without it these return GLA_ERR_UNSUPPORTED.
+ * RCCL errors are returned as -(3000 + ncclResult_t). */
+typedef struct gla_comm* gla_comm_t;
+/* Rank 0 obtains a 128-byte id (ncclGetUniqueId) and distributes it by any means; every rank then calls
+ * gla_comm_create on its own device (ncclCommInitRank + a private communication stream and two events). */
+int gla_comm_unique_id(void* id128_host);
+int gla_comm_create(const void* id128_host, int rank, int nranks, gla_comm_t* out);
+int gla_comm_destroy(gla_comm_t comm);
+int gla_comm_ranks(gla_comm_t comm, int* rank_host, int* nranks_host);
+/* Start the halo exchange of X: pack rows send_idx[0..n_send) into send_buf [S, K] on `stream`, then all-gather
+ * send_buf into X[n_in:] on the communicator's stream.  Returns at once; gla_halo_end makes `stream` wait for the
+ * gathered halo (stream-ordered, the host never blocks).  Kernels that read only X[:n_in] (interior row tiles,
+ * which_tiles = 1) may be enqueued in between. */
+int gla_halo_begin(gla_comm_t comm, int dtype, int K, void* X, int64_t n_in, const int32_t* send_idx,
+                   int64_t n_send, int64_t S, void* send_buf, gla_stream_t stream);
+int gla_halo_end(gla_comm_t comm, gla_stream_t stream);
+/* In-place sum over the ranks of `count` device values, stream-ordered (power method: the K resp. 2K partial sums
+ * of PowerMethodGNN.py:50-61 vertex_to_global_aggregation). */
+int gla_comm_all_reduce_sum(gla_comm_t comm, int dtype, void* buf, int64_t count, gla_stream_t stream);
+/* n_iters Jacobi sweeps of this rank's row block with the halo exchange of every sweep, enqueued entirely from the
+ * library (JacobiGNN.py:138-148 on the rank's rows).  Xa / Xb: [n_in + nranks * S, K] buffers; Xa[:n_rows] holds x0;
+ * the result is in Xa[:n_rows] for even n_iters, else in Xb[:n_rows].  overlap = 1: interior tiles run while the
+ * halo is in flight (classify the plan with gla_csr_classify_tiles(plan, n_in) first). */
+int gla_dist_jacobi_sweeps(gla_csr_t A, gla_comm_t comm, int dtype, int K, const void* diag, const void* B,
+                           int64_t ldb, void* Xa, void* Xb, int64_t n_in, const int32_t* send_idx, int64_t n_send,
+                           int64_t S, void* send_buf, double w, int n_iters, int overlap, gla_stream_t stream);
 
 /* ---- builders ----------------------------------------------------------------------------------- */
 /* 5-point negative Laplacian on an Ny x Nx grid (reference: Ny == Nx == N), COO sorted row-major with

@@ -1,0 +1,44 @@
+"""bench.py's launcher: `python bench.py --gpus N` must work as typed -- the parent starts N fresh rank processes and
+itself never imports torch or touches the GPU (a process that initialised HIP must not be replaced or forked)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=120)
+
+
+def test_parent_spawns_one_process_per_gpu_without_touching_torch():
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--launch-dry-run"])
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout)
+    assert plan["torch_imported_in_parent"] is False
+    kids = plan["children"]
+    assert len(kids) == 8
+    ports = {k["env"]["MASTER_PORT"] for k in kids}
+    assert len(ports) == 1
+    for r_, k in enumerate(kids):
+        e = k["env"]
+        assert e["RANK"] == str(r_) and e["LOCAL_RANK"] == str(r_) and e["WORLD_SIZE"] == "8"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert k["cmd"][1].endswith("bench.py") and k["cmd"][2:] == ["--gpus", "8", "--steps", "3", "--warmup", "1",
+                                                                      "--launch-dry-run"]
+
+
+def test_parent_relays_child_failure_as_nonzero_exit():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine WITHOUT a GPU (the ranks are expected to fail)")
+    """No GPU in this container: the ranks fail at the first device call; the parent must report that, not rc 0."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--single-device",
+              "--child-timeout", "90"])
+    assert r.returncode != 0
+    assert "Traceback" in r.stderr or "Error" in r.stderr
