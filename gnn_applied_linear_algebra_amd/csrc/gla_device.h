@@ -21,6 +21,7 @@ struct TileMap {
   int n_tiles;                // tiles to run in this launch
   int tiles_per_xcd;
   int xcd_chunk;              // see map_tile
+  int lds_cap = 0x7fffffff;   // tiles with more nonzeros than this are single long rows (CSR-adaptive "long" bin)
 };
 
 // grid = 8 * tiles_per_xcd workgroups; with chunking the per-XCD count is rounded up to whole chunks so that the
@@ -109,6 +110,65 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// CSR-adaptive "long" bin: a row with more than GLA_LONG_ROW nonzeros is a row tile of its own.  The whole workgroup
+// works on it: the nonzeros are cut into C = 256 / KL contiguous chunks (KL = lanes across the right-hand sides), every
+// lane adds its chunk in edge order, and the C partial sums are combined by a fixed binary tree over the chunk index --
+// deterministic and launch-independent, but (unlike the stream tiles' strictly sequential sums) not the association
+// order of a CPU scatter-add.  `sh` is workgroup LDS scratch of GLA_BLOCK elements.
+// ------------------------------------------------------------------------------------------------
+template <typename T, class Op>
+__device__ __forceinline__ T block_tree(T v, T* sh, int KL, Op op) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  sh[tid] = v;
+  __syncthreads();
+  for (int st = GLA_BLOCK / 2; st >= KL; st >>= 1) {
+    if (tid < st) sh[tid] = op(sh[tid], sh[tid + st]);
+    __syncthreads();
+  }
+  return sh[tid % KL];
+}
+
+struct ChunkRange { int a, b; };
+__device__ __forceinline__ ChunkRange chunk_of(int s, int e, int c, int C) {
+  const int len = e - s, clen = (len + C - 1) / C;
+  return ChunkRange{s + min(c * clen, len), s + min((c + 1) * clen, len)};
+}
+
+template <typename T, class Epi>
+__device__ void long_row_spmm(const int32_t* __restrict__ col, const T* __restrict__ val, int s, int e, int r, int t,
+                              const T* __restrict__ X, int64_t ldx, int K, const Epi& epi, T* sh) {
+  int KL = 1;
+  while (KL * 2 <= K && KL < 64) KL <<= 1;
+  const int tid = threadIdx.x, kk = tid % KL;
+  const ChunkRange cr = chunk_of(s, e, tid / KL, GLA_BLOCK / KL);
+  for (int kb = 0; kb < K; kb += KL) {
+    const bool live = kb + kk < K;
+    const int k = live ? kb + kk : K - 1;
+    const auto gxs = epi.template gx_load<T>(k);
+    T acc = T(0);
+    int j = cr.a;
+    for (; j + 8 <= cr.b; j += 8) {                 // eight independent gathers in flight, added in edge order
+      T v[8], xv[8];
+      int c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v[u] = val[j + u]; c[u] = col[j + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = epi.gx(X[(int64_t)c[u] * ldx + k], gxs);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = acc + v[u] * xv[u];
+    }
+    for (; j < cr.b; ++j) acc = acc + val[j] * epi.gx(X[(int64_t)col[j] * ldx + k], gxs);
+    const T tot = block_tree(acc, sh, KL, [](T a, T b) { return a + b; });
+    if (tid < KL && live) {
+      const auto pre = epi.load((int64_t)r, k);
+      epi.apply((int64_t)r, k, tot, pre);
+      if constexpr (Epi::NRED > 0) epi.partials_ptr()[(int64_t)t * K + k] = epi.redv(tot, pre);
+    }
+  }
+}
+
 inline int check_plan(gla_csr* A, int dtype, int K) {
   if (!A || K < 1 || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
@@ -172,6 +232,7 @@ inline unsigned grid_for(int64_t work, int per_block = GLA_BLOCK, int cap = 256 
 
 inline TileMap all_tiles(gla_csr* A) {
   TileMap tm;
+  tm.lds_cap = A->lds_elems;
   tm.tile_row = A->tile_row;
   tm.tile_info = reinterpret_cast<const int4*>(A->tile_info);
   tm.tile_list = nullptr;

@@ -56,6 +56,18 @@ __global__ __launch_bounds__(GLA_BLOCK) void soc_classic_kernel(
   const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
   if (r0 >= r1) return;
   const int tid = threadIdx.x;
+  if (len > tm.lds_cap) {                      // CSR-adaptive long bin: one row, whole workgroup (max is order-free)
+    const ChunkRange cr = chunk_of(s, s + len, tid, GLA_BLOCK);
+    T m = T(-1) * val[s];
+    for (int j = cr.a; j < cr.b; ++j) m = nan_max(m, T(-1) * val[j]);
+    m = block_tree(m, sv, 1, [](T a, T b) { return nan_max(a, b); });
+    if (tid == 0) v_out[r0] = m;
+    for (int j = s + tid; j < s + len; j += GLA_BLOCK) {
+      const T q = (T(-1) * val[j]) / m - theta;
+      S_out[perm ? (int64_t)perm[j] : (int64_t)j] = (q != q) ? q : (q > T(0) ? q : T(0));
+    }
+    return;
+  }
   {
     T v_[4];
 #define SOC_LD(u, i) v_[u] = val[s + (i)]
@@ -104,6 +116,24 @@ __global__ __launch_bounds__(GLA_BLOCK) void direct_interp_kernel(
   const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
   if (r0 >= r1) return;
   const int tid = threadIdx.x;
+  if (len > tm.lds_cap) {                      // CSR-adaptive long bin: one row, fixed-chunk sums by the whole workgroup
+    const ChunkRange cr = chunk_of(s, s + len, tid, GLA_BLOCK);
+    T num = T(0), den = T(0);
+    for (int j = cr.a; j < cr.b; ++j) {
+      const T a = val[j];
+      num = num + a;
+      den = den + (a * S[perm ? (int64_t)perm[j] : (int64_t)j]) * cf[col[j]];
+    }
+    num = block_tree(num, sa, 1, [](T a, T b) { return a + b; });
+    den = block_tree(den, sa, 1, [](T a, T b) { return a + b; });
+    const T gamma = num / den;
+    const T alpha = (T(1) / diag[r0]) * gamma;
+    if (alpha_out && tid == 0) alpha_out[r0] = alpha;
+    const T omc = T(1) - cf[r0];
+    for (int j = s + tid; j < s + len; j += GLA_BLOCK)
+      w_out[perm ? (int64_t)perm[j] : (int64_t)j] = omc * ((T(-1) * val[j]) * alpha);
+    return;
+  }
   {
     T a_[4], s_[4], c_[4];
 #define DI_LD(u, i)                                                                  \
@@ -156,6 +186,14 @@ __global__ __launch_bounds__(GLA_BLOCK) void soc_sa_kernel(
   const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
   if (r0 >= r1) return;
   const int tid = threadIdx.x;
+  if (len > tm.lds_cap) {                      // CSR-adaptive long bin: one row, purely edge-wise
+    const T di = diag[r0];
+    for (int j = s + tid; j < s + len; j += GLA_BLOCK) {
+      const T a = val[j];
+      S_out[perm ? (int64_t)perm[j] : (int64_t)j] = (a * a) / (di * diag[col[j]]);
+    }
+    return;
+  }
   {
     T a_[4], d_[4];
 #define SA_LD(u, i) { a_[u] = val[s + (i)]; d_[u] = diag[col[s + (i)]]; }
@@ -190,11 +228,37 @@ __global__ __launch_bounds__(GLA_BLOCK) void soc_sa_kernel(
 template <typename T, int KP>
 __global__ __launch_bounds__(GLA_BLOCK) void segment_reduce_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm, const T* __restrict__ src, int64_t lds_,
-    int K, int op, int64_t n_rows, T* __restrict__ out, int64_t ldo) {
+    int K, int op, int64_t n_rows, T* __restrict__ out, int64_t ldo, const int32_t* __restrict__ long_ids,
+    int n_long) {
   constexpr int RPP = GLA_BLOCK / KP;
   const int k0 = threadIdx.x % KP, rsub = threadIdx.x / KP;
-  for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n_rows; r += (int64_t)gridDim.x * RPP) {
+  const int nb = (int)gridDim.x - n_long;        // the last n_long workgroups take one long row each
+  if ((int)blockIdx.x >= nb) {
+    __shared__ T sh[GLA_BLOCK];
+    const int64_t r = long_ids[(int)blockIdx.x - nb];
     const int a = rowptr[r], b = rowptr[r + 1];
+    const ChunkRange cr = chunk_of(a, b, threadIdx.x / KP, RPP);
+    for (int kb = 0; kb < K; kb += KP) {
+      const bool live = kb + k0 < K;
+      const int k = live ? kb + k0 : K - 1;
+      T acc = (op == 0 || op == 3) ? T(0) : src[(perm ? (int64_t)perm[a] : (int64_t)a) * lds_ + k];
+      for (int p = cr.a; p < cr.b; ++p) {
+        const T v = src[(perm ? (int64_t)perm[p] : (int64_t)p) * lds_ + k];
+        if (op == 0 || op == 3) acc = acc + v;
+        else if (op == 1) acc = (v > acc || v != v) ? v : acc;
+        else acc = (v < acc || v != v) ? v : acc;
+      }
+      if (op == 0 || op == 3) acc = block_tree(acc, sh, KP, [](T x, T y) { return x + y; });
+      else if (op == 1) acc = block_tree(acc, sh, KP, [](T x, T y) { return (y > x || y != y) ? y : x; });
+      else acc = block_tree(acc, sh, KP, [](T x, T y) { return (y < x || y != y) ? y : x; });
+      if (op == 3) acc = acc / T(b - a);
+      if (threadIdx.x < KP && live) out[r * ldo + k] = acc;
+    }
+    return;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * RPP + rsub; r < n_rows; r += (int64_t)nb * RPP) {
+    const int a = rowptr[r], b = rowptr[r + 1];
+    if (n_long > 0 && b - a > GLA_LONG_ROW) continue;      // summed by its own workgroup above
     for (int k = k0; k < K; k += KP) {
       T acc = T(0);
       for (int p = a; p < b; ++p) {
@@ -487,10 +551,10 @@ int launch_segment_reduce(gla_csr* A, int K, const T* src, int64_t ld_src, int o
                           hipStream_t st) {
   int kp = 1;
   while (kp < K && kp < 64) kp <<= 1;
-  const unsigned grid = grid_for(A->n_rows, GLA_BLOCK / kp, 256 * 16);
+  const unsigned grid = grid_for(A->n_rows, GLA_BLOCK / kp, 256 * 16) + (unsigned)A->long_rows;
 #define GLA_SEG(KP_)                                                                                            \
   hipLaunchKernelGGL((segment_reduce_kernel<T, KP_>), dim3(grid), dim3(GLA_BLOCK), 0, st, A->rowptr, A->perm,  \
-                     src, ld_src, K, op, A->n_rows, out, ld_out)
+                     src, ld_src, K, op, A->n_rows, out, ld_out, A->long_row_ids, (int)A->long_rows)
   switch (kp) {
     case 1: GLA_SEG(1); break;
     case 2: GLA_SEG(2); break;
@@ -710,7 +774,6 @@ int gla_soc_classic(gla_csr_t A, int dtype, double theta, void* v_out, void* S_o
   if (rc) return rc;
   if (!v_out && A->n_rows > 0) return GLA_ERR_INVALID_ARG;
   if (!S_out && A->nnz > 0) return GLA_ERR_INVALID_ARG;
-  if (A->long_rows) return GLA_ERR_UNSUPPORTED;
   if (A->n_rows == 0) return GLA_OK;
   TileMap tm = all_tiles(A);
   GLA_DISPATCH(dtype, {
@@ -729,7 +792,6 @@ int gla_direct_interp(gla_csr_t A, int dtype, const void* diag, const void* cf, 
   if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
   if (A->n_rows > 0 && (!diag || !cf)) return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && (!S || !w_out)) return GLA_ERR_INVALID_ARG;
-  if (A->long_rows) return GLA_ERR_UNSUPPORTED;
   if (A->n_rows == 0) return GLA_OK;
   TileMap tm = all_tiles(A);
   GLA_DISPATCH(dtype, {
@@ -747,7 +809,6 @@ int gla_soc_sa(gla_csr_t A, int dtype, const void* diag, void* S_out, gla_stream
   if (rc) return rc;
   if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
   if ((A->n_rows > 0 && !diag) || (A->nnz > 0 && !S_out)) return GLA_ERR_INVALID_ARG;
-  if (A->long_rows) return GLA_ERR_UNSUPPORTED;
   if (A->n_rows == 0) return GLA_OK;
   TileMap tm = all_tiles(A);
   GLA_DISPATCH(dtype, {

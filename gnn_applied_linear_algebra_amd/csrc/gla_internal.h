@@ -16,8 +16,11 @@ constexpr int GLA_BLOCK = 256;          // 4 wavefronts of 64 lanes
 constexpr int GLA_XCDS = 8;             // MI355X: 8 XCDs, each with a private L2
 constexpr int GLA_LDS_ELEMS_MAX = 4096; // staged nnz per workgroup (32 KiB of f64 products)
 constexpr int GLA_TILE_NNZ_MIN = 1024;
-constexpr int GLA_PAD = 8;
-constexpr int GLA_DIA_MAX = 16;              // over-read slack (elements) behind val/col
+constexpr int GLA_PAD = 8;              // over-read slack (elements) behind val/col
+constexpr int GLA_DIA_MAX = 16;
+// rows longer than this never share an LDS tile: each is a row tile of its own (CSR-adaptive "long" bin) and is summed by
+// the whole workgroup in 256 fixed chunks; shorter rows stay in stream tiles with strictly in-order sums
+constexpr int GLA_LONG_ROW = GLA_LDS_ELEMS_MAX - GLA_TILE_NNZ_MIN;
 
 struct gla_csr {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
@@ -31,7 +34,8 @@ struct gla_csr {
   int32_t* tile_lists = nullptr; // [2 * n_tiles]: interior tiles then boundary tiles
   int32_t n_tiles = 0, n_interior = 0, n_boundary = 0;
   int32_t tile_nnz = 0, lds_elems = 0, max_row_len = 0;
-  int32_t sorted_input = 1, long_rows = 0;
+  int32_t sorted_input = 1, long_rows = 0;   // long_rows: number of rows with more than GLA_LONG_ROW nonzeros
+  int32_t* long_row_ids = nullptr;           // [long_rows] their row ids, ascending (device)
   // optional packed stream for the K = 1 kernels (option "compress"): 3 bytes per nonzero instead of 12
   int16_t* col16 = nullptr;      // [nnz + 16] column minus the first row of the nonzero's tile
   uint8_t* vcode = nullptr;      // [nnz + 16] index into vdict

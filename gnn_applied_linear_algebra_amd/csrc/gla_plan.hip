@@ -5,7 +5,9 @@
 // done once per graph: validate indices, stable-sort by row if needed (edge order is preserved inside a
 // row so that row sums keep the reference's summation order), build rowptr, measure the longest row and
 // cut the rows into tiles of ~tile_nnz nonzeros for the CSR-stream kernels.
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 #include <cstring>
 #include "gla_internal.h"
 #include <rocprim/device/device_radix_sort.hpp>
@@ -78,6 +80,24 @@ __global__ __launch_bounds__(GLA_BLOCK) void max_row_len_kernel(const int32_t* _
     m = max(m, rowptr[r + 1] - rowptr[r]);
   for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
   if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+// rows longer than `limit`: ids appended to list (any order, sorted on the host), out[0] = their number,
+// out[1] = the longest of the OTHER rows (what the LDS tile of the stream bin has to hold)
+__global__ __launch_bounds__(GLA_BLOCK) void long_rows_kernel(const int32_t* __restrict__ rowptr, int64_t n_rows,
+                                                              int limit, int* out, int32_t* __restrict__ list, int cap) {
+  int m = 0;
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int len = rowptr[r + 1] - rowptr[r];
+    if (len > limit) {
+      const int i = atomicAdd(out, 1);
+      if (i < cap) list[i] = (int32_t)r;
+    } else {
+      m = max(m, len);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out + 1, m);
 }
 
 // tile_row[k] = first row r with rowptr[r] >= k * tile_nnz (k < n_tiles); tile_row[n_tiles] = n_rows
@@ -510,7 +530,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void rowoff16_kernel(const int32_t* __re
 }
 
 int build_col16(gla_csr* p, hipStream_t st) {
-  if (p->col16_state != 0 || p->nnz == 0 || p->long_rows) return GLA_OK;
+  if (p->col16_state != 0 || p->nnz == 0) return GLA_OK;
   hipError_t e;
 #define PK(expr) do { e = (expr); if (e != hipSuccess) return -(1000 + (int)e); } while (0)
   int* d_fail = nullptr;
@@ -706,6 +726,7 @@ int gla_csr_destroy(gla_csr_t p) {
   if (p->tile_row) (void)hipFree(p->tile_row);
   if (p->tile_info) (void)hipFree(p->tile_info);
   if (p->tile_lists) (void)hipFree(p->tile_lists);
+  if (p->long_row_ids) (void)hipFree(p->long_row_ids);
   if (p->col16) (void)hipFree(p->col16);
   if (p->col16_wide) (void)hipFree(p->col16_wide);
   if (p->rowoff16) (void)hipFree(p->rowoff16);
@@ -770,24 +791,61 @@ int gla_csr_create_from_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const i
   PLAN_CHECK(hipStreamSynchronize(st));
   p->max_row_len = h_flags[1];
   {
-    // CSR-stream binning: ~256 rows per tile for the average row, bounded by the LDS tile.
+    // CSR-adaptive binning.  Stream bin: ~256 rows per tile for the average row, bounded by the LDS tile.  Long bin:
+    // every row with more than GLA_LONG_ROW nonzeros becomes a tile of its own (tile boundaries are inserted before and
+    // after it), so one hub row neither blows the LDS tile of its neighbours nor changes how THEIR sums are formed.
+    int short_max = p->max_row_len;
+    std::vector<int32_t> long_ids;
+    if (p->max_row_len > GLA_LONG_ROW) {
+      const int cap = (int)(nnz / (GLA_LONG_ROW + 1)) + 1;
+      int32_t* d_list = nullptr;
+      int h_out[2] = {0, 0};
+      PLAN_CHECK(hipMalloc(&d_list, (size_t)cap * sizeof(int32_t)));
+      PLAN_CHECK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), st));
+      hipLaunchKernelGGL(long_rows_kernel, dim3(grid_for(n_rows)), dim3(GLA_BLOCK), 0, st, p->rowptr, n_rows,
+                         GLA_LONG_ROW, d_flags, d_list, cap);
+      PLAN_CHECK(hipGetLastError());
+      PLAN_CHECK(hipMemcpyAsync(h_out, d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      PLAN_CHECK(hipStreamSynchronize(st));
+      long_ids.resize((size_t)h_out[0]);
+      PLAN_CHECK(hipMemcpy(long_ids.data(), d_list, long_ids.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      (void)hipFree(d_list);
+      std::sort(long_ids.begin(), long_ids.end());
+      short_max = h_out[1];
+      p->long_rows = (int32_t)long_ids.size();
+      PLAN_CHECK(hipMalloc(&p->long_row_ids, long_ids.size() * sizeof(int32_t)));
+      PLAN_CHECK(hipMemcpy(p->long_row_ids, long_ids.data(), long_ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     const double avg = n_rows > 0 ? (double)nnz / (double)n_rows : 0.0;
     int64_t target = (int64_t)(GLA_BLOCK * (avg < 1.0 ? 1.0 : avg) + 0.5);
     if (target < GLA_TILE_NNZ_MIN) target = GLA_TILE_NNZ_MIN;
     // packed stream: one batch of 8 nonzeros per lane covers 2048 entries (incl. alignment slack and the last row)
     if (g_tuning.compress && p->max_row_len <= 1000) target = 2040 - p->max_row_len;
     if (g_tuning.tile_nnz > 0) target = g_tuning.tile_nnz;
-    p->long_rows = (p->max_row_len > GLA_LDS_ELEMS_MAX - GLA_TILE_NNZ_MIN) ? 1 : 0;
-    if (!p->long_rows && target > GLA_LDS_ELEMS_MAX - p->max_row_len) target = GLA_LDS_ELEMS_MAX - p->max_row_len;
+    if (target > GLA_LDS_ELEMS_MAX - short_max) target = GLA_LDS_ELEMS_MAX - short_max;
     p->tile_nnz = (int32_t)target;
-    p->lds_elems = p->long_rows ? 0 : (int32_t)(target + p->max_row_len);
+    p->lds_elems = (int32_t)(target + short_max);
     int64_t nt = (nnz + target - 1) / target;
     if (nt < 1) nt = 1;
     p->n_tiles = (int32_t)nt;
-    PLAN_CHECK(hipMalloc(&p->tile_row, (nt + 1) * sizeof(int32_t)));
+    PLAN_CHECK(hipMalloc(&p->tile_row, (nt + 1 + 2 * long_ids.size()) * sizeof(int32_t)));
     hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((nt + 1 + GLA_BLOCK - 1) / GLA_BLOCK)), dim3(GLA_BLOCK), 0,
                        st, p->rowptr, n_rows, p->n_tiles, p->tile_nnz, p->tile_row);
     PLAN_CHECK(hipGetLastError());
+    if (!long_ids.empty()) {
+      // merge the regular boundaries with {r, r + 1} of every long row; equal boundaries (the empty tiles a long row
+      // leaves behind in the regular grid) collapse
+      std::vector<int32_t> bnd((size_t)nt + 1);
+      PLAN_CHECK(hipMemcpyAsync(bnd.data(), p->tile_row, bnd.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      PLAN_CHECK(hipStreamSynchronize(st));
+      for (int32_t r : long_ids) { bnd.push_back(r); bnd.push_back(r + 1); }
+      std::sort(bnd.begin(), bnd.end());
+      bnd.erase(std::unique(bnd.begin(), bnd.end()), bnd.end());
+      nt = (int64_t)bnd.size() - 1;
+      if (nt < 1) { nt = 1; bnd.assign({0, (int32_t)n_rows}); }
+      p->n_tiles = (int32_t)nt;
+      PLAN_CHECK(hipMemcpy(p->tile_row, bnd.data(), bnd.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     PLAN_CHECK(hipMalloc(&p->tile_info, nt * 4 * sizeof(int32_t)));
     hipLaunchKernelGGL(tile_info_kernel, dim3((unsigned)((nt + GLA_BLOCK - 1) / GLA_BLOCK)), dim3(GLA_BLOCK), 0, st,
                        p->rowptr, p->tile_row, p->n_tiles, reinterpret_cast<int4*>(p->tile_info));
@@ -887,7 +945,7 @@ int gla_csr_classify_tiles(gla_csr_t p, int64_t col_limit, gla_stream_t stream, 
   int32_t* d_flag = nullptr;
   GLA_HIP_CHECK(hipMalloc(&d_flag, nt * sizeof(int32_t)));
   GLA_HIP_CHECK(hipMemsetAsync(d_flag, 0, nt * sizeof(int32_t), st));
-  if (!p->long_rows && p->n_rows > 0) {
+  if (p->n_rows > 0) {
     const int32_t lim = (int32_t)(col_limit > INT32_MAX ? INT32_MAX : col_limit);
     hipLaunchKernelGGL(tile_flag_kernel, dim3(nt), dim3(GLA_BLOCK), 0, st, p->rowptr, p->col, p->tile_row, nt, lim,
                        d_flag);

@@ -13,8 +13,9 @@
 //
 // Tiles are contiguous row ranges holding ~tile_nnz nonzeros (CSR-adaptive "stream" binning computed at
 // plan creation); blockIdx is remapped so that the XCDs take turns of 64 consecutive tiles (gla_device.h,
-// map_tile): all of them stream one common region of HBM and a tile's x window stays in its XCD's L2.  Matrices with a row longer than the LDS tile fall back to a
-// wave-per-row (CSR-vector) kernel whose sums are tree-ordered (documented in DESIGN.md).
+// map_tile): all of them stream one common region of HBM and a tile's x window stays in its XCD's L2.  A row longer than
+// GLA_LONG_ROW is a tile of its own (the "long" bin): every kernel sends such a tile to long_row_spmm (gla_device.h),
+// where the whole workgroup sums it in fixed chunks; all other rows keep their strictly in-order sums.
 //
 // Multi-RHS (K > 1, row-major [n, K]): val/col are staged in LDS instead of products, and the lanes
 // are (row, rhs) pairs so that every gather reads K contiguous values of one X row.
@@ -212,6 +213,10 @@ __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
   const int4 ti = tm.tile_info[t];
   const int r0 = ti.x, r1 = ti.y, s = ti.z, e = ti.w;
   if (r0 >= r1) return;
+  if (e - s > tm.lds_cap) {                    // CSR-adaptive long bin: this tile is ONE row, summed by the whole workgroup
+    long_row_spmm<T>(col, val, s, e, r0, t, x, (int64_t)1, 1, epi, prod);
+    return;
+  }
   const int tid = threadIdx.x;
   const int r = r0 + tid;
   int ra = 0, rb = 0;
@@ -500,6 +505,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_kernel(
   if (r0 >= r1) return;
   const int s = rowptr[r0];
   const int len = rowptr[r1] - s;
+  if (len > tm.lds_cap) {                      // CSR-adaptive long bin: one row, whole workgroup
+    long_row_spmm<T>(col, val, s, s + len, r0, t, X, ldx, K, epi, sval);
+    return;
+  }
   const int tid = threadIdx.x;
   {
     T v_[4];
@@ -545,6 +554,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
   const int4 ti = tm.tile_info[t];
   const int r0 = ti.x, r1 = ti.y, s = ti.z, len = ti.w - ti.z;
   if (r0 >= r1) return;
+  if (len > tm.lds_cap) {                      // CSR-adaptive long bin: one row, whole workgroup
+    long_row_spmm<T>(col, val, s, s + len, r0, t, X, ldx, K, epi, sval);
+    return;
+  }
   const int tid = threadIdx.x;
   const int nrow_staged = min(r1 - r0, SPMM_ROWCAP);
   for (int i = tid; i <= nrow_staged; i += GLA_BLOCK) srow[i] = rowptr[r0 + i] - s;
@@ -650,45 +663,14 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// fallback for plans with a row longer than the LDS tile: one wave per row, tree-ordered sum
-// ------------------------------------------------------------------------------------------------
-template <typename T, class Epi>
-__global__ __launch_bounds__(GLA_BLOCK) void spmm_vector_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
-    const T* __restrict__ X, int64_t ldx, int K, int64_t n_rows, Epi epi) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x) >> 6;
-  const int64_t n_waves = ((int64_t)gridDim.x * GLA_BLOCK) >> 6;
-  for (int64_t r = wave; r < n_rows; r += n_waves) {
-    const int a = rowptr[r], b = rowptr[r + 1];
-    for (int k = 0; k < K; ++k) {
-      T acc = T(0);
-      for (int j = a + lane; j < b; j += 64) acc = acc + val[j] * X[(int64_t)col[j] * ldx + k];
-      acc = wave_sum(acc);
-      if (lane == 0) epi(r, k, acc);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // launch helper
 // ------------------------------------------------------------------------------------------------
 template <typename T, class Epi>
 int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int which, hipStream_t st) {
   if (A->n_rows == 0) return GLA_OK;
   const T* val = static_cast<const T*>(A->val);
-  if (Epi::NRED > 0 && (A->long_rows || (K > 1 && !((K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec_ok(2)))))
+  if (Epi::NRED > 0 && K > 1 && !((K % 2 == 0) && (ldx % 2 == 0) && al16(X) && epi.vec_ok(2)))
     return GLA_ERR_UNSUPPORTED;           // reducing epilogues exist for the K = 1 and paired-rhs kernels only
-  if (A->long_rows) {
-    if (which == 1) return GLA_OK;        // nothing is "interior" for the fallback: all rows run after the halo
-    const int64_t waves_needed = A->n_rows;
-    int64_t blocks = (waves_needed * 64 + GLA_BLOCK - 1) / GLA_BLOCK;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL((spmm_vector_kernel<T, Epi>), dim3((unsigned)blocks), dim3(GLA_BLOCK), 0, st,
-                       A->rowptr, A->col, val, X, ldx, K, A->n_rows, epi);
-    GLA_LAUNCH_CHECK();
-    return GLA_OK;
-  }
   {
     int64_t d_lo = -1, d_hi = -1;                 // rows the diagonal kernel may take for this launch
     const bool constv = A->dia_const && g_tuning.compress;      // opted-in: constant diagonals, no value stream
@@ -737,6 +719,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
     }
   }
   TileMap tm;
+  tm.lds_cap = A->lds_elems;                 // tiles above it are single long rows (whole-workgroup path in every kernel)
   tm.tile_row = A->tile_row;
   tm.tile_info = reinterpret_cast<const int4*>(A->tile_info);
   if (which == 0) { tm.tile_list = nullptr; tm.n_tiles = A->n_tiles; }
@@ -747,7 +730,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   if (tm.n_tiles == 0) return GLA_OK;
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
-  if (K == 1 && ldx == 1 && A->packed && g_tuning.compress && A->n_cols * (int64_t)sizeof(T) < ((int64_t)1 << 32)) {
+  if (K == 1 && ldx == 1 && A->packed && !A->long_rows && g_tuning.compress && A->n_cols * (int64_t)sizeof(T) < ((int64_t)1 << 32)) {
     const size_t ldsp = (size_t)(256 + A->lds_elems + 16) * sizeof(T);
     hipLaunchKernelGGL((spmv_packed_kernel<T, Epi>), grid, block, ldsp, st, A->rowptr, A->col16, A->vcode,
                        (const T*)A->vdict, X, (unsigned)A->n_cols, tm, epi, A->rowoff16);

@@ -348,7 +348,8 @@ def test_ragged_unsorted_and_long_rows():
     x = torch.rand(100, 1, generator=gen, dtype=torch.float64)
     va, _, _ = gnn(d(x), d(ei_w), d(W.reshape(-1, 1)), None)
     eq(va, rp.matvec_layer(x, ei_w, W.reshape(-1, 1))[0])
-    # one row of 6000 nnz forces the CSR-vector fallback (tree-ordered sums): tolerance, not bit-exact
+    # one row of 6000 nnz goes to the CSR-adaptive long bin (whole-workgroup chunked sum: tolerance for THAT row); every
+    # other row keeps its in-order sum and stays bit-exact
     rows = torch.cat([torch.full((6000,), 5), torch.arange(50)])
     cols = torch.cat([torch.randint(0, 50, (6000,), generator=gen), torch.arange(50)])
     ei_l = torch.stack([rows, cols])
@@ -357,7 +358,127 @@ def test_ragged_unsorted_and_long_rows():
     plan = gla.CsrPlan(d(ei_l), 50)
     assert plan.info.long_rows == 1
     va, _, _ = gnn(d(x), d(ei_l), d(ev_l), None)
-    close(va, rp.matvec_layer(x, ei_l, ev_l)[0], rtol=1e-13)
+    want = rp.matvec_layer(x, ei_l, ev_l)[0]
+    close(va, want, rtol=1e-13)
+    short = torch.arange(50) != 5
+    eq(va.cpu()[short], want[short])
+
+
+def _hub_graph(n, hubs, hub_len, gen, offdiag=True):
+    """n rows with 3..7 random off-diagonal entries each, plus `hub_len` extra entries in each row of `hubs`;
+    row-sorted, columns in random order inside a row."""
+    lens = torch.randint(3, 8, (n,), generator=gen)
+    for h in hubs:
+        lens[h] += hub_len
+    rows = torch.repeat_interleave(torch.arange(n), lens)
+    cols = torch.randint(0, n - 1, (rows.numel(),), generator=gen)
+    if offdiag:
+        cols = cols + (cols >= rows).long()                   # never the diagonal
+    return torch.stack([rows, cols])
+
+
+def test_csr_adaptive_long_row_bin_every_entry_point():
+    """1 M short rows + three 6 000-nnz hub rows (first row, a middle row, last row): every entry point accepts the
+    plan; short rows are bit-exact against the oracle, hub rows agree to rounding (fixed-chunk sums); the SpMV costs
+    what it costs without the hubs (+ 10 %)."""
+    gen = torch.Generator().manual_seed(77)
+    n, hubs = 1_000_000, [0, 431_977, 999_999]
+    ei = _hub_graph(n, hubs, 6000, gen)
+    nnz = ei.shape[1]
+    ev = torch.rand(nnz, 1, generator=gen, dtype=torch.float64) - 0.7
+    ev[ev == 0] = 0.1
+    short = torch.ones(n, dtype=torch.bool)
+    short[hubs] = False
+    e_short = short[ei[0]]
+    ei_d, ev_d = d(ei), d(ev)
+    plan = gla.plan_for(ei_d, n, edge_attr=ev_d)
+    assert plan.info.long_rows == 3 and plan.info.lds_elems <= 4096 and plan.info.max_row_len > 6000
+
+    def check_rows(got, want, rtol=1e-12):
+        got = got.cpu()
+        eq(got[short], want[short])
+        close(got[~short], want[~short], rtol=rtol)
+
+    # ---- SpMM, K = 1, 2 (paired lanes), 3 (scalar lanes), 16
+    for K in (1, 2, 3, 16):
+        X = torch.rand(n, K, generator=gen, dtype=torch.float64)
+        want = torch.zeros(n, K, dtype=torch.float64).index_add_(0, ei[0], ev * X[ei[1]])
+        check_rows(plan.spmm(d(X)), want)
+    # ---- residual / Jacobi / Chebyshev through the modules (K = 1)
+    b = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    x = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    diag = torch.rand(n, 1, generator=gen, dtype=torch.float64) + 8.0
+    r_w = rp.residual_forward(torch.cat([b, x], 1), ei, ev)
+    check_rows(gla.GNNResidual.GNNResidual()(d(torch.cat([b, x], 1)), ei_d, ev_d), r_w)
+    ea2 = torch.cat([ev, torch.zeros_like(ev)], 1)
+    g = torch.tensor([0.7], dtype=torch.float64)
+    j_w = rp.jacobi_forward(1, torch.cat([diag, b, x], 1), ei, ea2, g)
+    check_rows(gla.JacobiGNN.JacobiGNN()(1, d(torch.cat([diag, b, x], 1)), ei_d, d(ea2), d(g)), j_w)
+    gch = torch.tensor([0.3, 1.1], dtype=torch.float64)
+    c_w, _, _ = rp.cheby_forward(2, torch.cat([b, x], 1), ei, ev, gch)
+    c_g, _, _ = gla.ChebyGNN.ChebyRelaxGNN(2, return_edge_attr=False)(d(torch.cat([b, x], 1)), ei_d, ev_d, gch)
+    close(c_g, c_w, rtol=1e-9)                         # degree 2 mixes hub rows into their neighbours' second SpMV
+    # ---- fused power-method step (reducing epilogue) against SpMM + column dot
+    for K in (1, 2):
+        X = torch.rand(n, K, generator=gen, dtype=torch.float64)
+        Y, ss, _ = plan.power_step(d(X))
+        want = torch.zeros(n, K, dtype=torch.float64).index_add_(0, ei[0], ev * X[ei[1]])
+        check_rows(Y, want)
+        close(ss, (want * want).sum(0), rtol=1e-11)
+    # ---- aggregation primitive on its own
+    src = torch.rand(nnz, 2, generator=gen, dtype=torch.float64) - 0.5
+    for red, fn in (("sum", None), ("max", "amax"), ("min", "amin"), ("mean", None)):
+        got = plan.segment_reduce(d(src), red).cpu()
+        if fn is None:
+            want = torch.zeros(n, 2, dtype=torch.float64).index_add_(0, ei[0], src)
+            if red == "mean":
+                want = want / torch.bincount(ei[0], minlength=n).clamp(min=1).reshape(-1, 1)
+            check_rows(got, want)
+        else:
+            want = torch.zeros(n, 2, dtype=torch.float64).scatter_reduce(
+                0, ei[0].reshape(-1, 1).expand(-1, 2), src, fn, include_self=False)
+            eq(got, want)                              # max / min are order-free: exact on hub rows too
+    # ---- edge attributes
+    X = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    eq(plan.edge_products(d(X)), ev * X[ei[1]])
+    # ---- strength of connection, direct interpolation, SA strength (off-diagonal plan = this plan)
+    z = torch.zeros((n, 1), dtype=torch.float64)
+    S_w, v_w = rp.soc_classic_forward(0.25, z, ei, ev, return_v=True)
+    S_g, v_g = gla.SOCClassicGNN.SOCClassicGNN(0.25)(d(z), ei_d, ev_d, return_v=True)
+    eq(v_g, v_w)                                       # a max: exact everywhere
+    eq(S_g, S_w)
+    split = (torch.rand(n, 1, generator=gen) < 0.5).to(torch.float64)
+    ea = torch.hstack([ev, (S_w.reshape(-1, 1) > 0).to(torch.float64)])
+    w_w = rp.direct_interp_forward(torch.hstack([diag, split]), ei, ea)
+    w_g = gla.DirectInterpGNN.DirectInterpGNN()(d(torch.hstack([diag, split])), ei_d, d(ea)).cpu()
+    eq(w_g[e_short], w_w[e_short])
+    np.testing.assert_allclose(w_g[~e_short].numpy(), w_w[~e_short].numpy(), rtol=1e-11, atol=0, equal_nan=True)
+    eq(plan.soc_sa(d(diag.reshape(-1).contiguous())), rp.socsa_layer(diag, ei, ev)[1][:, 1])
+    # ---- cost: SpMV with the three hubs within 10 % of the same graph without them
+    ei0 = d(_hub_graph(n, [], 0, torch.Generator().manual_seed(77)))
+    ev0 = torch.rand(ei0.shape[1], 1, dtype=torch.float64, device=DEV)
+    plan0 = gla.plan_for(ei0, n, edge_attr=ev0)
+    assert plan0.info.long_rows == 0
+    X = torch.rand(n, 1, dtype=torch.float64, device=DEV)
+
+    def time_spmv(pl):
+        Y = torch.empty(n, 1, dtype=torch.float64, device=DEV)
+        for _ in range(5):
+            pl.spmm(X, out=Y)
+        ts = []
+        for _ in range(9):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                pl.spmm(X, out=Y)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 20)
+        return sorted(ts)[len(ts) // 2]
+
+    t_hub, t_plain = time_spmv(plan), time_spmv(plan0)
+    print(f"SpMV 1M rows: with 3 hub rows {t_hub * 1e3:.1f} us, without {t_plain * 1e3:.1f} us")
+    assert t_hub <= 1.10 * t_plain + 0.002, (t_hub, t_plain)
 
 
 def test_soc_di_vs_oracle_fem_like():
