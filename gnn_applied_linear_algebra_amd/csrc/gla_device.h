@@ -207,20 +207,38 @@ __global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage1(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage2(const T* __restrict__ partial, int nblocks, int K,
                                                             T* __restrict__ out) {
-  __shared__ T red[GLA_BLOCK];
-  const int tid = threadIdx.x;
-  for (int k = 0; k < K; ++k) {
-    T acc = T(0);
-    for (int b = tid; b < nblocks; b += GLA_BLOCK) acc = acc + partial[(int64_t)b * K + k];
-    red[tid] = acc;
-    __syncthreads();
-    for (int st = GLA_BLOCK / 2; st > 0; st >>= 1) {
-      if (tid < st) red[tid] = red[tid] + red[tid + st];
-      __syncthreads();
-    }
-    if (tid == 0) out[k] = red[0];
+  __shared__ T red[GLA_BLOCK];                   // one workgroup per column k = blockIdx.x, fixed-order tree
+  const int tid = threadIdx.x, k = blockIdx.x;
+  T acc = T(0);
+  for (int b = tid; b < nblocks; b += GLA_BLOCK) acc = acc + partial[(int64_t)b * K + k];
+  red[tid] = acc;
+  __syncthreads();
+  for (int st = GLA_BLOCK / 2; st > 0; st >>= 1) {
+    if (tid < st) red[tid] = red[tid] + red[tid + st];
     __syncthreads();
   }
+  if (tid == 0) out[k] = red[0];
+}
+
+// Sum of per-lane vectors over the lanes of a workgroup that share tid % KV (KV a power of two <= 32): xor-shuffles
+// inside each wave, then the four wave results through LDS in wave order.  Fixed order; the result is valid in lanes
+// tid < KV.  `sh` holds 4 * KV vectors.
+template <int KV, typename V>
+__device__ __forceinline__ V block_lane_group_sum(V v, V* sh) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int off = 32; off >= KV; off >>= 1) {
+    V o;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(V) / sizeof(v[0])); ++i) o[i] = __shfl_xor(v[i], off, 64);
+    v = v + o;
+  }
+  __syncthreads();
+  if ((tid & 63) < KV) sh[(tid >> 6) * KV + (tid & 63)] = v;
+  __syncthreads();
+  V tot = V();
+  if (tid < KV) tot = ((sh[tid] + sh[KV + tid]) + sh[2 * KV + tid]) + sh[3 * KV + tid];
+  return tot;
 }
 
 inline unsigned grid_for(int64_t work, int per_block = GLA_BLOCK, int cap = 256 * 8) {
@@ -261,7 +279,7 @@ int launch_col_dot(int64_t n, int K, const T* x, int64_t ldx, const T* y, int64_
   }
 #undef GLA_DOT_CASE
   GLA_LAUNCH_CHECK();
-  hipLaunchKernelGGL((col_dot_stage2<T>), dim3(1), dim3(GLA_BLOCK), 0, st, pw, (int)nb, K, out);
+  hipLaunchKernelGGL((col_dot_stage2<T>), dim3(K), dim3(GLA_BLOCK), 0, st, pw, (int)nb, K, out);
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }

@@ -54,6 +54,10 @@ struct gla_csr {
   int32_t dia_const = 0;         // 1 (option "compress"): every diagonal holds ONE value -> no value stream either
   double dia_cval[16] = {0};     // that value per diagonal
   int64_t dia_row_lo = 0, dia_row_hi = 0;   // rows [lo, hi) fit the diagonal set (halo rows of a row block do not)
+  // 2-D reading of the diagonal set for the blocked K > 1 kernel: off[d] = dia_a[d] * dia_S + dia_b[d] with a grid-line
+  // stride S and small |a| <= dia_A, |b| <= dia_B (5-point: S = N, a in {-1,0,1}, b in {-1,0,1}); dia_S = 0: none
+  int32_t dia_S = 0, dia_A = 0, dia_B = 0;
+  int8_t dia_a[16] = {0}, dia_b[16] = {0};
   int64_t int_row_lo = -1, int_row_hi = -1; // rows of the interior tiles when they form one contiguous run
 };
 

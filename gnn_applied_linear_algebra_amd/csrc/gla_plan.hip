@@ -456,6 +456,35 @@ int build_dia(gla_csr* p, hipStream_t st) {
     return GLA_OK;
   }
   p->dia_state = 1;
+  // 2-D reading of the offsets (blocked multi-rhs kernel): the line stride S is the far offset that splits every
+  // diagonal into a * S + b with the smallest max |b| (|a| <= 2, |b| <= 3)
+  p->dia_S = 0;
+  {
+    int best_b = 1 << 30;
+    for (int c = 0; c < D; ++c) {
+      const int64_t S = p->dia_off[c];
+      if (S <= 8) continue;
+      int maxa = 0, maxb = 0, ok = 1;
+      int8_t ta[16], tb[16];
+      for (int i = 0; i < D && ok; ++i) {
+        const int64_t off = p->dia_off[i];
+        int64_t a = (off >= 0 ? off + S / 2 : off - S / 2) / S;          // nearest multiple
+        const int64_t b = off - a * S;
+        if (a < -2 || a > 2 || b < -3 || b > 3) ok = 0;
+        ta[i] = (int8_t)a;
+        tb[i] = (int8_t)b;
+        maxa = std::max(maxa, (int)(a < 0 ? -a : a));
+        maxb = std::max(maxb, (int)(b < 0 ? -b : b));
+      }
+      if (ok && maxb < best_b) {
+        best_b = maxb;
+        p->dia_S = (int32_t)S;
+        p->dia_A = maxa;
+        p->dia_B = maxb;
+        for (int i = 0; i < D; ++i) { p->dia_a[i] = ta[i]; p->dia_b[i] = tb[i]; }
+      }
+    }
+  }
   return GLA_OK;
 #undef DK
 }

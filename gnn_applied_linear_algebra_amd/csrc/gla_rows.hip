@@ -645,21 +645,323 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
       }
     }
   }
-  if constexpr (Epi::NRED > 0) {       // lanes with the same rhs pair are LPR apart: fixed-order tree over the rows
-    __syncthreads();
-    T2* sred = reinterpret_cast<T2*>(smem_raw);
-    sred[tid] = red;
-    __syncthreads();
-    for (int st = GLA_BLOCK / 2; st >= LPR; st >>= 1) {
-      if (tid < st) sred[tid] = sred[tid] + sred[tid + st];
-      __syncthreads();
-    }
+  if constexpr (Epi::NRED > 0) {       // lanes with the same rhs pair are LPR apart: fixed-order sum over the rows
+    const T2 tot = block_lane_group_sum<LPR>(red, reinterpret_cast<T2*>(smem_raw));
     if (tid < LPR) {
 #pragma unroll
       for (int i = 0; i < VW; ++i)
-        if (k0 + i < K) epi.partials_ptr()[(int64_t)t * K + k0 + i] = sred[tid][i];
+        if (k0 + i < K) epi.partials_ptr()[(int64_t)t * K + k0 + i] = tot[i];
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K > 1, stencil matrices (option "dia"): 2-D blocked kernel with an LDS window of X.
+// The diagonal offsets are read as a * S + b (S = grid-line stride, plan->dia_S): a workgroup owns a block of BJ grid
+// lines x BI points (BI = 256 / KV, KV = 16-byte rhs vectors per row), stages the (BJ + 2A) x (BI + 2B) rows of X it
+// touches in LDS ONCE -- every X element is fetched once per workgroup instead of once per nonzero through L1 -- and
+// forms all products from LDS (conflict-free ds_read_b128: the lanes of a wave read 1 KiB of consecutive bytes).
+// Lanes = (point, rhs vector) as in the CSR tile kernel; a row's products are added in ascending diagonal order =
+// edge order, product and sum rounded separately: bit-identical to the CSR kernels.  Workgroups are numbered so that
+// an XCD works through chunks of 8 x 8 blocks: the halo lines of a block are L2 hits (its neighbours' lines).
+// ------------------------------------------------------------------------------------------------
+struct Dia2D {
+  const void* val;            // [D][n_rows]
+  const uint16_t* mask;       // [n_rows]
+  int32_t D, S, A, B;
+  int32_t da[GLA_DIA_MAX], db[GLA_DIA_MAX];
+  int64_t n_rows, n_cols;
+  int32_t nbi, nbj;           // blocks per grid line, block rows
+  int32_t nci, nchunks;       // chunks (8 x 8 blocks) per row of chunks, chunks in all
+  uint32_t w_magic;           // ceil(2^32 / W): x / W == umulhi(x, w_magic) for x < 2^16
+  int64_t part_off;           // reducing epilogues: block (jb, ib) writes partials[(part_off + jb * nbi + ib) * K + k]
+};
+
+template <typename T, class Epi, int KV, int DMAX, int BJ>
+__global__ __launch_bounds__(GLA_BLOCK) void spmm_dia2d_kernel(Dia2D dv, const T* __restrict__ X, int64_t ldx, Epi epi) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int K = KV * VW;
+  constexpr int BI = GLA_BLOCK / KV;
+  constexpr int NPT = BJ * BI;                    // grid points of a block
+  typedef T TV __attribute__((ext_vector_type(VW)));
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int W = BI + 2 * dv.B, H = BJ + 2 * dv.A;
+  TV* sx = reinterpret_cast<TV*>(smem_raw);                                  // [H * W * KV]
+  T* sv = reinterpret_cast<T*>(sx + H * W * KV);                             // [DMAX][NPT]
+  int* sm = reinterpret_cast<int*>(sv + DMAX * NPT);                         // [NPT] diagonal mask | live bit 16
+  // workgroup -> block: XCD e (= blockIdx % 8) takes chunk e of every round of 8 chunks; a chunk is 8 x 8 blocks
+  const int bid = blockIdx.x, jx = bid / GLA_XCDS;
+  const int chunk = (jx / 64) * GLA_XCDS + bid % GLA_XCDS, within = jx % 64;
+  if (chunk >= dv.nchunks) return;
+  const int jb = (chunk / dv.nci) * 8 + within / 8, ib = (chunk % dv.nci) * 8 + within % 8;
+  if (jb >= dv.nbj || ib >= dv.nbi) return;
+  const int tid = threadIdx.x, q = tid % KV;
+  const int64_t J0 = (int64_t)jb * BJ, I0 = (int64_t)ib * BI;
+  const T* __restrict__ val = static_cast<const T*>(dv.val);
+  // ---- stage the X window (branch-free batches of 4 16-byte loads per lane) and the block's values / masks
+  {
+    const int total = H * W * KV;
+    const auto gxs = epi.template gx_load<TV>(q * VW);
+    for (int base = 0; base < total; base += 4 * GLA_BLOCK) {
+      TV v_[4];
+      int f_[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int f = base + u * GLA_BLOCK + tid;              // f % KV == q for every slot of this lane
+        f = f < total ? f : total - KV + q;              // surplus lanes redo the last slot of their rhs vector
+        f_[u] = f;
+        const int xr = f / KV;
+        const int hh = (int)__umulhi((unsigned)xr, dv.w_magic), ww = xr - hh * W;
+        int64_t flat = (J0 + hh - dv.A) * dv.S + (I0 + ww - dv.B);
+        flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
+        v_[u] = ldv<TV>(X + flat * ldx + q * VW);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sx[f_[u]] = epi.gx(v_[u], gxs);
+    }
+    for (int p = tid; p < NPT; p += GLA_BLOCK) {
+      const int jj = p / BI, ii = p % BI;
+      const int64_t r = (J0 + jj) * dv.S + I0 + ii;
+      const bool live = I0 + ii < dv.S && r < dv.n_rows;
+      const int64_t rc = live ? r : 0;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) sv[d * NPT + p] = val[(int64_t)min(d, dv.D - 1) * dv.n_rows + rc];
+      sm[p] = live ? ((int)dv.mask[rc] | 0x10000) : 0;
+    }
+  }
+  int dl[DMAX];                                    // LDS offset of diagonal d relative to the row's own X slot
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) { const int dd = min(d, dv.D - 1); dl[d] = (dv.da[dd] * W + dv.db[dd]) * KV; }
+  __syncthreads();
+  // ---- products and in-order row sums from LDS, fused vertex update; BJ passes of BI rows, 4 passes in flight
+  const int ii = tid / KV;
+  TV red = TV(T(0));
+  constexpr int G = DMAX > 5 ? 2 : (BJ < 4 ? BJ : 4);      // 9+ diagonals: two passes in flight keep the kernel under 128 VGPRs
+#pragma unroll 1
+  for (int g = 0; g < BJ; g += G) {
+    typename Epi::template PreV<TV> pre[G];
+    int m[G];
+    int64_t rr[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int p = (g + u) * BI + ii;
+      m[u] = sm[p];
+      rr[u] = (J0 + g + u) * dv.S + I0 + ii;
+      pre[u] = epi.template loadv<TV>((m[u] & 0x10000) ? rr[u] : (int64_t)0, q * VW);
+    }
+    TV acc[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int p = (g + u) * BI + ii;
+      const int xs = ((g + u + dv.A) * W + ii + dv.B) * KV + q;
+      TV xv[DMAX];
+      T v[DMAX];
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) { xv[d] = sx[xs + dl[d]]; v[d] = sv[d * NPT + p]; }
+      TV a = TV(T(0));
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) {
+        const TV nxt = a + v[d] * xv[d];
+        a = ((m[u] >> d) & 1) ? nxt : a;
+      }
+      acc[u] = a;
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (m[u] & 0x10000) {
+        epi.template applyv<TV>(rr[u], q * VW, acc[u], pre[u]);
+        if constexpr (Epi::NRED > 0) red = red + epi.template redv<TV>(acc[u], pre[u]);
+      }
+    }
+  }
+  if constexpr (Epi::NRED > 0) {       // lanes with the same rhs vector are KV apart: fixed-order sum over the rows
+    const TV tot = block_lane_group_sum<KV>(red, reinterpret_cast<TV*>(smem_raw));
+    if (tid < KV) {
+      const int64_t blk = dv.part_off + (int64_t)jb * dv.nbi + ib;
+#pragma unroll
+      for (int i = 0; i < VW; ++i) epi.partials_ptr()[blk * K + q * VW + i] = tot[i];
+    }
+  }
+}
+
+// EXPERIMENT (gla_set_option("spmm_variant", 12), never the default): the same 2-D blocked kernel with the products
+// formed on the matrix cores -- north_star's "MFMA tile for the dense multi-RHS SpMM".  fp64, K = 16, 5-point stencils
+// only.  A wave owns tiles of 16 consecutive grid points x 16 right-hand sides; the 16 x 16 diagonal blocks of the lines
+// above / below (4 slices each) and the 16 x 18 band of the own line (5 slices) are multiplied as dense 16 x 4 slices by
+// v_mfma_f64_16x16x4_f64: 13 MFMAs per tile, 80 of whose 13 * 64 = 832 coefficients are non-zero (9.6 %).  The MFMA's
+// fused chain rounds differently from the reference's separate multiply and add (bit-identical only when the products
+// are exact, as with the Laplacian's -4 / +1), and a zero coefficient times an Inf / NaN of X pollutes the row, which
+// the masked VALU path cannot.  Measured A/B (profiles/r02/ab_mfma_f64_tile.txt): 1.1 - 1.55 x SLOWER than the VALU
+// path of the same kernel -- the path is HBM-bound and the matrix pipe spends 90 % of its cycles on zeros.
+typedef double D4 __attribute__((ext_vector_type(4)));
+
+template <class Epi, int BJ>
+__global__ __launch_bounds__(GLA_BLOCK) void spmm_dia2d_mfma_kernel(Dia2D dv, const double* __restrict__ X, int64_t ldx,
+                                                                    Epi epi) {
+  typedef double T;
+  constexpr int KV = 8, VW = 2, K = 16, DMAX = 9;
+  constexpr int BI = GLA_BLOCK / KV;              // 32 points per line
+  constexpr int NPT = BJ * BI;
+  typedef T TV __attribute__((ext_vector_type(VW)));
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int W = BI + 2 * dv.B, H = BJ + 2 * dv.A;
+  TV* sx = reinterpret_cast<TV*>(smem_raw);
+  T* sv = reinterpret_cast<T*>(sx + H * W * KV);
+  int* sm = reinterpret_cast<int*>(sv + DMAX * NPT);
+  const int bid = blockIdx.x, jx = bid / GLA_XCDS;
+  const int chunk = (jx / 64) * GLA_XCDS + bid % GLA_XCDS, within = jx % 64;
+  if (chunk >= dv.nchunks) return;
+  const int jb = (chunk / dv.nci) * 8 + within / 8, ib = (chunk % dv.nci) * 8 + within % 8;
+  if (jb >= dv.nbj || ib >= dv.nbi) return;
+  const int tid = threadIdx.x, q = tid % KV;
+  const int64_t J0 = (int64_t)jb * BJ, I0 = (int64_t)ib * BI;
+  const T* __restrict__ val = static_cast<const T*>(dv.val);
+  {                                               // staging: identical to spmm_dia2d_kernel
+    const int total = H * W * KV;
+    for (int base = 0; base < total; base += 4 * GLA_BLOCK) {
+      TV v_[4];
+      int f_[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int f = base + u * GLA_BLOCK + tid;
+        f = f < total ? f : total - KV + q;
+        f_[u] = f;
+        const int xr = f / KV;
+        const int hh = (int)__umulhi((unsigned)xr, dv.w_magic), ww = xr - hh * W;
+        int64_t flat = (J0 + hh - dv.A) * dv.S + (I0 + ww - dv.B);
+        flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
+        v_[u] = ldv<TV>(X + flat * ldx + q * VW);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sx[f_[u]] = v_[u];
+    }
+    for (int p = tid; p < NPT; p += GLA_BLOCK) {
+      const int jj = p / BI, ii = p % BI;
+      const int64_t r = (J0 + jj) * dv.S + I0 + ii;
+      const bool live = I0 + ii < dv.S && r < dv.n_rows;
+      const int64_t rc = live ? r : 0;
+      for (int d = 0; d < dv.D; ++d) sv[d * NPT + p] = val[(int64_t)d * dv.n_rows + rc];
+      sm[p] = live ? ((int)dv.mask[rc] | 0x10000) : 0;
+    }
+  }
+  __syncthreads();
+  const T* sxs = reinterpret_cast<const T*>(sx);  // X window as scalars: slot * K + rhs
+  const int lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, kk = lane >> 4;        // A operand: row m, column kk of the 16 x 4 slice; B: row kk, column m
+  // 5-point structure (checked by the launcher): d = 0: a = -1; d = 1, 2, 3: a = 0, b = -1, 0, +1; d = 4: a = +1
+#pragma unroll 1
+  for (int tile = wave; tile < BJ * (BI / 16); tile += GLA_BLOCK / 64) {
+    const int jj = tile / (BI / 16), i0 = (tile % (BI / 16)) * 16;
+    const int pm = jj * BI + i0 + m;              // this lane's A row (grid point) inside the block
+    const int msk = sm[pm];
+    double vd[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) vd[d] = ((msk >> d) & 1) ? sv[d * NPT + pm] : 0.0;
+    D4 acc = {0.0, 0.0, 0.0, 0.0};
+    const T* xl[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) xl[g] = sxs + (int64_t)((jj + dv.A + g - 1) * W + dv.B + i0) * K + m;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {              // line above: 16 x 16 diagonal block, X points i0 + 4 s + kk
+      const int xi = 4 * s4 + kk;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xi == m ? vd[0] : 0.0, xl[0][xi * K], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 5; ++s4) {              // own line: 16 x 18 band, X points i0 - 1 + 4 s + kk
+      const int xi = 4 * s4 + kk - 1;
+      const double av = xi - m == -1 ? vd[1] : (xi - m == 0 ? vd[2] : (xi - m == 1 ? vd[3] : 0.0));
+      const int xc = min(xi, BI - i0 + dv.B - 1);              // the two padding rows of the last slice stay in the window
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xl[1][xc * K], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {              // line below
+      const int xi = 4 * s4 + kk;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xi == m ? vd[4] : 0.0, xl[2][xi * K], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * i + kk;                 // D layout of v_mfma_f64_16x16x4_f64: register i, lane l -> row 4 i + l / 16, column l % 16
+      const int pi = jj * BI + i0 + row;
+      if (sm[pi] & 0x10000) {
+        const int64_t r = (J0 + jj) * dv.S + I0 + i0 + row;
+        epi((int64_t)r, m, acc[i]);
+      }
+    }
+  }
+}
+
+// > 0: the blocked stencil kernel takes this launch, with that many 16-byte rhs vectors per row
+template <typename T, class Epi>
+int dia2d_kv(const gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int which) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  if (!(K > 1 && which == 0 && A->dia_state == 1 && A->dia_val && A->dia_S > 0 && g_tuning.dia &&
+        g_tuning.spmm_variant != 9 && A->dia_row_lo == 0 && A->dia_row_hi == A->n_rows && A->n_rows == A->n_cols))
+    return 0;
+  const int kv = K / VW;
+  if (K % VW != 0 || !(kv == 1 || kv == 2 || kv == 4 || kv == 8) || ldx % VW != 0 || !al16(X) || !epi.vec_ok(VW)) return 0;
+  const int bj = g_tuning.spmm_variant == 10 ? 8 : 4, bi = GLA_BLOCK / kv;
+  const int dmax = A->dia_D <= 5 ? 5 : (A->dia_D <= 9 ? 9 : GLA_DIA_MAX);
+  const size_t lds = (size_t)(bj + 2 * A->dia_A) * (bi + 2 * A->dia_B) * kv * 16 + (size_t)dmax * bj * bi * sizeof(T) +
+                     (size_t)bj * bi * sizeof(int);
+  return lds <= 64 * 1024 ? kv : 0;
+}
+
+inline int64_t dia2d_nblocks(const gla_csr* A, int kv) {
+  const int bj = g_tuning.spmm_variant == 10 ? 8 : 4, bi = GLA_BLOCK / kv;
+  const int64_t lines = (A->n_rows + A->dia_S - 1) / A->dia_S;
+  return ((lines + bj - 1) / bj) * ((A->dia_S + bi - 1) / bi);
+}
+
+template <typename T, class Epi, int KV, int BJ>
+int launch_dia2d(gla_csr* A, const T* X, int64_t ldx, const Epi& epi, hipStream_t st) {
+  constexpr int BI = GLA_BLOCK / KV;
+  Dia2D dv;
+  dv.val = A->dia_val;
+  dv.mask = A->dia_mask;
+  dv.D = A->dia_D; dv.S = A->dia_S; dv.A = A->dia_A; dv.B = A->dia_B;
+  for (int i = 0; i < GLA_DIA_MAX; ++i) { dv.da[i] = i < A->dia_D ? A->dia_a[i] : 0; dv.db[i] = i < A->dia_D ? A->dia_b[i] : 0; }
+  dv.n_rows = A->n_rows; dv.n_cols = A->n_cols;
+  const int64_t lines = (A->n_rows + A->dia_S - 1) / A->dia_S;
+  dv.nbi = (int)((A->dia_S + BI - 1) / BI);
+  dv.nbj = (int)((lines + BJ - 1) / BJ);
+  dv.nci = (dv.nbi + 7) / 8;
+  const int ncj = (dv.nbj + 7) / 8;
+  dv.nchunks = dv.nci * ncj;
+  const int W = BI + 2 * dv.B, H = BJ + 2 * dv.A;
+  dv.w_magic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)W + 1);
+  dv.part_off = 0;                        // the only kernel of its launch: partial rows [0, blocks)
+  const int dmax = A->dia_D <= 5 ? 5 : (A->dia_D <= 9 ? 9 : GLA_DIA_MAX);
+  const size_t lds = (size_t)H * W * KV * 16 + (size_t)dmax * BJ * BI * sizeof(T) + (size_t)BJ * BI * sizeof(int);
+  const unsigned grid = (unsigned)(((dv.nchunks + GLA_XCDS - 1) / GLA_XCDS) * GLA_XCDS * 64);
+  if constexpr (sizeof(T) == 8 && KV == 8 && Epi::NRED == 0) {
+    const bool five_point = A->dia_D == 5 && A->dia_A == 1 && A->dia_B == 1 && A->dia_a[0] == -1 && A->dia_b[0] == 0 &&
+                            A->dia_a[1] == 0 && A->dia_b[1] == -1 && A->dia_a[2] == 0 && A->dia_b[2] == 0 &&
+                            A->dia_a[3] == 0 && A->dia_b[3] == 1 && A->dia_a[4] == 1 && A->dia_b[4] == 0;
+    if (g_tuning.spmm_variant == 12 && five_point) {        // MFMA tile experiment (see the kernel)
+      const size_t lds_m = (size_t)H * W * KV * 16 + (size_t)9 * BJ * BI * sizeof(T) + (size_t)BJ * BI * sizeof(int);
+      hipLaunchKernelGGL((spmm_dia2d_mfma_kernel<Epi, BJ>), dim3(grid), dim3(GLA_BLOCK), lds_m, st, dv,
+                         (const double*)X, ldx, epi);
+      GLA_LAUNCH_CHECK();
+      return GLA_OK;
+    }
+  }
+  if (dmax == 5)
+    hipLaunchKernelGGL((spmm_dia2d_kernel<T, Epi, KV, 5, BJ>), dim3(grid), dim3(GLA_BLOCK), lds, st, dv, X, ldx, epi);
+  else if (dmax == 9)
+    hipLaunchKernelGGL((spmm_dia2d_kernel<T, Epi, KV, 9, BJ>), dim3(grid), dim3(GLA_BLOCK), lds, st, dv, X, ldx, epi);
+  else
+    hipLaunchKernelGGL((spmm_dia2d_kernel<T, Epi, KV, GLA_DIA_MAX, BJ>), dim3(grid), dim3(GLA_BLOCK), lds, st, dv, X,
+                       ldx, epi);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+// number of 2-D blocks the blocked stencil kernel may use (upper bound over its block shapes): partials of reducing
+// epilogues need one slot per block
+inline int64_t dia2d_blocks_bound(const gla_csr* A) {
+  if (A->dia_state != 1 || A->dia_S <= 0) return 0;
+  const int64_t lines = (A->n_rows + A->dia_S - 1) / A->dia_S;
+  return ((lines + 3) / 4 + 1) * ((int64_t)(A->dia_S + 31) / 32 + 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -716,6 +1018,16 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
         hipLaunchKernelGGL((spmv_dia_kernel<T, Epi, GLA_DIA_MAX>), dgrid, dblock, 0, st, dv, X, bm, epi);
       GLA_LAUNCH_CHECK();
       return GLA_OK;
+    }
+  }
+  if (const int kv = dia2d_kv<T>(A, K, X, ldx, epi, which)) {
+    // stencil plans, K = 1, 2, 4 or 8 16-byte vectors of right-hand sides: 2-D blocks with an LDS window of X
+    const bool bj8 = g_tuning.spmm_variant == 10;        // A/B: 8-line blocks (larger LDS window, less halo, fewer waves)
+    switch (kv) {
+      case 1: return bj8 ? launch_dia2d<T, Epi, 1, 8>(A, X, ldx, epi, st) : launch_dia2d<T, Epi, 1, 4>(A, X, ldx, epi, st);
+      case 2: return bj8 ? launch_dia2d<T, Epi, 2, 8>(A, X, ldx, epi, st) : launch_dia2d<T, Epi, 2, 4>(A, X, ldx, epi, st);
+      case 4: return bj8 ? launch_dia2d<T, Epi, 4, 8>(A, X, ldx, epi, st) : launch_dia2d<T, Epi, 4, 4>(A, X, ldx, epi, st);
+      default: return bj8 ? launch_dia2d<T, Epi, 8, 8>(A, X, ldx, epi, st) : launch_dia2d<T, Epi, 8, 4>(A, X, ldx, epi, st);
     }
   }
   TileMap tm;
@@ -927,7 +1239,8 @@ int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, vo
 }
 
 static inline int64_t power_partials(const gla_csr* A) {
-  return (int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) + (A->n_rows + GLA_BLOCK - 1) / GLA_BLOCK;
+  const int64_t row_blocks = (A->n_rows + GLA_BLOCK - 1) / GLA_BLOCK, b2 = dia2d_blocks_bound(A);
+  return (int64_t)(A->n_tiles > 0 ? A->n_tiles : 1) + (row_blocks > b2 ? row_blocks : b2);
 }
 
 int64_t gla_power_work_bytes(gla_csr_t A, int K, int dtype) {
@@ -946,15 +1259,19 @@ int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, co
     return GLA_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = dtype == GLA_F64 ? 8 : 4;
-  if (which != 2)          // boundary launches add to the partials the interior launch already zeroed
-    GLA_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)power_partials(A) * K * esz, st));
   GLA_DISPATCH(dtype, {
     EpiPower<T> epi{(T*)Y, ldy, (const T*)nrm_in, (const T*)rnrm_in, (T*)work};
+    // partial rows in use: the blocked stencil kernel writes one per block (every block, no zero-fill needed);
+    // otherwise CSR tiles [0, n_tiles) and the diagonal kernel's row blocks behind them
+    const int kv = dia2d_kv<T>(A, K, (const T*)X, ldx, epi, which);
+    const int64_t rows_used = kv ? dia2d_nblocks(A, kv) : power_partials(A);
+    if (which != 2 && !kv)   // boundary launches add to the partials the interior launch already zeroed
+      GLA_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)rows_used * K * esz, st));
     rc = launch_rows<T>(A, K, (const T*)X, ldx, epi, which, st);
     if (rc) return rc;
-    if (sumsq_out && which != 1) {     // column sums of the tile partials once every tile has contributed
+    if (sumsq_out && which != 1) {     // column sums of the partials once every tile has contributed
       T* tile_part = (T*)work;
-      return launch_col_dot<T>(power_partials(A), K, tile_part, K, (const T*)nullptr, K, (T*)sumsq_out,
+      return launch_col_dot<T>(rows_used, K, tile_part, K, (const T*)nullptr, K, (T*)sumsq_out,
                                tile_part + power_partials(A) * K, st);
     }
     return GLA_OK;

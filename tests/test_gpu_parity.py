@@ -868,7 +868,8 @@ def test_dia_layout_bit_identical():
     flip = torch.argsort(ei[0] * 1000 - ei[1], stable=True)
     cases.append(("descending columns", ei[:, flip], ev[flip], 900, 0))
     def run_multi(ei, ev, n, dtype, K):
-        """the K > 1 ops (they stay on the CSR kernels whatever the option says)"""
+        """the K > 1 ops: with the diagonal layout and K = 1, 2, 4 or 8 16-byte vectors of right-hand sides they run on
+        the 2-D blocked LDS-window kernel (spmm_dia2d_kernel), otherwise on the CSR row-tile kernels"""
         plan = gla.CsrPlan(d(ei), n)
         plan.set_values(d(ev.to(dtype)))
         g2 = torch.Generator().manual_seed(3 + K)
@@ -879,7 +880,12 @@ def test_dia_layout_bit_identical():
         r, p, xo, p2 = (torch.empty_like(X) for _ in range(4))
         plan.cheby_first(B, X, r, p, xo, -0.25)
         plan.cheby_next(p, p2, r, xo, -0.25, -0.26, 0.1)
-        return outs + [r, p2, xo]
+        outs = outs + [r, p2, xo]
+        if K % 2 == 0:                                     # fused power step (reducing epilogue): Y exact, sums to rounding
+            nrm = torch.linspace(1.3, 2.1, K, dtype=torch.float64).to(dtype).to(DEV)
+            y, ss, _ = plan.power_step(X, nrm=nrm)
+            outs = outs + [y, ss]
+        return outs
 
     for name, ei, ev, n, want_D in cases:
         for dtype in (torch.float64, torch.float32):
@@ -887,7 +893,7 @@ def test_dia_layout_bit_identical():
                 check(lib().gla_set_option(b"dia", 0))
                 plan_csr, ref_out = run_all(ei, ev, n, dtype)
                 assert plan_csr.info.dia == 0
-                ref_multi = {K: run_multi(ei, ev, n, dtype, K) for K in (2, 6, 16, 20)}
+                ref_multi = {K: run_multi(ei, ev, n, dtype, K) for K in (2, 4, 6, 8, 16, 20, 32)}
             finally:
                 check(lib().gla_set_option(b"dia", 1))
             plan, out = run_all(ei, ev, n, dtype)
@@ -897,8 +903,24 @@ def test_dia_layout_bit_identical():
             # the fused power step's sum of squares is grouped by 256-row blocks here and by row tiles there
             close(out[-1], ref_out[-1], rtol=1e-12 if dtype == torch.float64 else 1e-5)
             for K, ref in ref_multi.items():
-                for a, b_ in zip(run_multi(ei, ev, n, dtype, K), ref):
+                got = run_multi(ei, ev, n, dtype, K)
+                for a, b_ in zip(got[:6], ref[:6]):
                     eq(a, b_)
+                if len(got) > 6:
+                    eq(got[6], ref[6])
+                    close(got[7], ref[7], rtol=1e-12 if dtype == torch.float64 else 1e-5)
+            if want_D and dtype == torch.float64:          # the kernel's block-shape variant and the MFMA experiment
+                for variant, exact in ((10, True), (12, False)):
+                    try:
+                        check(lib().gla_set_option(b"spmm_variant", variant))
+                        got = run_multi(ei, ev, n, dtype, 16)
+                    finally:
+                        check(lib().gla_set_option(b"spmm_variant", 0))
+                    for a, b_ in zip(got[:7], ref_multi[16][:7]):
+                        if exact:
+                            eq(a, b_)
+                        else:
+                            np.testing.assert_allclose(a.cpu().numpy(), b_.cpu().numpy(), rtol=1e-12, atol=1e-13)
 
 
 def test_col16_columns_bit_identical():
