@@ -403,16 +403,19 @@ def vcycle_interp_P(A, S_flags, splitting, diag_vals):
     va = torch.hstack([diag_vals, splitting.reshape(-1, 1)])
     w = direct_interp_forward(va, ei, ea)
     n = A.shape[0]
-    W = torch.eye(n) + torch.sparse_coo_tensor(ei, w, (n, n), dtype=torch.float)
+    W = torch.eye(n, dtype=A.dtype) + torch.sparse_coo_tensor(ei, w, (n, n), dtype=A.dtype)   # script: torch.float
     W = W.to_dense()
     return W[:, splitting.flatten() > 0].to_sparse()
 
 
 def vcycle(A, b, x, splitting, n_pre=3, n_post=3, cheb_deg=4, theta=0.25, w=0.7):
-    """runVCycle(use_jacobi=True), VCycle.py:175-237, fp32 as in the script (:259), N-agnostic
-    only through diag_vals = -4 (VCycle.py:117,165 hard-code it)."""
+    """runVCycle(use_jacobi=True), VCycle.py:175-237.  The script is fp32 (`dtype=torch.float`, :259); here every
+    such dtype follows A, and the scalar tensors (`torch.tensor(w)`, `torch.tensor([c, d])`) follow torch's default
+    dtype exactly as in the script -- so an fp32 A under the fp32 default reproduces the script, and an fp64 A under
+    torch.set_default_dtype(float64) reproduces the reference's functions driven in double precision
+    (oracle/gen_golden_vcycle64.py).  N-agnostic only through diag_vals = -4 (VCycle.py:117,165 hard-code it)."""
     n = A.shape[0]
-    diag = -4 * torch.ones((n, 1), dtype=torch.float)
+    diag = -4 * torch.ones((n, 1), dtype=A.dtype)
 
     def run_jacobi(k, x_):                                                     # :156-173
         ei, ea = coo_to_gnn_input(A)
@@ -430,7 +433,7 @@ def vcycle(A, b, x, splitting, n_pre=3, n_post=3, cheb_deg=4, theta=0.25, w=0.7)
 
     x = run_jacobi(n_pre, x)
     ei, ea = remove_diag_entries(*coo_to_gnn_input(A))                         # runSOC :72-92
-    S = soc_classic_forward(theta, torch.zeros((n, 1), dtype=torch.float), ei, ea).reshape(-1, 1) > 0
+    S = soc_classic_forward(theta, torch.zeros((n, 1), dtype=A.dtype), ei, ea).reshape(-1, 1) > 0
     P = vcycle_interp_P(A, S, splitting, diag)
     Ac = P.t() @ (A @ P)                                                       # :209
     r = run_residual(x)

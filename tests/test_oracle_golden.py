@@ -3,6 +3,8 @@
 The goldens were produced by the unmodified reference modules (oracle/gen_golden.py); the port
 uses the same torch CPU primitives in the same order, so equality is exact, not approximate.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -218,3 +220,44 @@ def test_fem_bc1_structure():
     assert A[bnd][:, ~bnd].abs().sum() == 0 and A[~bnd][:, bnd].abs().sum() == 0
     ei2, ev2 = rp.heateqnfem2dfun([m + 1, m + 1], [1.0, 2.0], [2, 2])
     assert torch.equal(A[~bnd][:, ~bnd], torch.sparse_coo_tensor(ei2, ev2.flatten(), (m * m, m * m)).to_dense())
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp64 V-cycle fixtures (the reference's own runVCycle driven in double precision, oracle/gen_golden_vcycle64.py)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def vc64():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vcycle64_vectors.npz"))
+
+
+@pytest.mark.parametrize("N", [5, 8, 16])
+def test_vcycle_fp64_oracle_reproduces_reference(vc64, N):
+    """5 two-grid cycles in fp64: the oracle restatement against the unmodified reference, iterate by iterate.
+    Everything is the same arithmetic in the same order except torch's sparse products, so the bar is 1e-12."""
+    ei, ev = rp.laplacianfun_torch(N)
+    A = torch.sparse_coo_tensor(ei, ev.flatten(), dtype=torch.float64)
+    b, x = torch.from_numpy(vc64[f"N{N}_b"]), torch.from_numpy(vc64[f"N{N}_x0"])
+    split = torch.zeros(N * N, dtype=torch.int64)
+    split[0::2] = 1
+    saved = torch.get_default_dtype()
+    try:
+        torch.set_default_dtype(torch.float64)
+        for k in range(5):
+            x = rp.vcycle(A, b, x, split)
+            np.testing.assert_allclose(x.numpy(), vc64[f"N{N}_xs"][k], rtol=1e-12, atol=1e-14)
+        ei_c, ea_c = rp.coo_to_gnn_input(A)
+        res = float(torch.norm(rp.residual_forward(torch.cat([b, x], 1), ei_c, ea_c)))
+    finally:
+        torch.set_default_dtype(saved)
+    np.testing.assert_allclose(res, vc64[f"N{N}_resnorm"][4], rtol=1e-9)
+
+
+@pytest.mark.parametrize("k", [1, 2, 16])
+def test_matvec_config1_size(vc64, k):
+    """BASELINE config 1 at its stated size: MatVecGNN on the 64 x 64 Laplacian (MatVecGNN.py:146-150), bit-exact."""
+    ei, ev = rp.laplacianfun_torch(64)
+    X = torch.from_numpy(vc64["mv64_X16"][:, :k]).contiguous()
+    va, ea, _ = rp.matvec_layer(X, ei, ev)
+    np.testing.assert_array_equal(va.numpy(), vc64[f"mv64_k{k}_va"])
+    if k <= 2:
+        np.testing.assert_array_equal(ea.numpy(), vc64[f"mv64_k{k}_ea"])
