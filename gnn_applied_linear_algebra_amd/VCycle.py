@@ -38,45 +38,27 @@ def default_splitting(n, device):
 
 
 def pmis_splitting(edgeij_pair_od, strong, n, max_rounds=64):
-    """Deterministic PMIS-style C/F splitting on the device (stands in for pyamg's randomised CLJP,
-    VCycle.py:114).  `strong[e]` says that vertex row(e) strongly depends on col(e).
-    weight_i = (number of vertices that strongly depend on i, fixed 32-bit hash of i, low bits of i) compared
-    lexicographically, so ties are practically impossible and the result is reproducible; a vertex becomes C when its weight beats every undecided strong neighbour (either
-    direction), then every undecided vertex that strongly depends on a new C point becomes F.  Vertices without
-    any strong connection become C (identity interpolation; the DI formula has no finite weight for them).
-    Returns an int64 vector, 1 = C point."""
-    dev = edgeij_pair_od.device
-    strong = strong.reshape(-1).to(torch.bool)
-    row, col = edgeij_pair_od[0][strong], edgeij_pair_od[1][strong]
-    lam = torch.bincount(col, minlength=n)
-    idx = torch.arange(n, device=dev, dtype=torch.int64)
-    h = (idx + 1) & 0xFFFFFFFF                                       # murmur3 fmix32: a fixed pseudo-random order
-    h = h ^ (h >> 16)
-    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
-    h = h ^ (h >> 13)
-    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
-    h = h ^ (h >> 16)
-    w = (lam << 52) | (h << 20) | (idx & 0xFFFFF)                    # integer weight: influence count, then hash
-    state = torch.zeros(n, dtype=torch.int64, device=dev)            # 0 undecided, 1 C, -1 F
-    touched = torch.zeros(n, dtype=torch.bool, device=dev)
-    touched[row] = True
-    touched[col] = True
-    state[~touched] = 1
-    a = torch.cat([row, col])                                        # symmetrised strong graph a -> b
-    b = torch.cat([col, row])
-    for _ in range(max_rounds):
-        und = state == 0
-        if not bool(und.any()):
-            break
-        live = und[a] & und[b]
-        m = torch.full((n,), -1, dtype=torch.int64, device=dev)
-        m.scatter_reduce_(0, a[live], w[b[live]], "amax", include_self=True)
-        new_c = und & (w > m)
-        state[new_c] = 1
-        dep = (state[row] == 0) & (state[col] == 1)                  # undecided i strongly depends on a C point
-        state[row[dep]] = -1
-    state[state == 0] = 1
-    return (state == 1).to(torch.int64)
+    """Deterministic PMIS-style C/F splitting in libgla_hip (gla_pmis_split, csrc/gla_sparse.hip); stands in for pyamg's
+    randomised CLJP (VCycle.py:114).  `strong[e]` says that vertex row(e) strongly depends on
+    col(e).  weight_i = (number of vertices that strongly depend on i, fixed 32-bit hash of i, low bits of i) compared
+    lexicographically; a vertex becomes C when its weight beats every undecided strong neighbour (either direction),
+    then every undecided vertex that strongly depends on a new C point becomes F.  Vertices without any strong
+    connection become C (identity interpolation; the DI formula has no finite weight for them).
+    Returns an int64 vector on the caller's device, 1 = C point.  (Checked against a CPU restatement of the same rule kept with the test oracle.)"""
+    import ctypes
+    from ._lib import check, lib, ptr, stream_ptr
+    dev = compute_device(edgeij_pair_od)
+    ei = to_dev(edgeij_pair_od, dev)
+    flags = to_dev(strong, dev).reshape(-1).to(torch.uint8).contiguous()
+    if flags.numel() != ei.shape[1]:
+        raise ValueError(f"strong has {flags.numel()} entries, the edge list {ei.shape[1]}")
+    plan = plan_for(ei, int(n))
+    split = torch.empty(int(n), dtype=torch.int64, device=dev)
+    rounds = ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        check(lib().gla_pmis_split(plan._h, ptr(flags), ptr(split), int(max_rounds), ctypes.byref(rounds),
+                                   stream_ptr(dev)))
+    return split.to(edgeij_pair_od.device)
 
 
 class GridSplitting:

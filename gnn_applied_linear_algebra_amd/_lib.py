@@ -17,7 +17,7 @@ _DTYPES = {torch.float32: GLA_F32, torch.float64: GLA_F64}
 
 
 class GlaError(RuntimeError):
-    pass
+    code = None                      # the library's status code (include/gla.h), when the error came from a call
 
 
 class CsrInfo(ctypes.Structure):
@@ -76,6 +76,7 @@ SIGNATURES = {
     "gla_release_scratch": (_I, []),
     "gla_spgemm_count": (_I, [_P, _P, ctypes.POINTER(_I64), _P]),
     "gla_spgemm": (_I, [_P, _P, _I, _I64, _P, _P, _P, ctypes.POINTER(_I64), _P]),
+    "gla_pmis_split": (_I, [_P, _P, _P, _I, ctypes.POINTER(_I), _P]),
     "gla_comm_unique_id": (_I, [_P]),
     "gla_comm_create": (_I, [_P, _I, _I, ctypes.POINTER(_P)]),
     "gla_comm_destroy": (_I, [_P]),
@@ -110,7 +111,9 @@ def lib():
 def check(rc):
     if rc != 0:
         msg = lib().gla_error_string(rc)
-        raise GlaError(f"libgla_hip error {rc}: {msg.decode() if msg else '?'}")
+        err = GlaError(f"libgla_hip error {rc}: {msg.decode() if msg else '?'}")
+        err.code = rc
+        raise err
 
 
 def dtype_code(dt):

@@ -10,6 +10,8 @@
 //             result is deterministic and its summation order is defined (A's CSR order, then B's).
 // These are setup-time, HBM-bound integer/byte passes (no MFMA); they are not on the per-sweep hot path.
 #include <cstring>
+#include <map>
+#include <mutex>
 #include "gla_internal.h"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -61,12 +63,17 @@ template <typename T>
 __global__ __launch_bounds__(GLA_BLOCK) void coo_keys_kernel(const int64_t* __restrict__ row,
                                                              const int64_t* __restrict__ col,
                                                              const T* __restrict__ val, int64_t stride, int64_t nnz,
-                                                             int64_t n_cols, uint64_t* __restrict__ keys,
-                                                             T* __restrict__ vals) {
+                                                             int64_t n_rows, int64_t n_cols,
+                                                             uint64_t* __restrict__ keys, T* __restrict__ vals,
+                                                             int* __restrict__ range_flag) {
+  int bad = 0;
   for (int64_t e = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * GLA_BLOCK) {
-    keys[e] = (uint64_t)(row[e] * n_cols + col[e]);
+    const int64_t r = row[e], c = col[e];
+    bad |= (r < 0 || r >= n_rows || c < 0 || c >= n_cols);
+    keys[e] = (uint64_t)(r * n_cols + c);
     vals[e] = val[e * stride];
   }
+  if (bad) atomicOr(range_flag, 1);
 }
 
 __global__ __launch_bounds__(GLA_BLOCK) void head_flags_kernel(const uint64_t* __restrict__ keys, int64_t n,
@@ -97,11 +104,29 @@ __global__ __launch_bounds__(GLA_BLOCK) void compress_kernel(const uint64_t* __r
 // Setup scratch comes from one grow-only device pool (gla_release_scratch frees it): a hipMalloc / hipFree pair of
 // several GB per call costs up to seconds of page mapping, far more than the kernels.  Every setup entry point sizes
 // its scratch up front, reserves the pool once and bump-allocates from it; the entry points synchronise before they
-// return, so the pool is free again at every call boundary.  They are NOT re-entrant (one setup call at a time).
+// return, so the pool is free again at every call boundary.
 struct Pool {
   char* base = nullptr;
   size_t cap = 0, used = 0;
-} g_pool;
+};
+// one pool per HIP device (the Python layer may drive several GPUs from one process) and one lock for all setup entry
+// points: they are serialised, not re-entrant
+std::mutex g_pool_mu;
+std::map<int, Pool> g_pools;
+thread_local Pool* t_pool = nullptr;       // the calling thread's pool for the duration of an entry point
+
+struct PoolScope {
+  std::lock_guard<std::mutex> lock;
+  int rc = GLA_OK;
+  PoolScope() : lock(g_pool_mu) {
+    int dev = 0;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { rc = -(1000 + (int)e); t_pool = nullptr; return; }
+    t_pool = &g_pools[dev];
+  }
+  ~PoolScope() { t_pool = nullptr; }
+};
+#define g_pool (*t_pool)
 
 inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -217,15 +242,118 @@ int coalesce_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* ro
                   int64_t stride, int64_t* row_out, int64_t* col_out, T* val_out, int64_t* nnz_out, hipStream_t st) {
   *nnz_out = 0;
   if (nnz == 0) return GLA_OK;
-  int rc = pool_reserve(al256(nnz * 8) + al256(nnz * sizeof(T)) + compress_need<T>(nnz, key_bits(n_rows, n_cols)));
+  int rc = pool_reserve(al256(nnz * 8) + al256(nnz * sizeof(T)) + 256 + compress_need<T>(nnz, key_bits(n_rows, n_cols)));
   if (rc) return rc;
   uint64_t* keys = pool_get<uint64_t>(nnz);
   T* vals = pool_get<T>(nnz);
-  if (!keys || !vals) return GLA_ERR_INVALID_ARG;
+  int* flag = pool_get<int>(1);
+  if (!keys || !vals || !flag) return GLA_ERR_INVALID_ARG;
+  GLA_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
   hipLaunchKernelGGL((coo_keys_kernel<T>), dim3(grid_for(nnz)), dim3(GLA_BLOCK), 0, st, row, col, val, stride, nnz,
-                     n_cols, keys, vals);
+                     n_rows, n_cols, keys, vals, flag);
   GLA_LAUNCH_CHECK();
+  int h_flag = 0;                       // an out-of-range index would be packed into a wrong key: report, do not sort
+  GLA_HIP_CHECK(hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  GLA_HIP_CHECK(hipStreamSynchronize(st));
+  if (h_flag) return GLA_ERR_INDEX_RANGE;
   return sort_and_compress<T>(keys, vals, nnz, n_rows, n_cols, row_out, col_out, val_out, nnz_out, st);
+}
+
+// ---- C/F splitting (replaces pyamg.classical.split.CLJP, pytorch/VCycle.py:114) ---------------------------------
+// pyamg's CLJP draws random tie-breaking weights, so its output is not pinned by anything in the reference (SURVEY 8c:
+// parity unpinned); the splitting is an INPUT of DirectInterpGNN.  This is the library's own deterministic PMIS rule:
+//   weight_i = (number of vertices that strongly depend on i) << 52 | fmix32(i + 1) << 20 | (i & 0xFFFFF)
+//   round:  an undecided vertex whose weight beats every undecided strong neighbour (either direction) becomes C;
+//           then every undecided vertex that strongly depends on a C point becomes F
+//   vertices without any strong connection are C; whatever is undecided after max_rounds becomes C.
+// Restated on the CPU with the test oracle; tests demand equality.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+constexpr unsigned long long PMIS_BIAS = 0x8000000000000000ull;      // int64 order as unsigned order
+
+__global__ __launch_bounds__(GLA_BLOCK) void pmis_count_kernel(const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ col,
+                                                               const int32_t* __restrict__ perm,
+                                                               const uint8_t* __restrict__ strong, int64_t n,
+                                                               unsigned* __restrict__ lam, uint8_t* __restrict__ touched) {
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * GLA_BLOCK)
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p)
+      if (strong[perm ? perm[p] : p]) {
+        atomicAdd(&lam[col[p]], 1u);
+        touched[r] = 1;
+        touched[col[p]] = 1;
+      }
+}
+
+__global__ __launch_bounds__(GLA_BLOCK) void pmis_init_kernel(const unsigned* __restrict__ lam,
+                                                              const uint8_t* __restrict__ touched, int64_t n,
+                                                              unsigned long long* __restrict__ w, int8_t* __restrict__ state,
+                                                              unsigned long long* __restrict__ m) {
+  for (int64_t i = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GLA_BLOCK) {
+    const unsigned long long wi = ((unsigned long long)lam[i] << 52) | ((unsigned long long)fmix32((uint32_t)(i + 1)) << 20) |
+                                  ((unsigned long long)i & 0xFFFFFull);
+    w[i] = wi ^ PMIS_BIAS;
+    state[i] = touched[i] ? 0 : 1;
+    m[i] = ~0ull ^ PMIS_BIAS;                       // int64 -1: "no undecided neighbour"
+  }
+}
+
+// m[i] = max weight over the undecided strong neighbours of i (both directions), undecided i only
+__global__ __launch_bounds__(GLA_BLOCK) void pmis_max_kernel(const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ perm,
+                                                             const uint8_t* __restrict__ strong, int64_t n,
+                                                             const unsigned long long* __restrict__ w,
+                                                             const int8_t* __restrict__ state,
+                                                             unsigned long long* __restrict__ m) {
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * GLA_BLOCK) {
+    if (state[r] != 0) continue;
+    unsigned long long best = ~0ull ^ PMIS_BIAS;
+    const unsigned long long wr = w[r];
+    for (int p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+      const int j = col[p];
+      if (strong[perm ? perm[p] : p] && state[j] == 0) {
+        best = max(best, w[j]);
+        atomicMax(&m[j], wr);
+      }
+    }
+    atomicMax(&m[r], best);
+  }
+}
+
+__global__ __launch_bounds__(GLA_BLOCK) void pmis_select_kernel(int64_t n, const unsigned long long* __restrict__ w,
+                                                                int8_t* __restrict__ state,
+                                                                unsigned long long* __restrict__ m) {
+  for (int64_t i = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GLA_BLOCK) {
+    if (state[i] == 0 && w[i] > m[i]) state[i] = 1;
+    m[i] = ~0ull ^ PMIS_BIAS;                       // reset for the next round
+  }
+}
+
+// undecided rows that strongly depend on a C point become F; counts what stays undecided
+__global__ __launch_bounds__(GLA_BLOCK) void pmis_f_kernel(const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col,
+                                                           const int32_t* __restrict__ perm,
+                                                           const uint8_t* __restrict__ strong, int64_t n,
+                                                           int8_t* __restrict__ state, unsigned* __restrict__ undecided) {
+  unsigned cnt = 0;
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * GLA_BLOCK) {
+    if (state[r] != 0) continue;
+    bool f = false;
+    for (int p = rowptr[r]; p < rowptr[r + 1] && !f; ++p)
+      f = strong[perm ? perm[p] : p] && state[col[p]] == 1;   // C states are final; only this thread writes state[r]
+    if (f) state[r] = -1; else ++cnt;
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(undecided, cnt);
+}
+
+__global__ __launch_bounds__(GLA_BLOCK) void pmis_out_kernel(const int8_t* __restrict__ state, int64_t n,
+                                                             int64_t* __restrict__ split) {
+  for (int64_t i = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GLA_BLOCK)
+    split[i] = state[i] >= 0 ? 1 : 0;               // C, or still undecided after max_rounds
 }
 
 }  // namespace
@@ -233,9 +361,56 @@ int coalesce_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* ro
 extern "C" {
 
 int gla_release_scratch(void) {
-  if (g_pool.base) (void)hipFree(g_pool.base);
-  g_pool.base = nullptr;
-  g_pool.cap = g_pool.used = 0;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  for (auto& kv : g_pools) {                          // every device's pool (hipFree takes any device's pointer)
+    if (kv.second.base) (void)hipFree(kv.second.base);
+    kv.second = Pool();
+  }
+  return GLA_OK;
+}
+
+int gla_pmis_split(gla_csr_t A, const uint8_t* strong_edge, int64_t* split_out, int max_rounds, int* rounds_host,
+                   gla_stream_t stream) {
+  if (!A || max_rounds < 0 || A->n_rows != A->n_cols || (A->nnz > 0 && !strong_edge) || (A->n_rows > 0 && !split_out))
+    return GLA_ERR_INVALID_ARG;
+  if (rounds_host) *rounds_host = 0;
+  const int64_t n = A->n_rows;
+  if (n == 0) return GLA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  PoolScope scope;
+  if (scope.rc) return scope.rc;
+  int rc = pool_reserve(al256(n * 4) + 2 * al256(n) + 2 * al256(n * 8) + 4096);
+  if (rc) return rc;
+  unsigned* lam = pool_get<unsigned>(n);
+  uint8_t* touched = pool_get<uint8_t>(n);
+  int8_t* state = pool_get<int8_t>(n);
+  unsigned long long* w = pool_get<unsigned long long>(n);
+  unsigned long long* m = pool_get<unsigned long long>(n);
+  unsigned* undecided = pool_get<unsigned>(1);
+  if (!lam || !touched || !state || !w || !m || !undecided) return GLA_ERR_INVALID_ARG;
+  GLA_HIP_CHECK(hipMemsetAsync(lam, 0, n * sizeof(unsigned), st));
+  GLA_HIP_CHECK(hipMemsetAsync(touched, 0, n, st));
+  const dim3 grid(grid_for(n)), block(GLA_BLOCK);
+  hipLaunchKernelGGL(pmis_count_kernel, grid, block, 0, st, A->rowptr, A->col, A->perm, strong_edge, n, lam, touched);
+  GLA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pmis_init_kernel, grid, block, 0, st, lam, touched, n, w, state, m);
+  GLA_LAUNCH_CHECK();
+  int rounds = 0;
+  for (; rounds < max_rounds; ++rounds) {
+    unsigned left = 0;
+    GLA_HIP_CHECK(hipMemsetAsync(undecided, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(pmis_max_kernel, grid, block, 0, st, A->rowptr, A->col, A->perm, strong_edge, n, w, state, m);
+    hipLaunchKernelGGL(pmis_select_kernel, grid, block, 0, st, n, w, state, m);
+    hipLaunchKernelGGL(pmis_f_kernel, grid, block, 0, st, A->rowptr, A->col, A->perm, strong_edge, n, state, undecided);
+    GLA_LAUNCH_CHECK();
+    GLA_HIP_CHECK(hipMemcpyAsync(&left, undecided, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    GLA_HIP_CHECK(hipStreamSynchronize(st));
+    if (left == 0) { ++rounds; break; }
+  }
+  hipLaunchKernelGGL(pmis_out_kernel, grid, block, 0, st, state, n, split_out);
+  GLA_LAUNCH_CHECK();
+  GLA_HIP_CHECK(hipStreamSynchronize(st));
+  if (rounds_host) *rounds_host = rounds;
   return GLA_OK;
 }
 
@@ -244,6 +419,8 @@ int gla_spgemm_count(gla_csr_t A, gla_csr_t B, int64_t* n_products_host, gla_str
   hipStream_t st = (hipStream_t)stream;
   *n_products_host = 0;
   if (A->nnz == 0) return GLA_OK;
+  PoolScope scope;
+  if (scope.rc) return scope.rc;
   size_t tmp_bytes = 0;
   GLA_HIP_CHECK(rocprim::inclusive_scan(nullptr, tmp_bytes, (int64_t*)nullptr, (int64_t*)nullptr, (size_t)A->nnz,
                                         rocprim::plus<int64_t>(), st));
@@ -268,6 +445,8 @@ int gla_spgemm(gla_csr_t A, gla_csr_t B, int dtype, int64_t n_products, int64_t*
     return GLA_ERR_INVALID_ARG;
   if ((A->nnz > 0 && A->val_dtype != dtype) || (B->nnz > 0 && B->val_dtype != dtype)) return GLA_ERR_NO_VALUES;
   if (n_products > 0 && (!row_out || !col_out || !val_out)) return GLA_ERR_INVALID_ARG;
+  PoolScope scope;
+  if (scope.rc) return scope.rc;
   if (dtype == GLA_F64)
     return spgemm_impl<double>(A, B, n_products, row_out, col_out, (double*)val_out, nnz_out_host, (hipStream_t)stream);
   return spgemm_impl<float>(A, B, n_products, row_out, col_out, (float*)val_out, nnz_out_host, (hipStream_t)stream);
@@ -279,6 +458,8 @@ int gla_coo_coalesce(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t*
   if (n_rows < 0 || n_cols < 0 || nnz < 0 || !nnz_out_host || val_stride < 1 || (dtype != GLA_F32 && dtype != GLA_F64))
     return GLA_ERR_INVALID_ARG;
   if (nnz > 0 && (!row || !col || !val || !row_out || !col_out || !val_out)) return GLA_ERR_INVALID_ARG;
+  PoolScope scope;
+  if (scope.rc) return scope.rc;
   if (dtype == GLA_F64)
     return coalesce_impl<double>(n_rows, n_cols, nnz, row, col, (const double*)val, val_stride, row_out, col_out,
                                  (double*)val_out, nnz_out_host, (hipStream_t)stream);

@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from ._lib import check, dtype_code, lib, ptr, stream_ptr
+from ._lib import GlaError, check, dtype_code, lib, ptr, stream_ptr
 from .plan import CsrPlan, _DeviceGuard
 
 
@@ -21,15 +21,18 @@ def coalesce(edge_index, values, n_rows, n_cols):
     nnz = ei.shape[1]
     if vals.numel() != nnz:
         raise ValueError("values and edge_index disagree on the number of entries")
-    if nnz and (int(ei.min()) < 0 or int(ei[0].max()) >= n_rows or int(ei[1].max()) >= n_cols):
-        raise ValueError("edge index out of range")
     out_i = torch.empty((2, nnz), dtype=torch.long, device=ei.device)
     out_v = torch.empty(nnz, dtype=vals.dtype, device=ei.device)
     n_out = ctypes.c_int64()
     with _DeviceGuard(ei.device):
-        check(lib().gla_coo_coalesce(int(n_rows), int(n_cols), nnz, ptr(ei[0]), ptr(ei[1]), ptr(vals), 1,
-                                     dtype_code(vals.dtype), ptr(out_i[0]), ptr(out_i[1]), ptr(out_v),
-                                     ctypes.byref(n_out), stream_ptr(ei.device)))
+        try:                                            # the library validates the indices in its key pass
+            check(lib().gla_coo_coalesce(int(n_rows), int(n_cols), nnz, ptr(ei[0]), ptr(ei[1]), ptr(vals), 1,
+                                         dtype_code(vals.dtype), ptr(out_i[0]), ptr(out_i[1]), ptr(out_v),
+                                         ctypes.byref(n_out), stream_ptr(ei.device)))
+        except GlaError as exc:
+            if exc.code == -2:
+                raise ValueError("edge index out of range") from None
+            raise
     return out_i[:, :n_out.value].contiguous(), out_v[:n_out.value].contiguous()
 
 

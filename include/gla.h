@@ -48,7 +48,8 @@ enum {
 };
 
 /* 100 * major + minor; entry points are only ever added within a major version (110: + gla_edge_attr,
- * gla_segment_stats, gla_edge_dot, gla_mlp_relu3 / gla_mlp_work_bytes). */
+ * gla_segment_stats, gla_edge_dot, gla_mlp_relu3 / gla_mlp_work_bytes; 120: + gla_comm_*, gla_halo_*, gla_dist_jacobi_sweeps,
+ * gla_pmis_split). */
 int gla_version(void);
 /* Tuning knobs (process-wide): "spmv_variant" (kernel flavour for K = 1), "tile_nnz" (target nnz per row
  * tile for plans created afterwards; 0 = automatic), "compress" (1: value-dependent compression at gla_csr_set_values:
@@ -297,9 +298,19 @@ int gla_coo_coalesce(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t*
  * row_out / col_out / val_out [n_products] and returns the number of entries of C.  Both synchronise.
  * Duplicates are added in a defined order: A's CSR order, then B's. */
 int gla_spgemm_count(gla_csr_t A, gla_csr_t B, int64_t* n_products_host, gla_stream_t stream);
-/* gla_coo_coalesce / gla_spgemm* keep their scratch in one grow-only device pool (one setup call at a time, not
- * re-entrant); this frees it. */
+/* gla_coo_coalesce / gla_spgemm* / gla_pmis_split keep their scratch in one grow-only pool per device; the setup
+ * entry points serialise on one lock (safe to call from several threads / for several devices).  This frees the pools. */
 int gla_release_scratch(void);
+
+/* Deterministic PMIS-style C/F splitting on the OFF-DIAGONAL plan; strong_edge[e] != 0 says vertex row(e) strongly
+ * depends on col(e) (EDGE order, e.g. S_ij > 0 of gla_soc_classic); split_out int64 [n], 1 = C point.  Stands where
+ * the reference calls pyamg.classical.split.CLJP (VCycle.py:103-116, DirectInterpGNN.py:194) -- upstream is randomised,
+ * so the rule is this library's own (csrc/gla_sparse.hip; a CPU restatement lives with the test oracle):
+ * weight = (influence count, fixed hash of the vertex id), rounds of "local weight maxima of the undecided strong graph
+ * become C, undecided vertices depending on a C point become F".  Synchronises once per round (rounds_host, may be
+ * NULL, receives their number). */
+int gla_pmis_split(gla_csr_t A_od, const uint8_t* strong_edge, int64_t* split_out, int max_rounds,
+                   int* rounds_host, gla_stream_t stream);
 int gla_spgemm(gla_csr_t A, gla_csr_t B, int dtype, int64_t n_products, int64_t* row_out, int64_t* col_out,
                void* val_out, int64_t* nnz_out_host, gla_stream_t stream);
 

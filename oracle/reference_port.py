@@ -443,6 +443,44 @@ def vcycle(A, b, x, splitting, n_pre=3, n_post=3, cheb_deg=4, theta=0.25, w=0.7)
     return run_jacobi(n_post, x)
 
 
+def pmis_splitting(edgeij_pair_od, strong, n, max_rounds=64):
+    """CPU restatement (torch ops) of the library's deterministic PMIS rule, gla_pmis_split (csrc/gla_sparse.hip).
+    NOT a reference function: the reference calls pyamg's randomised CLJP (VCycle.py:114), whose output nothing in
+    the reference pins (parity unpinned), so the rule is the build's own and this is its checker.
+    weight_i = (number of vertices that strongly depend on i) << 52 | fmix32(i + 1) << 20 | (i & 0xFFFFF)."""
+    strong = strong.reshape(-1).to(torch.bool)
+    row, col = edgeij_pair_od[0][strong], edgeij_pair_od[1][strong]
+    lam = torch.bincount(col, minlength=n)
+    idx = torch.arange(n, dtype=torch.int64)
+    h = (idx + 1) & 0xFFFFFFFF                                       # murmur3 fmix32: a fixed pseudo-random order
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h = h ^ (h >> 16)
+    w = (lam << 52) | (h << 20) | (idx & 0xFFFFF)
+    state = torch.zeros(n, dtype=torch.int64)                        # 0 undecided, 1 C, -1 F
+    touched = torch.zeros(n, dtype=torch.bool)
+    touched[row] = True
+    touched[col] = True
+    state[~touched] = 1
+    a = torch.cat([row, col])                                        # symmetrised strong graph a -> b
+    b = torch.cat([col, row])
+    for _ in range(max_rounds):
+        und = state == 0
+        if not bool(und.any()):
+            break
+        live = und[a] & und[b]
+        m = torch.full((n,), -1, dtype=torch.int64)
+        m.scatter_reduce_(0, a[live], w[b[live]], "amax", include_self=True)
+        new_c = und & (w > m)
+        state[new_c] = 1
+        dep = (state[row] == 0) & (state[col] == 1)                  # undecided i strongly depends on a C point
+        state[row[dep]] = -1
+    state[state == 0] = 1
+    return (state == 1).to(torch.int64)
+
+
 # ---------------------------------------------------------------------------------------------------
 # learned Jacobi diagonal (SURVEY.md 8f rank 4): pytorch/TrainableJacobiDiag/{TrainableJacobiGNN,loss}.py.
 # Pinned by tests/golden/trainable_vectors.npz (oracle/gen_golden_trainable.py, unmodified reference).
