@@ -789,8 +789,8 @@ int gla_direct_interp(gla_csr_t A, int dtype, const void* diag, const void* cf, 
                       void* alpha_out, gla_stream_t stream) {
   int rc = check_plan(A, dtype, 1);
   if (rc) return rc;
-  if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
-  if (A->n_rows > 0 && (!diag || !cf)) return GLA_ERR_INVALID_ARG;
+  if (A->n_cols < A->n_rows) return GLA_ERR_INVALID_ARG;      // cf is indexed by column AND by row: [n_cols] with the
+  if (A->n_rows > 0 && (!diag || !cf)) return GLA_ERR_INVALID_ARG;   // plan's rows first (a row block + its halo columns)
   if (A->nnz > 0 && (!S || !w_out)) return GLA_ERR_INVALID_ARG;
   if (A->n_rows == 0) return GLA_OK;
   TileMap tm = all_tiles(A);

@@ -332,7 +332,7 @@ class CsrPlan:
     def direct_interp(self, diag, cf, S, want_alpha=False):
         dtype = diag.dtype
         self._need(dtype)
-        for name, t, n in (("diag", diag, self.n_rows), ("cf", cf, self.n_rows), ("S", S, self.nnz)):
+        for name, t, n in (("diag", diag, self.n_rows), ("cf", cf, self.n_cols), ("S", S, self.nnz)):
             if t.numel() != n or not t.is_contiguous() or t.dtype != dtype or not t.is_cuda:
                 raise ValueError(f"{name} must be a contiguous {dtype} GPU vector of {n} elements")
         w = torch.empty((self.nnz,), dtype=dtype, device=self.device)

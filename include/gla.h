@@ -225,8 +225,9 @@ int gla_edge_attr(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, voi
 int gla_soc_classic(gla_csr_t A_od, int dtype, double theta, void* v_out, void* S_out, gla_stream_t stream);
 
 /* Direct interpolation on the off-diagonal plan: gamma_i = sum_k A_ik / sum_k (A_ik*S_ik*C_k),
- * alpha_i = (1/A_ii)*gamma_i, w_e = (1 - C_i) * (-A_e * alpha_i); S, w in edge order, cf/diag [n].
- * DirectInterpGNN.py:50-174.  alpha_out may be NULL. */
+ * alpha_i = (1/A_ii)*gamma_i, w_e = (1 - C_i) * (-A_e * alpha_i); S, w in edge order, diag [n_rows], cf [n_cols]
+ * (square plans: the same n; a row block whose columns are numbered [own rows | halo] passes the flags of its halo
+ * columns behind its own).  DirectInterpGNN.py:50-174.  alpha_out may be NULL. */
 int gla_direct_interp(gla_csr_t A_od, int dtype, const void* diag, const void* cf, const void* S,
                       void* w_out, void* alpha_out, gla_stream_t stream);
 

@@ -292,3 +292,66 @@ def test_library_loop_host_cost_per_sweep():
     torch.cuda.synchronize()
     print(f"library loop host cost: {t_host * 1e6:.1f} us per sweep (pack + all-gather + 2 launches + events)")
     assert t_host < 100e-6, t_host
+
+
+def _amg_dist_setup_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gnn_applied_linear_algebra_amd as gla
+        from gnn_applied_linear_algebra_amd.dist_amg import RowBlockAMG, even_blocks, _row_slice
+        dev = torch.device("cuda:0")
+        V = gla.VCycle
+        m = 63
+        n = m * m
+        ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 2.0], device=dev)
+        lo, hi = even_blocks(n, world)[rank]
+        e_l, v_l = _row_slice(ei, ev, lo, hi)                       # all this rank is given: its rows of A
+        for kwargs in (dict(coarse_solver="dense"), dict(coarse_deg=8)):
+            H = V.AMGHierarchy(V._as_sparse(ei, ev, (n, n)), levels=3, splitting=V.GridSplitting(m, m), **kwargs)
+            D = RowBlockAMG.distributed_setup(e_l, v_l, n, levels=3, splitting=V.GridSplitting(m, m), **kwargs)
+            assert D.n_levels == len(H.A) == 3
+            for lv in range(3):                                     # every level operator: this rank's rows, bit for bit
+                h_ei, h_ea, _, h_dg = H.gnn[lv]
+                blo, bhi = D.blocks[lv][rank]
+                w_ei, w_ev = _row_slice(h_ei, h_ea, blo, bhi)
+                part = D.A_ops[lv].part
+                assert part.row_lo == blo and part.row_hi == bhi
+                rowptr, col, _ = D.A_ops[lv].plan.arrays()
+                assert int(rowptr[-1]) == w_ei.shape[1], (lv, int(rowptr[-1]), w_ei.shape[1])
+                assert torch.equal(D.diag[lv], h_dg.reshape(-1)[blo:bhi])
+            assert D.setup_nnz_local[0] == e_l.shape[1] < ei.shape[1]
+            gen = torch.Generator().manual_seed(5)
+            b = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
+            x_ref = torch.zeros_like(b)
+            x_loc, b_loc = D.local(x_ref), D.local(b)
+            for _ in range(3):
+                x_ref = H.cycle(b, x_ref)
+                x_loc = D.cycle(b_loc, x_loc)
+                assert torch.equal(x_loc, D.local(x_ref)), "distributed-setup cycle differs from the single-rank cycle"
+            assert torch.equal(D.residual(b_loc, x_loc), D.local(H.residual(b, x_ref)))
+        torch.cuda.synchronize()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_vcycle_setup(world):
+    """BASELINE config 5's SETUP distributed by row blocks (nothing of nnz size replicated): each rank builds its rows
+    of S, W, P, A P, P^T and A_c from its rows of A plus fetched halo rows; the resulting hierarchy and its cycles are
+    bit-identical to the single-rank AMGHierarchy (2 and 3 ranks sharing the GPU, gloo carries the setup objects)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_amg_dist_setup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in sorted(res):
+        assert status == "ok", f"rank {rank}: {status}"
