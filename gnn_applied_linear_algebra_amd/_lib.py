@@ -49,6 +49,7 @@ SIGNATURES = {
     "gla_residual": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
     "gla_jacobi_sweep": (_I, [_P, _I, _I, _P, _P, _I64, _P, _I64, _P, _I64, _D, _I, _P]),
     "gla_jacobi_sweeps": (_I, [_P, _I, _I, _P, _P, _I64, _P, _I64, _P, _P, _I64, _D, _I, _P]),
+    "gla_jacobi_sweeps_schedule": (_I, [_P, _I, _I, ctypes.POINTER(_I)]),
     "gla_cheby_first": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I, _P]),
     "gla_cheby_next": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _D, _D, _I, _P]),
     "gla_dot_work_bytes": (_I64, [_I64, _I, _I]),

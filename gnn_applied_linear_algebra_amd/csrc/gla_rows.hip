@@ -965,6 +965,152 @@ inline int64_t dia2d_blocks_bound(const gla_csr* A) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K = 1, 2-D stencil plans: TS = 2 or 4 Jacobi sweeps per pass over the data (temporal blocking, gla_jacobi_sweeps).
+// A sweep is HBM-bound at 74 B per row (5-point: 40 B of values, 2 B mask, b, A_ii, x in, x out); x^(k+1) .. x^(k+TS-1)
+// are only ever needed to form the next iterate, so a workgroup whose 256 lanes cover a strip of 256 points marches
+// down `lines` grid lines keeping four lines of each intermediate iterate in LDS rings and the coefficients of the
+// last TS lines in registers: every matrix value, b and A_ii is read ONCE per TS sweeps and the intermediate
+// iterates never touch HBM -- 74 / TS bytes per row and sweep, plus the overlap: iterate t is valid on the strip minus
+// t * B points either side (strips overlap by 2 * TS * B points), blocks overlap by 2 * (TS - 1) coefficient lines.
+// Every load is a coalesced 2 KiB row segment.  Per row exactly the arithmetic of spmv_dia_kernel + EpiJacobi, TS times:
+// in-order masked sum over the diagonals, then x + (w * (b - sum)) / A_ii (JacobiGNN.py:119) -- bit-identical to TS
+// single sweeps.
+//   step jl:  ring[0] <- x^(k) line jl + 1 (prefetched) | prefetch x^(k) line jl + 2, coefficients of line jl + 1 |
+//             for t = 1 .. TS:  sync;  x^(k+t) on line jl - (t - 1) from ring[t - 1] lines -1 .. +1 -> ring[t] (t = TS: HBM)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DMAX>
+struct DiaCoef {                                  // one row's matrix data
+  T v[DMAX], b, dg;
+  int m;                                          // diagonal mask | live bit 16
+};
+
+template <typename T, int DMAX, int TS>
+__global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv, const T* __restrict__ diag,
+                                                                       const T* __restrict__ bvec,
+                                                                       const T* __restrict__ x, T* __restrict__ xo, T w,
+                                                                       int lines, int nstrips, int64_t nlines, TileMap tm) {
+  constexpr int BW = GLA_BLOCK;                   // window width = lanes
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* ring = reinterpret_cast<T*>(smem_raw);       // [TS][4][BW]: ring t holds four lines of x^(k+t)
+  const int blk = map_tile(tm);
+  if (blk < 0) return;
+  const int B = dv.B, halo = TS * B, bi_eff = BW - 2 * halo;
+  const int lb = blk / nstrips, strip = blk - lb * nstrips;
+  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bi_eff - halo;   // lane tid <-> point P0 + tid
+  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int tid = threadIdx.x;
+  const T* __restrict__ val = static_cast<const T*>(dv.val);
+  int da[DMAX], db[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) { const int dd = min(d, dv.D - 1); da[d] = dv.da[dd]; db[d] = dv.db[dd]; }
+
+  auto x0_at = [&](int jl) -> T {                 // x^(k) at line J0 + jl, this lane's point (clamped: never used dead)
+    int64_t flat = (J0 + jl) * dv.S + P0 + tid;
+    flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
+    return x[flat];
+  };
+  auto coef_at = [&](int jl) -> DiaCoef<T, DMAX> {   // row (line J0 + jl, this lane's point); dead rows: mask 0
+    const int64_t gj = J0 + jl, gi = P0 + tid, r = gj * dv.S + gi;
+    const bool live = gj >= 0 && gj < nlines && gi >= 0 && gi < dv.S && r < dv.n_rows;
+    const int64_t rc = live ? r : 0;
+    DiaCoef<T, DMAX> c;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) c.v[d] = val[(int64_t)min(d, dv.D - 1) * dv.n_rows + rc];
+    c.b = bvec[rc];
+    c.dg = diag[rc];
+    c.m = live ? ((int)dv.mask[rc] | 0x10000) : 0;
+    return c;
+  };
+  // one Jacobi update of this lane's row on line jl from ring r (lines jl - 1 .. jl + 1; slot of line j: (j + 8) & 3)
+  auto update = [&](const DiaCoef<T, DMAX>& c, const T* r, int jl) -> T {
+    T acc = T(0);
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+      const int pos = min(max(tid + db[d], 0), BW - 1);            // window edge lanes: their results are never used
+      const T xv = r[((jl + da[d] + 8) & 3) * BW + pos];
+      const T nxt = acc + c.v[d] * xv;
+      acc = ((c.m >> d) & 1) ? nxt : acc;
+    }
+    const T xc = r[((jl + 8) & 3) * BW + tid];
+    return xc + (w * (c.b - acc)) / c.dg;
+  };
+
+  // x^(k+1) is formed on lines -(TS-1) .. L-1+(TS-1): it needs x^(k) on lines -TS .. L-1+TS
+  const int j_first = -(TS - 1), j_last = L - 1 + (TS - 1);
+  ring[((j_first - 1 + 8) & 3) * BW + tid] = x0_at(j_first - 1);
+  ring[((j_first + 8) & 3) * BW + tid] = x0_at(j_first);
+  T xpre = x0_at(j_first + 1);
+  DiaCoef<T, DMAX> c[TS];                         // c[t]: coefficients of line jl - t
+  c[0] = coef_at(j_first);
+#pragma unroll
+  for (int t = 1; t < TS; ++t) c[t] = c[0];
+  DiaCoef<T, DMAX> nxt = c[0];
+#pragma unroll 1
+  for (int jl = j_first; jl <= j_last; ++jl) {
+    ring[((jl + 1 + 8) & 3) * BW + tid] = xpre;
+    if (jl + 2 <= j_last + 1) xpre = x0_at(jl + 2);                // prefetch for the next step
+    if (jl + 1 <= j_last) nxt = coef_at(jl + 1);
+#pragma unroll
+    for (int t = 1; t <= TS; ++t) {
+      __syncthreads();
+      const int line = jl - (t - 1);              // x^(k+t) is needed on lines -(TS-t) .. L-1+(TS-t)
+      if (line >= -(TS - t) && line <= L - 1 + (TS - t)) {
+        const T xn = update(c[t - 1], ring + (size_t)(t - 1) * 4 * BW, line);
+        if (t < TS) ring[(size_t)t * 4 * BW + ((line + 8) & 3) * BW + tid] = xn;
+        else if ((c[t - 1].m & 0x10000) && tid >= halo && tid < BW - halo) xo[(J0 + line) * dv.S + P0 + tid] = xn;
+      }
+    }
+#pragma unroll
+    for (int t = TS - 1; t >= 1; --t) c[t] = c[t - 1];
+    c[0] = nxt;
+  }
+}
+
+template <typename T>
+bool jacobi_fused_ok(const gla_csr* A) {
+  return g_tuning.jacobi_fuse && g_tuning.dia && g_tuning.spmv_variant == 0 && A->dia_state == 1 && A->dia_val &&
+         A->dia_S > 0 && A->dia_A == 1 && A->dia_B >= 1 && A->dia_B <= 2 && A->dia_D <= 9 && A->dia_row_lo == 0 &&
+         A->dia_row_hi == A->n_rows && A->n_rows == A->n_cols && !(g_tuning.compress && (A->dia_const || A->packed));
+}
+
+template <typename T, int TS>
+int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st) {
+  Dia2D dv;
+  dv.val = A->dia_val;
+  dv.mask = A->dia_mask;
+  dv.D = A->dia_D; dv.S = A->dia_S; dv.A = A->dia_A; dv.B = A->dia_B;
+  for (int i = 0; i < GLA_DIA_MAX; ++i) { dv.da[i] = i < A->dia_D ? A->dia_a[i] : 0; dv.db[i] = i < A->dia_D ? A->dia_b[i] : 0; }
+  dv.n_rows = A->n_rows; dv.n_cols = A->n_cols;
+  dv.nbi = dv.nbj = dv.nci = dv.nchunks = 0; dv.w_magic = 0; dv.part_off = 0;
+  const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
+  const int bi_eff = GLA_BLOCK - 2 * TS * dv.B;
+  const int nstrips = (int)((A->dia_S + bi_eff - 1) / bi_eff);
+  int lines = g_tuning.jacobi_lines;
+  if (lines <= 0) {
+    // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (TS - 1) coefficient
+    // lines) for which all workgroups are resident at once -- 256 CUs x the waves per SIMD the register budget allows
+    const int64_t slots = 256 * (sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS == 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5));
+    const int64_t blocks = slots / nstrips > 0 ? slots / nstrips : 1;
+    int64_t l = (nlines + blocks - 1) / blocks;
+    if (l < 8 * TS) l = 8 * TS;
+    if (l > 1024) l = 1024;
+    lines = (int)l;
+  }
+  TileMap tm;
+  tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
+  tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
+  set_tile_mapping(tm);
+  const size_t lds = (size_t)TS * 4 * GLA_BLOCK * sizeof(T);
+  const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
+  if (A->dia_D <= 5)
+    hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips, nlines, tm);
+  else
+    hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 9, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips, nlines, tm);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch helper
 // ------------------------------------------------------------------------------------------------
 template <typename T, class Epi>
@@ -1190,6 +1336,25 @@ int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void
   })
 }
 
+// launches of 4, 2 and 1 sweeps that gla_jacobi_sweeps uses for n_iters sweeps on contiguous single-rhs operands
+static void jacobi_schedule(gla_csr* A, int dtype, bool contiguous_k1, int n_iters, int steps[3]) {
+  int tmax = 1;
+  if (contiguous_k1 && n_iters >= 2 && A->n_rows > 0 && A->val_dtype == dtype &&
+      (dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A)))
+    tmax = g_tuning.jacobi_fuse == 2 ? 2 : 4;
+  int left = n_iters;
+  steps[0] = steps[1] = 0;
+  if (tmax >= 4) { steps[0] = left / 4; left %= 4; }
+  if (tmax >= 2) { steps[1] = left / 2; left %= 2; }
+  steps[2] = left;
+}
+
+int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_4_2_1_host) {
+  if (!A || n_iters < 0 || !launches_4_2_1_host || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  jacobi_schedule(A, dtype, true, n_iters, launches_4_2_1_host);
+  return GLA_OK;
+}
+
 int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X0,
                       int64_t ldx0, void* Xout, void* Xtmp, int64_t ldw, double w, int n_iters,
                       gla_stream_t stream) {
@@ -1197,11 +1362,30 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
   if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
   if (n_iters == 0) return GLA_OK;
   if (!Xout || (n_iters > 1 && !Xtmp) || Xout == Xtmp) return GLA_ERR_INVALID_ARG;
+  // 2-D stencil plans, single right-hand side, contiguous vectors: the sweeps are taken 4 (then 2) at a time by the
+  // temporally blocked kernel (the intermediate iterates stay on chip); what is left over runs as ordinary sweeps.
+  // Same arithmetic per row: bit-identical.  Option "jacobi_fuse": 0 off, 1 (default) up to 4, 2 up to 2 per pass.
+  int steps[3];                                    // launches of 4, 2 and 1 sweeps
+  jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && diag && B && X0, n_iters, steps);
+  const int n_launch = steps[0] + steps[1] + steps[2];
   const void* src = X0;
   int64_t lds_ = ldx0;
-  for (int i = 1; i <= n_iters; ++i) {
-    void* dst = ((n_iters - i) % 2 == 0) ? Xout : Xtmp;
-    int rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, src, lds_, dst, ldw, w, 0, stream);
+  for (int i = 1; i <= n_launch; ++i) {
+    void* dst = ((n_launch - i) % 2 == 0) ? Xout : Xtmp;
+    const int ts = i <= steps[0] ? 4 : (i <= steps[0] + steps[1] ? 2 : 1);
+    int rc;
+    if (ts > 1 && src == dst) return GLA_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (ts == 4 && dtype == GLA_F64)
+      rc = launch_jacobi_fused<double, 4>(A, (const double*)diag, (const double*)B, (const double*)src, (double*)dst, (double)w, st);
+    else if (ts == 4)
+      rc = launch_jacobi_fused<float, 4>(A, (const float*)diag, (const float*)B, (const float*)src, (float*)dst, (float)w, st);
+    else if (ts == 2 && dtype == GLA_F64)
+      rc = launch_jacobi_fused<double, 2>(A, (const double*)diag, (const double*)B, (const double*)src, (double*)dst, (double)w, st);
+    else if (ts == 2)
+      rc = launch_jacobi_fused<float, 2>(A, (const float*)diag, (const float*)B, (const float*)src, (float*)dst, (float)w, st);
+    else
+      rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, src, lds_, dst, ldw, w, 0, stream);
     if (rc) return rc;
     src = dst;
     lds_ = ldw;

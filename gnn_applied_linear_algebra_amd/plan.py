@@ -198,6 +198,12 @@ class CsrPlan:
                                       ptr(Xout), ptr(Xtmp), K, float(w), int(n_iters), stream_ptr(self.device)))
         return Xout
 
+    def jacobi_schedule(self, n_iters, dtype=torch.float64):
+        """(launches of 4 sweeps, of 2, of 1) gla_jacobi_sweeps uses for n_iters sweeps on one contiguous rhs."""
+        out = (ctypes.c_int * 3)()
+        check(lib().gla_jacobi_sweeps_schedule(self._h, dtype_code(dtype), int(n_iters), out))
+        return tuple(out)
+
     @_on_device
     def cheby_first(self, B, X, R, P, Xout, alpha, which=ALL_TILES):
         X, K, ldx = _dense(X, self.n_cols, "X")

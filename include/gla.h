@@ -134,6 +134,12 @@ int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void
 int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb,
                       const void* X0, int64_t ldx0, void* Xout, void* Xtmp, int64_t ldw, double w,
                       int n_iters, gla_stream_t stream);
+/* On 2-D stencil plans (diagonal layout whose offsets read as a * S + b on a grid of line length S) with one
+ * contiguous right-hand side, gla_jacobi_sweeps takes the sweeps 4 (then 2) at a time in ONE pass over the data
+ * (temporal blocking: the intermediate iterates stay in LDS; same arithmetic per row, bit-identical results; option
+ * "jacobi_fuse": 0 off, 1 default, 2 at most two per pass; "jacobi_lines": grid lines per workgroup, 0 = automatic).
+ * This reports the launches it will use for n_iters sweeps: out[0] of four sweeps, out[1] of two, out[2] of one. */
+int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_4_2_1_host);
 
 /* Chebyshev, first degree (two MetaLayers fused): R = B - A X; P = R; Xout = X + alpha*R.
  * ChebyGNN.py:49-163. */

@@ -1046,6 +1046,50 @@ def test_dia_layout_bit_identical():
                             np.testing.assert_allclose(a.cpu().numpy(), b_.cpu().numpy(), rtol=1e-12, atol=1e-13)
 
 
+def test_jacobi_temporal_blocking_bit_identical():
+    """gla_jacobi_sweeps on 2-D stencil plans takes the sweeps four (then two) at a time (temporal blocking: the
+    intermediate iterates stay in LDS, the matrix is read once per pass).  Same per-row arithmetic: bit-identical to
+    single sweeps for every sweep count (4 + 2 + 1 combinations), block height, 5- and 9-point stencils, grids that are
+    not multiples of the strip width or narrower than a strip, fp64 and fp32."""
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+    cases = []
+    ei, ev = rp.laplacianfun_torch(300)
+    cases.append(("laplacian 300^2", ei, ev, 90000))
+    ei, ev = rp.laplacianfun_torch(50, 33)                                   # 33 lines of 50 points
+    cases.append(("laplacian 50 x 33", ei, ev, 1650))
+    ei, ev = rp.laplacianfun_torch(1000, 9)                                  # 4 strips, fewer lines than a block
+    cases.append(("laplacian 1000 x 9", ei, ev, 9000))
+    ei, ev = rp.heateqnfem2dfun([71, 59], [1.0, 4.0])
+    cases.append(("fem 9-point 70 x 58", ei, ev, 70 * 58))
+    gen = torch.Generator().manual_seed(21)
+    ei, ev = rp.laplacianfun_torch(64)
+    cases.append(("random values on the 5-point pattern", ei, torch.rand(ei.shape[1], 1, generator=gen, dtype=torch.float64) - 0.3, 4096))
+    for name, ei, ev, n in cases:
+        for dtype in (torch.float64, torch.float32):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            assert plan.info.dia in (5, 9), name
+            g2 = torch.Generator().manual_seed(n)
+            b = d(torch.rand(n, 1, generator=g2, dtype=torch.float64).to(dtype))
+            x = d(torch.rand(n, 1, generator=g2, dtype=torch.float64).to(dtype))
+            diag = d((torch.rand(n, generator=g2, dtype=torch.float64) + 3.0).to(dtype))
+            for its in (1, 2, 3, 6, 7, 20):
+                try:
+                    check(lib().gla_set_option(b"jacobi_fuse", 0))
+                    want = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                finally:
+                    check(lib().gla_set_option(b"jacobi_fuse", 1))
+                for fuse, lines in ((1, 64), (1, 5), (2, 32), (2, 3)):
+                    try:
+                        check(lib().gla_set_option(b"jacobi_fuse", fuse))
+                        check(lib().gla_set_option(b"jacobi_lines", lines))
+                        got = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                    finally:
+                        check(lib().gla_set_option(b"jacobi_fuse", 1))
+                        check(lib().gla_set_option(b"jacobi_lines", 0))
+                    assert torch.equal(got, want), (name, dtype, its, fuse, lines, float((got - want).abs().max()))
+
+
 def test_col16_columns_bit_identical():
     """The default K = 1 kernels read int16 tile-relative columns (option "col16"); tiles with a far column keep
     int32.  Every fused op must give exactly the int32-column result, tile partition unchanged (also the partials)."""

@@ -17,12 +17,15 @@ tag = sys.argv[3] if len(sys.argv) > 3 else "r01"
 col16 = int(sys.argv[4]) if len(sys.argv) > 4 else 1      # the workload ran with int16 tile-relative columns
 dia = int(sys.argv[5]) if len(sys.argv) > 5 else 5          # diagonals of the stencil layout (0: CSR kernels)
 res = collections.defaultdict(lambda: collections.defaultdict(list))
+kernel_names = set()
 for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        key = "jacobi" if "EpiJacobi" in name else ("calib_add" if "CUDAFunctor_add" in name else None)
+        key = "jacobi" if ("EpiJacobi" in name or "jacobi_fused_dia2d" in name) else ("calib_add" if "CUDAFunctor_add" in name else None)
         if key:
             res[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if key == "jacobi":
+                kernel_names.add(name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:120])
 mean = lambda v: sum(v) / len(v)
 j, c = res["jacobi"], res["calib_add"]
 calib_read = 2 * 512 * 1024                      # KiB actually read by the calibration kernel
@@ -33,10 +36,21 @@ alg = 12 * nnz + 4 * (n + 1) + 32 * n
 layout = (10 * nnz + 2 * (n + n // 256) + 32 * n) if col16 else alg      # int16 columns + uint16 row offsets
 if dia:
     layout = (8 * dia + 2 + 32) * n                                        # diagonal-major values + row mask
+fused = any("jacobi_fused_dia2d" in k for k in kernel_names)  # several sweeps per launch (temporal blocking)
+sweeps_per_launch = 1
+if fused:
+    import re
+    ts = {int(re.search(r",\s*(\d+)>", k).group(1)) for k in kernel_names if "jacobi_fused_dia2d" in k}
+    assert len(ts) == 1, f"mixed launch kinds in the workload: {kernel_names}"
+    sweeps_per_launch = ts.pop()
+alg *= sweeps_per_launch
+if fused:
+    layout = (8 * dia + 2 + 32) * n                                        # ONE pass over the data per launch
 rd = mean(j["FETCH_SIZE"]) * 1024 * 2.0
 wr = mean(j["WRITE_SIZE"]) * 1024
 out = {"n": N, "col16": col16, "dia": dia,
-       "kernel": "spmv_dia_kernel<double,EpiJacobi>" if dia else "spmv_stream_vec2_kernel<double,EpiJacobi>", "launches": len(j["FETCH_SIZE"]),
+       "kernel": sorted(kernel_names)[0] if kernel_names else None, "sweeps_per_launch": sweeps_per_launch,
+       "launches": len(j["FETCH_SIZE"]),
        "FETCH_SIZE_KiB": mean(j["FETCH_SIZE"]), "WRITE_SIZE_KiB": mean(j["WRITE_SIZE"]),
        "fetch_correction": 2.0, "calibration_fetch_factor_measured": round(fetch_factor, 4),
        "calibration_write_factor_measured": round(write_factor, 4),
