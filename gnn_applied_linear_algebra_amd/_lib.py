@@ -26,7 +26,8 @@ class CsrInfo(ctypes.Structure):
                 ("n_tiles", ctypes.c_int32), ("tile_nnz", ctypes.c_int32), ("lds_elems", ctypes.c_int32),
                 ("long_rows", ctypes.c_int32), ("val_dtype", ctypes.c_int32), ("packed", ctypes.c_int32),
                 ("col16", ctypes.c_int32), ("col16_wide_tiles", ctypes.c_int32), ("dia", ctypes.c_int32),
-                ("reserved_", ctypes.c_int32), ("dia_row_lo", ctypes.c_int64), ("dia_row_hi", ctypes.c_int64)]
+                ("dia_stride", ctypes.c_int32), ("dia_row_lo", ctypes.c_int64), ("dia_row_hi", ctypes.c_int64),
+                ("dia_A", ctypes.c_int32), ("dia_B", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p
@@ -50,6 +51,7 @@ SIGNATURES = {
     "gla_jacobi_sweep": (_I, [_P, _I, _I, _P, _P, _I64, _P, _I64, _P, _I64, _D, _I, _P]),
     "gla_jacobi_sweeps": (_I, [_P, _I, _I, _P, _P, _I64, _P, _I64, _P, _P, _I64, _D, _I, _P]),
     "gla_jacobi_sweeps_schedule": (_I, [_P, _I, _I, ctypes.POINTER(_I)]),
+    "gla_jacobi_fused": (_I, [_P, _I, _P, _P, _P, _P, _D, _I, _I, _P]),
     "gla_cheby_first": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I, _P]),
     "gla_cheby_next": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _D, _D, _I, _P]),
     "gla_dot_work_bytes": (_I64, [_I64, _I, _I]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "gla_comm_ranks": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gla_halo_begin": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _I64, _P, _P]),
     "gla_halo_end": (_I, [_P, _P]),
+    "gla_comm_all_gather_begin": (_I, [_P, _I, _P, _P, _I64, _P]),
     "gla_comm_all_reduce_sum": (_I, [_P, _I, _P, _I64, _P]),
     "gla_dist_jacobi_sweeps": (_I, [_P, _P, _I, _I, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _P, _D, _I, _I, _P]),
 }

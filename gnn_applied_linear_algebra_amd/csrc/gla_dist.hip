@@ -171,7 +171,20 @@ int gla_halo_begin(gla_comm_t c, int dtype, int K, void* X, int64_t n_in, const 
   return GLA_OK;
 }
 
-// Makes `stream` wait for the all-gather started by the last gla_halo_begin (stream-ordered; the host does not block).
+int gla_comm_all_gather_begin(gla_comm_t c, int dtype, const void* send, void* recv, int64_t count,
+                              gla_stream_t stream) {
+  if (!c || !send || !recv || count < 0 || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  if (count == 0) return GLA_OK;
+  GLA_HIP_CHECK(hipEventRecord(c->ev_pack, (hipStream_t)stream));
+  GLA_HIP_CHECK(hipStreamWaitEvent(c->comm_stream, c->ev_pack, 0));
+  GLA_RCCL_CHECK(g_rccl.all_gather(send, recv, (size_t)count, dtype == GLA_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32, c->comm,
+                                   c->comm_stream));
+  GLA_HIP_CHECK(hipEventRecord(c->ev_halo, c->comm_stream));
+  return GLA_OK;
+}
+
+// Makes `stream` wait for the all-gather started by the last gla_halo_begin / gla_comm_all_gather_begin (stream-ordered;
+// the host does not block).
 int gla_halo_end(gla_comm_t c, gla_stream_t stream) {
   if (!c) return GLA_ERR_INVALID_ARG;
   GLA_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, c->ev_halo, 0));

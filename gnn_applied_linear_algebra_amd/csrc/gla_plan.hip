@@ -938,9 +938,11 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->long_rows = p->long_rows; info->val_dtype = p->val_dtype; info->packed = (p->dia_const && g_tuning.compress) ? 2 : p->packed;
   info->col16 = (p->col16_state == 1 && g_tuning.col16) ? 1 : 0; info->col16_wide_tiles = p->col16_wide_tiles;
   info->dia = (p->dia_state == 1 && g_tuning.dia) ? p->dia_D : 0;
-  info->reserved_ = 0;
+  info->dia_stride = info->dia ? p->dia_S : 0;
   info->dia_row_lo = info->dia ? p->dia_row_lo : 0;
   info->dia_row_hi = info->dia ? p->dia_row_hi : 0;
+  info->dia_A = info->dia ? p->dia_A : 0;
+  info->dia_B = info->dia ? p->dia_B : 0;
   return GLA_OK;
 }
 

@@ -988,12 +988,15 @@ template <typename T, int DMAX, int TS>
 __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv, const T* __restrict__ diag,
                                                                        const T* __restrict__ bvec,
                                                                        const T* __restrict__ x, T* __restrict__ xo, T w,
-                                                                       int lines, int nstrips, int64_t nlines, TileMap tm) {
+                                                                       int lines, int nstrips, int64_t nlines, TileMap tm,
+                                                                       int tile_base0, int tile_split, int tile_base1) {
   constexpr int BW = GLA_BLOCK;                   // window width = lanes
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* ring = reinterpret_cast<T*>(smem_raw);       // [TS][4][BW]: ring t holds four lines of x^(k+t)
-  const int blk = map_tile(tm);
-  if (blk < 0) return;
+  const int slot = map_tile(tm);
+  if (slot < 0) return;
+  // the launch covers tiles base0 + [0, split) and base1 + [0, n - split) (all / interior / first + last line block)
+  const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
   const int B = dv.B, halo = TS * B, bi_eff = BW - 2 * halo;
   const int lb = blk / nstrips, strip = blk - lb * nstrips;
   const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bi_eff - halo;   // lane tid <-> point P0 + tid
@@ -1074,7 +1077,7 @@ bool jacobi_fused_ok(const gla_csr* A) {
 }
 
 template <typename T, int TS>
-int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st) {
+int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0) {
   Dia2D dv;
   dv.val = A->dia_val;
   dv.mask = A->dia_mask;
@@ -1096,16 +1099,31 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     if (l > 1024) l = 1024;
     lines = (int)l;
   }
+  const int nlb_all = (int)((nlines + lines - 1) / lines);
+  // the interior / boundary split only holds when a block is at least 2 TS lines high (block 1 then reads no x from the
+  // first TS lines); otherwise every block counts as boundary
+  const int nlb = (part != 0 && lines < 2 * TS) ? 1 : nlb_all;
+  int base0 = 0, split = nlb_all * nstrips, base1 = 0, count = nlb_all * nstrips;
+  if (part == 1) {                                  // line blocks 1 .. nlb - 2
+    if (nlb < 3) return GLA_OK;
+    base0 = nstrips; count = split = (nlb - 2) * nstrips;
+  } else if (part == 2) {                           // the first and the last line block (all of them when nlb < 3)
+    if (nlb >= 3) { base0 = 0; split = nstrips; base1 = (nlb - 1) * nstrips; count = 2 * nstrips; }
+  } else if (part != 0) {
+    return GLA_ERR_INVALID_ARG;
+  }
   TileMap tm;
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
-  tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
+  tm.n_tiles = count;
   set_tile_mapping(tm);
   const size_t lds = (size_t)TS * 4 * GLA_BLOCK * sizeof(T);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   if (A->dia_D <= 5)
-    hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips, nlines, tm);
+    hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips,
+                       nlines, tm, base0, split, base1);
   else
-    hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 9, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips, nlines, tm);
+    hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 9, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips,
+                       nlines, tm, base0, split, base1);
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }
@@ -1353,6 +1371,23 @@ int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launche
   if (!A || n_iters < 0 || !launches_4_2_1_host || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
   jacobi_schedule(A, dtype, true, n_iters, launches_4_2_1_host);
   return GLA_OK;
+}
+
+int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
+                     int sweeps, int part, gla_stream_t stream) {
+  if (!A || !diag || !B || !X || !Xout || X == Xout || (sweeps != 2 && sweeps != 4) || part < 0 || part > 2 ||
+      (dtype != GLA_F32 && dtype != GLA_F64))
+    return GLA_ERR_INVALID_ARG;
+  if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
+  if (A->n_rows == 0) return GLA_OK;
+  if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A))) return GLA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GLA_F64) {
+    if (sweeps == 4) return launch_jacobi_fused<double, 4>(A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st, part);
+    return launch_jacobi_fused<double, 2>(A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st, part);
+  }
+  if (sweeps == 4) return launch_jacobi_fused<float, 4>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
+  return launch_jacobi_fused<float, 2>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
 }
 
 int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X0,

@@ -82,6 +82,42 @@ def _use_lib_comm(group, device, host_loop):
         return True
     return dist.get_backend(group) == "nccl"
 
+def _publish_rows(ei, ev, row_lo, row_hi, wanted_by_rank, group):
+    """Sparse-row exchange (setup only, object collectives): `wanted_by_rank[q]` = sorted global row ids rank q asks
+    for.  Every rank publishes those of its rows [row_lo, row_hi) that anyone wants; returns the (edge_index, values)
+    of all published rows of OTHER ranks that this rank asked for (CPU -> caller's device), row-sorted."""
+    rank = dist.get_rank(group)
+    dev = ei.device
+    mine = [w[(w >= row_lo) & (w < row_hi)] for q, w in enumerate(wanted_by_rank) if q != rank]
+    pub_ids = torch.unique(torch.cat(mine)) if mine else torch.zeros(0, dtype=torch.int64)
+    if pub_ids.numel():
+        m = torch.isin(ei[0], pub_ids.to(dev))
+        pub = (ei[:, m].cpu(), ev.reshape(-1)[m].cpu())
+    else:
+        pub = (torch.zeros((2, 0), dtype=torch.int64), torch.zeros(0, dtype=ev.dtype))
+    pool = [None] * dist.get_world_size(group)
+    dist.all_gather_object(pool, pub, group=group)
+    want = wanted_by_rank[rank]
+    got_i, got_v = [], []
+    for q, (pi, pv) in enumerate(pool):
+        if q == rank or pi.shape[1] == 0:
+            continue
+        m = torch.isin(pi[0], want)
+        got_i.append(pi[:, m])
+        got_v.append(pv[m])
+    if not got_i:
+        return torch.zeros((2, 0), dtype=torch.int64, device=dev), torch.zeros(0, dtype=ev.dtype, device=dev)
+    gi, gv = torch.cat(got_i, 1), torch.cat(got_v)
+    order = torch.argsort(gi[0], stable=True)                  # owners are disjoint row ranges: row-sorted overall
+    return gi[:, order].to(dev), gv[order].to(dev)
+
+
+def _all_wanted(need, group):
+    wanted = [None] * dist.get_world_size(group)
+    dist.all_gather_object(wanted, need.cpu(), group=group)
+    return wanted
+
+
 class RowBlockPartition:
     def __init__(self, edgeij_pair, n_global, row_lo, row_hi, group=None, col_blocks=None):
         """edgeij_pair [2, nnz_local]: the edges whose ROW lies in [row_lo, row_hi), GLOBAL vertex ids.
@@ -246,12 +282,161 @@ class RowBlockOps:
         return self.part.all_reduce_sum(t)
 
 class RowBlockJacobi(RowBlockOps):
-    """JacobiGNN.forward on a row block: same arguments as the module, local rows only (JacobiGNN.py:138-148)."""
+    """JacobiGNN.forward on a row block: same arguments as the module, local rows only (JacobiGNN.py:138-148).
+
+    Two routes.  (1) One halo exchange per sweep (north_star's wording): interior / boundary tiles of the block's own
+    plan.  (2) `temporal=True` (default) on 2-D stencil blocks with one right-hand side: the temporally blocked kernel
+    of the single-GPU path (4, then 2 sweeps per pass over the data) on the block EXTENDED by ghost lines, with ONE
+    exchange per pass -- the 4 (2) grid lines either side that the pass depends on -- instead of one per sweep
+    (communication-avoiding; the ghost lines are recomputed redundantly, exactly like the overlap between the line
+    blocks of one GPU).  The ghost rows of the matrix are fetched once at construction, those of b and A_ii once per
+    forward().  Same per-row arithmetic: bit-identical to route (1) and to the single-GPU module."""
+
+    TS_MAX = 4
+    ext = None                                               # set by _setup_temporal when the route applies
+
+    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None,
+                 host_loop=False, temporal=True):
+        super().__init__(edgeij_pair, edge_attr, n_global, row_lo, row_hi, group, overlap, col_blocks, host_loop)
+        self.ext = None
+        if temporal and col_blocks is None and self.part.world > 1 and edgeij_pair.is_cuda:
+            self._setup_temporal(edgeij_pair, edge_attr)
+        if self.ext is not None:
+            self.mode = ("temporally blocked: one ghost-line exchange per 4 (2) sweeps, "
+                         + ("libgla_hip RCCL all-gather on a side stream, interior / boundary line blocks overlapped"
+                            if self.comm is not None else "torch.distributed all-gather (host-ordered)"))
+
+    # ---- temporally blocked route -----------------------------------------------------------------------
+    def _setup_temporal(self, edgeij_pair, edge_attr):
+        """Build the plan of the block extended by TS_MAX ghost lines either side (true global rows for the ghost lines
+        within TS_MAX - 1 of the block, fetched from their owners); leaves self.ext = None when the block is not a 2-D
+        stencil, too small, or the extended plan does not qualify for the fused kernel."""
+        from .plan import CsrPlan
+        p, T = self.part, self.TS_MAX
+        info = self.plan.info
+        S = int(info.dia_stride)
+        ok = int(S > 0 and int(info.dia_A) == 1 and all(hi - lo >= T * S for lo, hi in p.blocks)
+                 and all(lo % S == 0 for lo, _ in p.blocks) and p.n_global % S == 0)
+        flag = torch.tensor([ok], dtype=torch.int64)
+        if p.distributed:                                  # every rank must take the same route (collectives below)
+            flags = [None] * p.world
+            dist.all_gather_object(flags, ok, group=p.group)
+            ok = int(all(flags))
+        if not ok:
+            return
+        lo, hi, n = p.row_lo, p.row_hi, p.n_global
+        elo, ehi = max(0, lo - T * S), min(n, hi + T * S)                  # extended x domain
+        glo, ghi = max(0, lo - (T - 1) * S), min(n, hi + (T - 1) * S)      # rows whose matrix entries are needed
+        dev = edgeij_pair.device
+        want = torch.cat([torch.arange(glo, lo), torch.arange(hi, ghi)])
+        ev = edge_attr[:, 0] if edge_attr.dim() == 2 else edge_attr
+        g_ei, g_ev = _publish_rows(edgeij_pair, ev, lo, hi, _all_wanted(want, p.group), p.group)
+        all_ei = torch.cat([g_ei[:, g_ei[0] < lo], edgeij_pair, g_ei[:, g_ei[0] >= hi]], 1)
+        all_ev = torch.cat([g_ev[g_ei[0] < lo], ev.reshape(-1), g_ev[g_ei[0] >= hi]])
+        inside = (all_ei[1] >= elo) & (all_ei[1] < ehi)
+        good = int(bool(inside.all()))
+        plan = None
+        if good:
+            plan = CsrPlan(all_ei - elo, ehi - elo, ehi - elo)
+            plan.set_values(all_ev)
+            good = int(plan.jacobi_schedule(T, all_ev.dtype)[0] == 1 and int(plan.info.dia_stride) == S)
+        goods = [None] * p.world
+        dist.all_gather_object(goods, good, group=p.group)
+        if not all(goods):
+            return
+        up = p.rank > 0 and lo - elo == T * S                # a neighbour above / below supplies T ghost lines
+        down = p.rank < p.world - 1 and ehi - hi == T * S
+        self.ext = dict(plan=plan, S=S, elo=elo, ehi=ehi, n_ext=ehi - elo, off=lo - elo, up=up, down=down,
+                        slab=T * S, dtype=all_ev.dtype, dev=dev)
+
+    def _ghost_exchange(self, own, K_unused=1, begin_only=False):
+        """All-gather of every rank's first and last TS_MAX grid lines of `own` ([n_local]); returns (upper, lower) ghost
+        slabs for this rank (None where there is no neighbour).  With the library communicator the gather runs on its
+        side stream: call with begin_only=True, launch work that needs no ghosts, then _ghost_finish()."""
+        e, p = self.ext, self.part
+        m = e["slab"]
+        send = torch.cat([own[:m], own[-m:]])
+        recv = torch.empty(p.world * 2 * m, dtype=own.dtype, device=own.device)
+        if self.comm is not None:
+            from ._lib import check, dtype_code, lib, ptr, stream_ptr
+            check(lib().gla_comm_all_gather_begin(self.comm._h, dtype_code(own.dtype), ptr(send), ptr(recv), 2 * m,
+                                                  stream_ptr(own.device)))
+            self._ghost_pending = (send, recv)              # keep the buffers alive until the gather has been waited for
+            if begin_only:
+                return None
+            return self._ghost_finish()
+        if own.is_cuda and dist.get_backend(p.group) == "gloo":        # rehearsal route: gloo moves host memory
+            recv_h = torch.empty(p.world * 2 * m, dtype=own.dtype)
+            dist.all_gather_into_tensor(recv_h, send.cpu(), group=p.group)
+            recv = recv_h.to(own.device)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=p.group)
+        self._ghost_pending = (send, recv)
+        return None if begin_only else self._ghost_finish(wait=False)
+
+    def _ghost_finish(self, wait=True):
+        e, p = self.ext, self.part
+        m = e["slab"]
+        send, recv = self._ghost_pending
+        if wait and self.comm is not None:
+            from ._lib import check, lib, stream_ptr
+            check(lib().gla_halo_end(self.comm._h, stream_ptr(recv.device)))
+        upper = recv[(p.rank - 1) * 2 * m + m:(p.rank - 1) * 2 * m + 2 * m] if e["up"] else None      # neighbour's LAST lines
+        lower = recv[(p.rank + 1) * 2 * m:(p.rank + 1) * 2 * m + m] if e["down"] else None             # neighbour's FIRST lines
+        return upper, lower
+
+    def _fill_ghosts(self, ext_vec, slabs):
+        e = self.ext
+        upper, lower = slabs
+        if upper is not None:
+            ext_vec[:e["off"]] = upper
+        if lower is not None:
+            ext_vec[e["off"] + self.part.n_local:] = lower
+
+    def _forward_temporal(self, n_iters, diag, b, x0, w):
+        from ._lib import check, dtype_code, lib, ptr, stream_ptr
+        e, p = self.ext, self.part
+        n_ext, off, nl = e["n_ext"], e["off"], p.n_local
+        dev, dt = x0.device, x0.dtype
+        code, st, h = dtype_code(dt), stream_ptr(dev), e["plan"]._h
+
+        def extended(own, fill):
+            v = torch.full((n_ext,), fill, dtype=dt, device=dev)
+            v[off:off + nl] = own
+            self._fill_ghosts(v, self._ghost_exchange(own))
+            return v
+        d_ext = extended(diag, 1.0)                          # ghost rows of b and A_ii: once per forward
+        b_ext = extended(b, 0.0)
+        cur = torch.zeros(n_ext, dtype=dt, device=dev)
+        nxt = torch.zeros(n_ext, dtype=dt, device=dev)
+        cur[off:off + nl] = x0
+        left = int(n_iters)
+        while left > 0:
+            ts = 4 if left >= 4 else (2 if left >= 2 else 1)
+            own = cur[off:off + nl]
+            if ts == 1:                                      # one ordinary sweep of the extended block
+                self._fill_ghosts(cur, self._ghost_exchange(own))
+                check(lib().gla_jacobi_sweep(h, code, 1, ptr(d_ext), ptr(b_ext), 1, ptr(cur), 1, ptr(nxt), 1, w, 0, st))
+            elif self.comm is not None and self.overlap:
+                self._ghost_exchange(own, begin_only=True)   # ghost lines in flight on the side stream ...
+                check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, st))
+                self._fill_ghosts(cur, self._ghost_finish())  # ... while the interior line blocks run
+                check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 2, st))
+            else:
+                self._fill_ghosts(cur, self._ghost_exchange(own))
+                check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 0, st))
+            cur, nxt = nxt, cur
+            left -= ts
+        self._ghost_pending = None
+        return cur[off:off + nl].reshape(-1, 1).clone()
 
     def forward(self, n_iters, vertex_attr, g):
         p = self.part
         va = vertex_attr
         K = 1 if va.dim() == 2 else va.shape[2]
+        if self.ext is not None and K == 1 and va.dim() == 2 and va.dtype == self.ext["dtype"] and int(n_iters) > 0:
+            return self._forward_temporal(int(n_iters), va[:, 0].contiguous(), va[:, 1].contiguous(),
+                                          va[:, 2].contiguous(), float(g.reshape(-1)[0]))
         diag = (va[:, 0] if va.dim() == 2 else va[:, 0, 0]).contiguous()
         B = (va[:, 1].reshape(-1, 1) if va.dim() == 2 else va[:, 1, :]).contiguous()
         w = float(g.reshape(-1)[0])

@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from .ChebyGNN import chebyshev_relax
-from .dist import RowBlockOps
+from .dist import RowBlockOps, _all_wanted, _publish_rows
 
 
 def even_blocks(n, world):
@@ -50,42 +50,6 @@ class _CoarseSolve:
     def __init__(self, H):
         self.plan, self.lu, self.bounds = H.plans[-1], H._coarse_lu, H.coarse_bounds
         self.sweeps, self.deg = H.coarse_sweeps, H.cheby.deg
-
-
-def _publish_rows(ei, ev, row_lo, row_hi, wanted_by_rank, group):
-    """Sparse-row exchange (setup only, object collectives): `wanted_by_rank[q]` = sorted global row ids rank q asks
-    for.  Every rank publishes those of its rows [row_lo, row_hi) that anyone wants; returns the (edge_index, values)
-    of all published rows of OTHER ranks that this rank asked for (CPU -> caller's device), row-sorted."""
-    rank = dist.get_rank(group)
-    dev = ei.device
-    mine = [w[(w >= row_lo) & (w < row_hi)] for q, w in enumerate(wanted_by_rank) if q != rank]
-    pub_ids = torch.unique(torch.cat(mine)) if mine else torch.zeros(0, dtype=torch.int64)
-    if pub_ids.numel():
-        m = torch.isin(ei[0], pub_ids.to(dev))
-        pub = (ei[:, m].cpu(), ev.reshape(-1)[m].cpu())
-    else:
-        pub = (torch.zeros((2, 0), dtype=torch.int64), torch.zeros(0, dtype=ev.dtype))
-    pool = [None] * dist.get_world_size(group)
-    dist.all_gather_object(pool, pub, group=group)
-    want = wanted_by_rank[rank]
-    got_i, got_v = [], []
-    for q, (pi, pv) in enumerate(pool):
-        if q == rank or pi.shape[1] == 0:
-            continue
-        m = torch.isin(pi[0], want)
-        got_i.append(pi[:, m])
-        got_v.append(pv[m])
-    if not got_i:
-        return torch.zeros((2, 0), dtype=torch.int64, device=dev), torch.zeros(0, dtype=ev.dtype, device=dev)
-    gi, gv = torch.cat(got_i, 1), torch.cat(got_v)
-    order = torch.argsort(gi[0], stable=True)                  # owners are disjoint row ranges: row-sorted overall
-    return gi[:, order].to(dev), gv[order].to(dev)
-
-
-def _all_wanted(need, group):
-    wanted = [None] * dist.get_world_size(group)
-    dist.all_gather_object(wanted, need.cpu(), group=group)
-    return wanted
 
 
 class RowBlockAMG:

@@ -95,9 +95,11 @@ typedef struct {
   int32_t col16;            /* 1: int16 tile-relative columns are in use for K = 1 (option "col16") */
   int32_t col16_wide_tiles; /* row tiles that keep int32 columns (a column out of int16 range) */
   int32_t dia;              /* > 0: the diagonal (stencil) layout with this many diagonals is in use for K = 1 */
-  int32_t reserved_;
+  int32_t dia_stride;       /* > 0: the offsets read as a * S + b on a 2-D grid with this line length S (the blocked
+                             * multi-rhs kernel and the temporally blocked Jacobi kernel apply); 0: no 2-D reading */
   int64_t dia_row_lo, dia_row_hi;   /* rows [lo, hi) that fit the diagonal set (all rows on one GPU; a row block's
                                      * halo rows at either end do not and stay on the CSR kernels) */
+  int32_t dia_A, dia_B;     /* max |a| (grid lines) and max |b| (points) of the 2-D reading */
 } gla_csr_info_t;
 int gla_csr_info(gla_csr_t plan, gla_csr_info_t* info_host);
 
@@ -140,6 +142,12 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
  * "jacobi_fuse": 0 off, 1 default, 2 at most two per pass; "jacobi_lines": grid lines per workgroup, 0 = automatic).
  * This reports the launches it will use for n_iters sweeps: out[0] of four sweeps, out[1] of two, out[2] of one. */
 int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_4_2_1_host);
+/* ONE temporally blocked launch: Xout = `sweeps` (2 or 4) Jacobi sweeps of X (contiguous vectors, K = 1).
+ * part: 0 = every block of grid lines; 1 = the blocks that touch neither the first nor the last block of lines
+ * (they read no x from the first / last `sweeps` grid lines: multi-GPU, while the ghost lines are in flight);
+ * 2 = the first and the last block.  GLA_ERR_UNSUPPORTED when the plan has no 2-D stencil reading. */
+int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
+                     int sweeps, int part, gla_stream_t stream);
 
 /* Chebyshev, first degree (two MetaLayers fused): R = B - A X; P = R; Xout = X + alpha*R.
  * ChebyGNN.py:49-163. */
@@ -261,6 +269,11 @@ int gla_comm_ranks(gla_comm_t comm, int* rank_host, int* nranks_host);
 int gla_halo_begin(gla_comm_t comm, int dtype, int K, void* X, int64_t n_in, const int32_t* send_idx,
                    int64_t n_send, int64_t S, void* send_buf, gla_stream_t stream);
 int gla_halo_end(gla_comm_t comm, gla_stream_t stream);
+/* All-gather of `count` values per rank (send [count] -> recv [nranks * count]) on the communicator's stream once the
+ * work already enqueued on `stream` is done; returns at once, gla_halo_end makes `stream` wait for the result.  Used
+ * for the ghost-line slabs of the temporally blocked multi-GPU sweep (dist.py). */
+int gla_comm_all_gather_begin(gla_comm_t comm, int dtype, const void* send, void* recv, int64_t count,
+                              gla_stream_t stream);
 /* In-place sum over the ranks of `count` device values, stream-ordered (power method: the K resp. 2K partial sums
  * of PowerMethodGNN.py:50-61 vertex_to_global_aggregation). */
 int gla_comm_all_reduce_sum(gla_comm_t comm, int dtype, void* buf, int64_t count, gla_stream_t stream);

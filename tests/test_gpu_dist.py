@@ -55,6 +55,14 @@ def _worker(rank, world, port, overlap, q):
         x1_ref = gla.JacobiGNN.JacobiGNN()(6, torch.stack([diag[:, 0], B[:, 0], X[:, 0]], 1), ei, ea, g)
         x1_loc = jac.forward(6, torch.stack([diag[lo:hi, 0], B[lo:hi, 0], X[lo:hi, 0]], 1), g)
         assert torch.equal(x1_loc, x1_ref[lo:hi]), "jacobi K=1"
+        # route: blocks of >= 4 grid lines take the temporally blocked route (one ghost-line exchange per 4 / 2 sweeps);
+        # the world-4 partition has a one-line block, which sends every rank to the exchange-per-sweep route
+        assert (jac.ext is not None) == (world == 2), (world, jac.ext is None)
+        va1, va1_loc = torch.stack([diag[:, 0], B[:, 0], X[:, 0]], 1), torch.stack([diag[lo:hi, 0], B[lo:hi, 0], X[lo:hi, 0]], 1)
+        for its in (1, 2, 4, 7):                               # 1, 2, 4 and 4 + 2 + 1 sweeps
+            assert torch.equal(jac.forward(its, va1_loc, g), gla.JacobiGNN.JacobiGNN()(its, va1, ei, ea, g)[lo:hi]), its
+        jac_ps = RowBlockJacobi(ei_l, ev_l, n, lo, hi, overlap=overlap, temporal=False)      # exchange per sweep
+        assert jac_ps.ext is None and torch.equal(jac_ps.forward(6, va1_loc, g), x1_ref[lo:hi]), "jacobi per-sweep route"
         info = jac.plan.info                                   # the block's own rows are stencil rows, its halo rows not
         assert info.dia == 5 or hi - lo <= 2 * Nx, info.dia
         if info.dia:
@@ -355,3 +363,50 @@ def test_distributed_vcycle_setup(world):
         p.join(timeout=60)
     for rank, status in sorted(res):
         assert status == "ok", f"rank {rank}: {status}"
+
+
+def test_jacobi_fused_parts_and_library_all_gather():
+    """gla_jacobi_fused: interior line blocks (part 1) + first / last line block (part 2) == all blocks (part 0) == 4
+    single sweeps; and gla_comm_all_gather_begin / gla_halo_end on a real (one-rank) RCCL communicator -- the two
+    pieces the temporally blocked multi-GPU route is made of (dist.RowBlockJacobi._forward_temporal)."""
+    import ctypes
+    import gnn_applied_linear_algebra_amd as gla
+    from gnn_applied_linear_algebra_amd._lib import check, lib, ptr, stream_ptr, dtype_code
+    from gnn_applied_linear_algebra_amd.dist import LibComm
+    dev = torch.device("cuda:0")
+    Nx, Ny = 300, 700
+    n = Nx * Ny
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(Nx, Ny=Ny, device=dev)
+    plan = gla.CsrPlan(ei, n)
+    plan.set_values(ev)
+    gen = torch.Generator().manual_seed(2)
+    b = torch.rand(n, generator=gen, dtype=torch.float64).to(dev)
+    x = torch.rand(n, generator=gen, dtype=torch.float64).to(dev)
+    diag = torch.full((n,), -4.0, dtype=torch.float64, device=dev)
+    st, code = stream_ptr(dev), dtype_code(torch.float64)
+    for ts in (4, 2):
+        try:
+            check(lib().gla_set_option(b"jacobi_fuse", 0))
+            want = plan.jacobi_sweeps(diag, b.reshape(-1, 1), x.reshape(-1, 1), 0.7, ts).reshape(-1)
+        finally:
+            check(lib().gla_set_option(b"jacobi_fuse", 1))
+        for lines in (0, 40, 5):                               # 5 < 2 * ts: every block counts as boundary
+            try:
+                check(lib().gla_set_option(b"jacobi_lines", lines))
+                whole, parts = torch.zeros_like(x), torch.zeros_like(x)
+                check(lib().gla_jacobi_fused(plan._h, code, ptr(diag), ptr(b), ptr(x), ptr(whole), 0.7, ts, 0, st))
+                check(lib().gla_jacobi_fused(plan._h, code, ptr(diag), ptr(b), ptr(x), ptr(parts), 0.7, ts, 1, st))
+                mid = parts.clone()
+                check(lib().gla_jacobi_fused(plan._h, code, ptr(diag), ptr(b), ptr(x), ptr(parts), 0.7, ts, 2, st))
+            finally:
+                check(lib().gla_set_option(b"jacobi_lines", 0))
+            assert torch.equal(whole, want) and torch.equal(parts, want), (ts, lines)
+            if lines == 40:                                    # the interior launch alone leaves the outer blocks alone
+                assert bool((mid[:40 * Nx] == 0).all()) and bool((mid[-20 * Nx:] == 0).all()) and bool((mid[40 * Nx:80 * Nx] != 0).all())
+    comm = LibComm()
+    send = torch.arange(1000, dtype=torch.float64, device=dev)
+    recv = torch.zeros(1000, dtype=torch.float64, device=dev)
+    check(lib().gla_comm_all_gather_begin(comm._h, code, ptr(send), ptr(recv), 1000, st))
+    check(lib().gla_halo_end(comm._h, st))
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send)
