@@ -2,8 +2,11 @@
 sandialabs/gnn-applied-linear-algebra's sparse message-passing hot path.
 
 Module names mirror the reference's flat `pytorch/` directory (UtilsGNN, MatVecGNN, GNNResidual, JacobiGNN,
-ChebyGNN, PowerMethodGNN, SOCClassicGNN, DirectInterpGNN, VCycle, SOCSAGNN, MatrixWeightedNorm).  All arithmetic
-runs in libgla_hip.so (csrc/, C ABI in include/gla.h); there is no CPU fallback.
+ChebyGNN, PowerMethodGNN, SOCClassicGNN, DirectInterpGNN, VCycle, SOCSAGNN, MatrixWeightedNorm).  The sparse arithmetic
+of the path -- every SpMV / SpMM / aggregation, strength of connection, interpolation weights, C/F splitting, coalesce,
+SpGEMM, halo exchange -- runs in libgla_hip.so (csrc/, C ABI in include/gla.h); torch ops remain for tensor glue (cat,
+stack, slicing), the dense LU of a coarsest AMG level and the O(n) index vectors of the distributed setup.  There is
+no CPU fallback.
 """
 from . import _lib  # noqa: F401
 from .meta import MetaLayer  # noqa: F401
