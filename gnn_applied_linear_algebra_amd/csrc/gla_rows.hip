@@ -140,8 +140,9 @@ struct EpiChebyNext {                   // r -= a_old*(A p); p = r + beta p; x +
 template <typename T>
 __device__ __forceinline__ T div_by(T a, T b, T rb) {
   // a / b from the correctly rounded reciprocal rb = RN(1/b) with one Markstein correction step: q = RN(a*rb),
-  // r = a - q*b (exact in an FMA), q' = RN(q + r*rb) -- the correctly rounded quotient except for rare
-  // last-place cases, at 3 instructions instead of the ~30 of an IEEE fp64 division per gathered value.
+  // r = a - q*b (exact in an FMA), q' = RN(q + r*rb) = RN(a / b) (Markstein 1990) for every b whose significand is
+  // not all ones; those divisors take the true division (all_ones, below).  3 instructions instead of the ~30 of an
+  // IEEE fp64 division per gathered value; 671 M random quotients compared bit for bit (tools/exp_power_division.py).
   const T q = a * rb;
   const T r = fma_t(-q, b, a);
   return fma_t(r, rb, q);
@@ -152,21 +153,31 @@ struct EpiPower {
   T* y; int64_t ldy; const T* nrm; const T* rnrm; T* partials;
   template <typename V> struct PreV {};
   static constexpr int NRED = 1;
-  template <typename V> struct GxV { V n, rn; };                // this lane's divisor(s), loaded once per kernel
+  template <typename V> struct GxV { V n, rn; bool slow; };      // this lane's divisor(s), loaded once per kernel
+  static __device__ __forceinline__ bool all_ones(T v) {         // significand all ones: the one case Markstein excludes
+    if constexpr (sizeof(T) == 8) return (__builtin_bit_cast(unsigned long long, v) & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+    else return (__builtin_bit_cast(unsigned, v) & 0x7FFFFFu) == 0x7FFFFFu;
+  }
   template <typename V> __device__ __forceinline__ GxV<V> gx_load(int k) const {
     GxV<V> g;
-    if constexpr (sizeof(V) == sizeof(T)) { g.n = nrm ? nrm[k] : T(1); g.rn = nrm ? rnrm[k] : T(1); }
-    else {
+    g.slow = false;
+    if constexpr (sizeof(V) == sizeof(T)) {
+      g.n = nrm ? nrm[k] : T(1);
+      g.rn = nrm ? rnrm[k] : T(1);
+      g.slow = all_ones(g.n);
+    } else {
 #pragma unroll
       for (int i = 0; i < (int)(sizeof(V) / sizeof(T)); ++i) {
         g.n[i] = nrm ? nrm[k + i] : T(1);
         g.rn[i] = nrm ? rnrm[k + i] : T(1);
+        g.slow = g.slow || all_ones(g.n[i]);
       }
     }
     return g;
   }
   template <typename V> __device__ __forceinline__ V gx(V xv, const GxV<V>& g) const {
     if (!nrm) return xv;
+    if (g.slow) return xv / g.n;                                 // IEEE division (never taken in practice)
     if constexpr (sizeof(V) == sizeof(T)) return div_by(xv, g.n, g.rn);
     else {
       V o;

@@ -176,7 +176,8 @@ int gla_col_scale_rsqrt(int dtype, int64_t n, int K, const void* X, int64_t ldx,
 /* One FUSED power-method step on K columns (PowerMethodGNN.py:86-207, the three MetaLayers of an iteration):
  *   Y = A * (X ./ nrm_in)      (nrm_in [K] = sqrt of the previous sums and rnrm_in [K] = 1 ./ nrm_in, both NULL: X
  *                               used as is; every gathered value is divided through the reciprocal with one
- *                               correction step, i.e. the reference's b = b / n up to rare last-place cases)
+ *                               Markstein correction step = the correctly rounded b / n of the reference; divisors
+ *                               whose significand is all ones, the theorem's one exception, take a true division)
  *   sumsq_out[k] = sum_i Y[i,k]^2   (workgroup partials in `work`, then a fixed-order second stage)
  * work: gla_power_work_bytes(A, K, dtype).  With which_tiles = 1 (interior) the second stage is deferred to the
  * which_tiles = 2 (boundary) call.  Returns GLA_ERR_UNSUPPORTED for plans with long rows or odd K > 1 (use

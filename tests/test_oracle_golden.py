@@ -261,3 +261,44 @@ def test_matvec_config1_size(vc64, k):
     np.testing.assert_array_equal(va.numpy(), vc64[f"mv64_k{k}_va"])
     if k <= 2:
         np.testing.assert_array_equal(ea.numpy(), vc64[f"mv64_k{k}_ea"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# U4 (heateqnfem2dfun, MATLAB only): an INDEPENDENT known answer for the whole matrix, boundary rows included
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cx,cy,hx,hy", [(6, 5, 1.0, 1.0), (9, 7, 1.0, 4.0), (4, 12, 0.5, 0.125), (33, 17, 2.0, 3.0)])
+def test_heateqnfem2dfun_equals_tensor_product_stiffness(cx, cy, hx, hy):
+    """The element matrix of matlab/heateqnfem2dfun.m:71-100, (1/6a)[2a^2+2, -2a^2+1, a^2-2, -1-a^2] with a = hy/hx,
+    is the Q1 stiffness matrix of -Laplace on hx x hy rectangles, and a Q1 stiffness matrix on a tensor-product mesh
+    IS K = M_y (x) K_x + K_y (x) M_x with the 1-D matrices K = tridiag(-1, 2, -1)/h, M = tridiag(1, 4, 1) h/6 (vertex
+    k = j*nx + i).  Eliminating the Dirichlet boundary (BC type 2, :164-168) keeps the interior blocks of the 1-D matrices.
+    This pins EVERY row of the restated builder -- rows next to the boundary too, which the file's own known answer
+    (interior stencil, :105-110) does not -- through an assembly that shares no code with it; BC type 1 (:143-161) is then
+    the same interior block plus identity rows."""
+    import scipy.sparse as sp
+
+    def tri(n, lo, di):
+        return sp.diags([lo * np.ones(n - 1), di * np.ones(n), lo * np.ones(n - 1)], [-1, 0, 1], format="csr")
+
+    a = hy / hx                                                    # only the ratio enters (2-D stiffness is scale-free)
+    mx, my = cx - 1, cy - 1
+    Kx, Mx = tri(mx, -1.0, 2.0), tri(mx, 1.0, 4.0) / 6.0           # hx = 1
+    Ky, My = tri(my, -1.0, 2.0) / a, tri(my, 1.0, 4.0) * (a / 6.0)  # hy = a
+    K_ref = (sp.kron(My, Kx, format="csr") + sp.kron(Ky, Mx, format="csr")).tocsr()
+    K_ref.sum_duplicates()
+    K_ref.eliminate_zeros()
+    ei, ev = rp.heateqnfem2dfun([cx, cy], [hx, hy], bcs=(2, 2))
+    n = mx * my
+    K = sp.csr_matrix((ev.numpy().ravel(), (ei[0].numpy(), ei[1].numpy())), shape=(n, n))
+    assert K.nnz == (3 * mx - 2) * (3 * my - 2) == K_ref.nnz        # same pattern: 9-point, cut at the boundary
+    assert (abs(K - K_ref) > 1e-14 * abs(K_ref).max()).nnz == 0
+    assert abs(K - K.T).max() == 0.0                                # exactly symmetric
+    # BC type 1: all (cx+1)(cy+1) vertices; boundary rows / columns are identity, the interior block is the matrix above
+    ei1, ev1 = rp.heateqnfem2dfun([cx, cy], [hx, hy], bcs=(1, 1))
+    nx, N = cx + 1, (cx + 1) * (cy + 1)
+    K1 = sp.csr_matrix((ev1.numpy().ravel(), (ei1[0].numpy(), ei1[1].numpy())), shape=(N, N))
+    k = np.arange(N)
+    bnd = (k % nx == 0) | (k % nx == cx) | (k // nx == 0) | (k // nx == cy)
+    assert abs(K1[~bnd][:, ~bnd] - K).max() == 0.0
+    assert abs(K1[bnd][:, bnd] - sp.identity(int(bnd.sum()))).max() == 0.0
+    assert K1[bnd][:, ~bnd].nnz == 0 and K1[~bnd][:, bnd].nnz == 0
