@@ -278,14 +278,13 @@ def single_gpu(args, gla, dev):
     elapsed, step_ms = timed_steps(step, args.steps, 0)
     plan.jacobi_sweeps = _sweeps
     total_sweeps = args.steps * args.sweeps
-    # launches behind one step: on 2-D stencil plans gla_jacobi_sweeps takes the sweeps 4 (then 2) at a time in one
+    # launches behind one step: on 2-D stencil plans gla_jacobi_sweeps takes the sweeps 5, 4 or 2 at a time in one
     # pass over the data (temporal blocking); the dominant kernel is the one that covers most sweeps
-    n4, n2, n1 = plan.jacobi_schedule(args.sweeps)
-    launches = n4 + n2 + n1
-    spl = 4 if n4 else (2 if n2 else 1)                      # sweeps per launch of the dominant kernel
-    dominant_share = (4 * n4 if n4 else (2 * n2 if n2 else n1)) / args.sweeps
+    n5, n4, n2, n1 = plan.jacobi_schedule(args.sweeps)
+    launches = n5 + n4 + n2 + n1
+    spl = 5 if n5 else (4 if n4 else (2 if n2 else 1))      # sweeps per launch of the dominant kernel
     per_call = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in sweep_events]      # seconds per jacobi_sweeps call
-    # every launch of a call is the same kernel when the count divides (20 = 5 x 4: the BASELINE configuration);
+    # every launch of a call is the same kernel when the count divides (20 = 4 x 5: the BASELINE configuration);
     # otherwise the call's time is apportioned by sweeps (the left-over launches run at a lower rate: a conservative
     # figure for the dominant kernel)
     per_launch = [t * spl / args.sweeps for t in per_call]

@@ -976,7 +976,7 @@ inline int64_t dia2d_blocks_bound(const gla_csr* A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K = 1, 2-D stencil plans: TS = 2 or 4 Jacobi sweeps per pass over the data (temporal blocking, gla_jacobi_sweeps).
+// K = 1, 2-D stencil plans: TS = 2, 4 or 5 Jacobi sweeps per pass over the data (temporal blocking, gla_jacobi_sweeps).
 // A sweep is HBM-bound at 74 B per row (5-point: 40 B of values, 2 B mask, b, A_ii, x in, x out); x^(k+1) .. x^(k+TS-1)
 // are only ever needed to form the next iterate, so a workgroup whose 256 lanes cover a strip of 256 points marches
 // down `lines` grid lines keeping four lines of each intermediate iterate in LDS rings and the coefficients of the
@@ -1103,7 +1103,7 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   if (lines <= 0) {
     // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (TS - 1) coefficient
     // lines) for which all workgroups are resident at once -- 256 CUs x the waves per SIMD the register budget allows
-    const int64_t slots = 256 * (sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS == 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5));
+    const int64_t slots = 256 * (sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5));
     const int64_t blocks = slots / nstrips > 0 ? slots / nstrips : 1;
     int64_t l = (nlines + blocks - 1) / blocks;
     if (l < 8 * TS) l = 8 * TS;
@@ -1365,28 +1365,36 @@ int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void
   })
 }
 
-// launches of 4, 2 and 1 sweeps that gla_jacobi_sweeps uses for n_iters sweeps on contiguous single-rhs operands
-static void jacobi_schedule(gla_csr* A, int dtype, bool contiguous_k1, int n_iters, int steps[3]) {
+// launches of 5, 4, 2 and 1 sweeps that gla_jacobi_sweeps uses for n_iters sweeps on contiguous single-rhs operands:
+// the fewest passes over the data, and among those the fewest unfused single sweeps (6 = 4 + 2, not 5 + 1)
+static void jacobi_schedule(gla_csr* A, int dtype, bool contiguous_k1, int n_iters, int steps[4]) {
   int tmax = 1;
   if (contiguous_k1 && n_iters >= 2 && A->n_rows > 0 && A->val_dtype == dtype &&
       (dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A)))
-    tmax = g_tuning.jacobi_fuse == 2 ? 2 : 4;
-  int left = n_iters;
-  steps[0] = steps[1] = 0;
-  if (tmax >= 4) { steps[0] = left / 4; left %= 4; }
-  if (tmax >= 2) { steps[1] = left / 2; left %= 2; }
-  steps[2] = left;
+    tmax = g_tuning.jacobi_fuse == 2 ? 2 : 5;
+  steps[0] = steps[1] = steps[2] = 0;
+  steps[3] = n_iters;
+  if (tmax == 2) { steps[2] = n_iters / 2; steps[3] = n_iters % 2; return; }
+  if (tmax < 5) return;
+  int best = 1 << 30;
+  for (int a = n_iters / 5; a >= 0 && a >= n_iters / 5 - 3; --a) {
+    int rem = n_iters - 5 * a;
+    const int b = rem / 4; rem %= 4;
+    const int c = rem / 2; rem %= 2;
+    const int cost = 2 * (a + b + c + rem) + rem;          // passes first, then single sweeps
+    if (cost < best) { best = cost; steps[0] = a; steps[1] = b; steps[2] = c; steps[3] = rem; }
+  }
 }
 
-int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_4_2_1_host) {
-  if (!A || n_iters < 0 || !launches_4_2_1_host || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
-  jacobi_schedule(A, dtype, true, n_iters, launches_4_2_1_host);
+int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_5_4_2_1_host) {
+  if (!A || n_iters < 0 || !launches_5_4_2_1_host || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  jacobi_schedule(A, dtype, true, n_iters, launches_5_4_2_1_host);
   return GLA_OK;
 }
 
 int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
                      int sweeps, int part, gla_stream_t stream) {
-  if (!A || !diag || !B || !X || !Xout || X == Xout || (sweeps != 2 && sweeps != 4) || part < 0 || part > 2 ||
+  if (!A || !diag || !B || !X || !Xout || X == Xout || (sweeps != 2 && sweeps != 4 && sweeps != 5) || part < 0 || part > 2 ||
       (dtype != GLA_F32 && dtype != GLA_F64))
     return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
@@ -1394,9 +1402,11 @@ int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, co
   if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A))) return GLA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == GLA_F64) {
+    if (sweeps == 5) return launch_jacobi_fused<double, 5>(A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st, part);
     if (sweeps == 4) return launch_jacobi_fused<double, 4>(A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st, part);
     return launch_jacobi_fused<double, 2>(A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st, part);
   }
+  if (sweeps == 5) return launch_jacobi_fused<float, 5>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
   if (sweeps == 4) return launch_jacobi_fused<float, 4>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
   return launch_jacobi_fused<float, 2>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
 }
@@ -1408,28 +1418,20 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
   if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
   if (n_iters == 0) return GLA_OK;
   if (!Xout || (n_iters > 1 && !Xtmp) || Xout == Xtmp) return GLA_ERR_INVALID_ARG;
-  // 2-D stencil plans, single right-hand side, contiguous vectors: the sweeps are taken 4 (then 2) at a time by the
-  // temporally blocked kernel (the intermediate iterates stay on chip); what is left over runs as ordinary sweeps.
-  // Same arithmetic per row: bit-identical.  Option "jacobi_fuse": 0 off, 1 (default) up to 4, 2 up to 2 per pass.
-  int steps[3];                                    // launches of 4, 2 and 1 sweeps
+  // 2-D stencil plans, single right-hand side, contiguous vectors: the sweeps are taken 5, 4 or 2 at a time by the
+  // temporally blocked kernel (the intermediate iterates stay on chip); what is left over runs as an ordinary sweep.
+  // Same arithmetic per row: bit-identical.  Option "jacobi_fuse": 0 off, 1 (default) up to 5, 2 up to 2 per pass.
+  int steps[4];                                    // launches of 5, 4, 2 and 1 sweeps
   jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && diag && B && X0, n_iters, steps);
-  const int n_launch = steps[0] + steps[1] + steps[2];
+  const int n_launch = steps[0] + steps[1] + steps[2] + steps[3];
   const void* src = X0;
   int64_t lds_ = ldx0;
   for (int i = 1; i <= n_launch; ++i) {
     void* dst = ((n_launch - i) % 2 == 0) ? Xout : Xtmp;
-    const int ts = i <= steps[0] ? 4 : (i <= steps[0] + steps[1] ? 2 : 1);
+    const int ts = i <= steps[0] ? 5 : (i <= steps[0] + steps[1] ? 4 : (i <= steps[0] + steps[1] + steps[2] ? 2 : 1));
     int rc;
-    if (ts > 1 && src == dst) return GLA_ERR_INVALID_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (ts == 4 && dtype == GLA_F64)
-      rc = launch_jacobi_fused<double, 4>(A, (const double*)diag, (const double*)B, (const double*)src, (double*)dst, (double)w, st);
-    else if (ts == 4)
-      rc = launch_jacobi_fused<float, 4>(A, (const float*)diag, (const float*)B, (const float*)src, (float*)dst, (float)w, st);
-    else if (ts == 2 && dtype == GLA_F64)
-      rc = launch_jacobi_fused<double, 2>(A, (const double*)diag, (const double*)B, (const double*)src, (double*)dst, (double)w, st);
-    else if (ts == 2)
-      rc = launch_jacobi_fused<float, 2>(A, (const float*)diag, (const float*)B, (const float*)src, (float*)dst, (float)w, st);
+    if (ts > 1)
+      rc = gla_jacobi_fused(A, dtype, diag, B, src, dst, w, ts, 0, stream);
     else
       rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, src, lds_, dst, ldw, w, 0, stream);
     if (rc) return rc;

@@ -286,13 +286,13 @@ class RowBlockJacobi(RowBlockOps):
 
     Two routes.  (1) One halo exchange per sweep (north_star's wording): interior / boundary tiles of the block's own
     plan.  (2) `temporal=True` (default) on 2-D stencil blocks with one right-hand side: the temporally blocked kernel
-    of the single-GPU path (4, then 2 sweeps per pass over the data) on the block EXTENDED by ghost lines, with ONE
-    exchange per pass -- the 4 (2) grid lines either side that the pass depends on -- instead of one per sweep
+    of the single-GPU path (5, 4 or 2 sweeps per pass over the data) on the block EXTENDED by ghost lines, with ONE
+    exchange per pass -- the 5 grid lines either side that a pass can depend on -- instead of one per sweep
     (communication-avoiding; the ghost lines are recomputed redundantly, exactly like the overlap between the line
     blocks of one GPU).  The ghost rows of the matrix are fetched once at construction, those of b and A_ii once per
     forward().  Same per-row arithmetic: bit-identical to route (1) and to the single-GPU module."""
 
-    TS_MAX = 4
+    TS_MAX = 5
     ext = None                                               # set by _setup_temporal when the route applies
 
     def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None,
@@ -302,7 +302,7 @@ class RowBlockJacobi(RowBlockOps):
         if temporal and col_blocks is None and self.part.world > 1 and edgeij_pair.is_cuda:
             self._setup_temporal(edgeij_pair, edge_attr)
         if self.ext is not None:
-            self.mode = ("temporally blocked: one ghost-line exchange per 4 (2) sweeps, "
+            self.mode = ("temporally blocked: one ghost-line exchange per pass of 5 (4, 2) sweeps, "
                          + ("libgla_hip RCCL all-gather on a side stream, interior / boundary line blocks overlapped"
                             if self.comm is not None else "torch.distributed all-gather (host-ordered)"))
 
@@ -340,6 +340,7 @@ class RowBlockJacobi(RowBlockOps):
             plan = CsrPlan(all_ei - elo, ehi - elo, ehi - elo)
             plan.set_values(all_ev)
             good = int(plan.jacobi_schedule(T, all_ev.dtype)[0] == 1 and int(plan.info.dia_stride) == S)
+            self._sched = plan.jacobi_schedule
         goods = [None] * p.world
         dist.all_gather_object(goods, good, group=p.group)
         if not all(goods):
@@ -410,9 +411,8 @@ class RowBlockJacobi(RowBlockOps):
         cur = torch.zeros(n_ext, dtype=dt, device=dev)
         nxt = torch.zeros(n_ext, dtype=dt, device=dev)
         cur[off:off + nl] = x0
-        left = int(n_iters)
-        while left > 0:
-            ts = 4 if left >= 4 else (2 if left >= 2 else 1)
+        n5, n4, n2, n1 = self._sched(int(n_iters), dt)       # the single-GPU path's launch plan (fewest passes)
+        for ts in [5] * n5 + [4] * n4 + [2] * n2 + [1] * n1:
             own = cur[off:off + nl]
             if ts == 1:                                      # one ordinary sweep of the extended block
                 self._fill_ghosts(cur, self._ghost_exchange(own))
@@ -426,7 +426,6 @@ class RowBlockJacobi(RowBlockOps):
                 self._fill_ghosts(cur, self._ghost_exchange(own))
                 check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 0, st))
             cur, nxt = nxt, cur
-            left -= ts
         self._ghost_pending = None
         return cur[off:off + nl].reshape(-1, 1).clone()
 

@@ -199,8 +199,8 @@ class CsrPlan:
         return Xout
 
     def jacobi_schedule(self, n_iters, dtype=torch.float64):
-        """(launches of 4 sweeps, of 2, of 1) gla_jacobi_sweeps uses for n_iters sweeps on one contiguous rhs."""
-        out = (ctypes.c_int * 3)()
+        """(launches of 5 sweeps, of 4, of 2, of 1) gla_jacobi_sweeps uses for n_iters sweeps on one contiguous rhs."""
+        out = (ctypes.c_int * 4)()
         check(lib().gla_jacobi_sweeps_schedule(self._h, dtype_code(dtype), int(n_iters), out))
         return tuple(out)
 

@@ -137,12 +137,13 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
                       const void* X0, int64_t ldx0, void* Xout, void* Xtmp, int64_t ldw, double w,
                       int n_iters, gla_stream_t stream);
 /* On 2-D stencil plans (diagonal layout whose offsets read as a * S + b on a grid of line length S) with one
- * contiguous right-hand side, gla_jacobi_sweeps takes the sweeps 4 (then 2) at a time in ONE pass over the data
+ * contiguous right-hand side, gla_jacobi_sweeps takes the sweeps 5, 4 or 2 at a time in ONE pass over the data
  * (temporal blocking: the intermediate iterates stay in LDS; same arithmetic per row, bit-identical results; option
  * "jacobi_fuse": 0 off, 1 default, 2 at most two per pass; "jacobi_lines": grid lines per workgroup, 0 = automatic).
- * This reports the launches it will use for n_iters sweeps: out[0] of four sweeps, out[1] of two, out[2] of one. */
-int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_4_2_1_host);
-/* ONE temporally blocked launch: Xout = `sweeps` (2 or 4) Jacobi sweeps of X (contiguous vectors, K = 1).
+ * This reports the launches it will use for n_iters sweeps: out[0] of five sweeps, out[1] of four, out[2] of two,
+ * out[3] of one (the fewest passes; 20 = 4 x 5, 6 = 4 + 2). */
+int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_5_4_2_1_host);
+/* ONE temporally blocked launch: Xout = `sweeps` (2, 4 or 5) Jacobi sweeps of X (contiguous vectors, K = 1).
  * part: 0 = every block of grid lines; 1 = the blocks that touch neither the first nor the last block of lines
  * (they read no x from the first / last `sweeps` grid lines: multi-GPU, while the ghost lines are in flight);
  * 2 = the first and the last block.  GLA_ERR_UNSUPPORTED when the plan has no 2-D stencil reading. */

@@ -55,11 +55,11 @@ def _worker(rank, world, port, overlap, q):
         x1_ref = gla.JacobiGNN.JacobiGNN()(6, torch.stack([diag[:, 0], B[:, 0], X[:, 0]], 1), ei, ea, g)
         x1_loc = jac.forward(6, torch.stack([diag[lo:hi, 0], B[lo:hi, 0], X[lo:hi, 0]], 1), g)
         assert torch.equal(x1_loc, x1_ref[lo:hi]), "jacobi K=1"
-        # route: blocks of >= 4 grid lines take the temporally blocked route (one ghost-line exchange per 4 / 2 sweeps);
+        # route: blocks of >= 5 grid lines take the temporally blocked route (one ghost-line exchange per 5 / 4 / 2 sweeps);
         # the world-4 partition has a one-line block, which sends every rank to the exchange-per-sweep route
         assert (jac.ext is not None) == (world == 2), (world, jac.ext is None)
         va1, va1_loc = torch.stack([diag[:, 0], B[:, 0], X[:, 0]], 1), torch.stack([diag[lo:hi, 0], B[lo:hi, 0], X[lo:hi, 0]], 1)
-        for its in (1, 2, 4, 7):                               # 1, 2, 4 and 4 + 2 + 1 sweeps
+        for its in (1, 2, 4, 5, 7, 11):                        # 1, 2, 4, 5, 5 + 2 and 5 + 4 + 2 sweeps
             assert torch.equal(jac.forward(its, va1_loc, g), gla.JacobiGNN.JacobiGNN()(its, va1, ei, ea, g)[lo:hi]), its
         jac_ps = RowBlockJacobi(ei_l, ev_l, n, lo, hi, overlap=overlap, temporal=False)      # exchange per sweep
         assert jac_ps.ext is None and torch.equal(jac_ps.forward(6, va1_loc, g), x1_ref[lo:hi]), "jacobi per-sweep route"
@@ -384,7 +384,7 @@ def test_jacobi_fused_parts_and_library_all_gather():
     x = torch.rand(n, generator=gen, dtype=torch.float64).to(dev)
     diag = torch.full((n,), -4.0, dtype=torch.float64, device=dev)
     st, code = stream_ptr(dev), dtype_code(torch.float64)
-    for ts in (4, 2):
+    for ts in (5, 4, 2):
         try:
             check(lib().gla_set_option(b"jacobi_fuse", 0))
             want = plan.jacobi_sweeps(diag, b.reshape(-1, 1), x.reshape(-1, 1), 0.7, ts).reshape(-1)

@@ -1047,9 +1047,9 @@ def test_dia_layout_bit_identical():
 
 
 def test_jacobi_temporal_blocking_bit_identical():
-    """gla_jacobi_sweeps on 2-D stencil plans takes the sweeps four (then two) at a time (temporal blocking: the
+    """gla_jacobi_sweeps on 2-D stencil plans takes the sweeps five, four or two at a time (temporal blocking: the
     intermediate iterates stay in LDS, the matrix is read once per pass).  Same per-row arithmetic: bit-identical to
-    single sweeps for every sweep count (4 + 2 + 1 combinations), block height, 5- and 9-point stencils, grids that are
+    single sweeps for every sweep count (5 / 4 / 2 / 1 combinations), block height, 5- and 9-point stencils, grids that are
     not multiples of the strip width or narrower than a strip, fp64 and fp32."""
     from gnn_applied_linear_algebra_amd._lib import lib, check
     cases = []
@@ -1073,7 +1073,7 @@ def test_jacobi_temporal_blocking_bit_identical():
             b = d(torch.rand(n, 1, generator=g2, dtype=torch.float64).to(dtype))
             x = d(torch.rand(n, 1, generator=g2, dtype=torch.float64).to(dtype))
             diag = d((torch.rand(n, generator=g2, dtype=torch.float64) + 3.0).to(dtype))
-            for its in (1, 2, 3, 6, 7, 20):
+            for its in (1, 2, 3, 5, 6, 7, 13, 20):
                 try:
                     check(lib().gla_set_option(b"jacobi_fuse", 0))
                     want = plan.jacobi_sweeps(diag, b, x, 0.7, its)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B: gla_jacobi_sweeps with one sweep per pass (spmv_dia_kernel) vs two / four sweeps per pass
+"""A/B: gla_jacobi_sweeps with one sweep per pass (spmv_dia_kernel) vs two / five sweeps per pass
 (jacobi_fused_dia2d_kernel, temporal blocking), same process, interleaved.
 Usage: python tools/ab_jacobi_fuse.py [N=4096] [lines,lines,...] [fem]"""
 import os
@@ -28,7 +28,7 @@ x = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
 diag = torch.full((n,), -4.0 if not fem else 8.0 / 3.0, dtype=torch.float64, device=dev)
 B_J = 12 * nnz + 4 * (n + 1) + 32 * n
 SW = 20
-variants = [("single", 0, 0)] + [(f"x2 L={L}", 2, L) for L in lines_list] + [(f"x4 L={L}", 1, L) for L in lines_list]
+variants = [("single", 0, 0)] + [(f"x2 L={L}", 2, L) for L in lines_list] + [(f"x5 L={L}", 1, L) for L in lines_list]
 res, outs = {}, {}
 for rnd in range(7):
     for name, fuse, L in variants:
