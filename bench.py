@@ -259,24 +259,27 @@ def single_gpu(args, gla, dev):
 
     plan = gla.plan_for(pr.ei, pr.n_local, edge_attr=pr.edge_attr)
     # HIP events around the sweep launches INSIDE the timed steps (recorded on the launch stream = torch's current
-    # stream): the module calls plan.jacobi_sweeps, which is wrapped on this plan instance
+    # stream): the module calls plan.jacobi_sweeps_aos / plan.jacobi_sweeps, which are wrapped on this plan instance
     sweep_events = []
-    _sweeps = plan.jacobi_sweeps
+    _sweeps, _sweeps_aos = plan.jacobi_sweeps, plan.jacobi_sweeps_aos
 
-    def _timed_sweeps(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = _sweeps(*a, **k)
-        e1.record()
-        sweep_events.append((e0, e1))
-        return out
-    plan.jacobi_sweeps = _timed_sweeps
+    def _timed(fn):
+        def wrapped(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            if out is not None:                               # (the AoS entry returns None when it does not apply)
+                sweep_events.append((e0, e1))
+            return out
+        return wrapped
+    plan.jacobi_sweeps, plan.jacobi_sweeps_aos = _timed(_sweeps), _timed(_sweeps_aos)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     del sweep_events[:]                                      # keep only the events of the timed steps
     elapsed, step_ms = timed_steps(step, args.steps, 0)
-    plan.jacobi_sweeps = _sweeps
+    plan.jacobi_sweeps, plan.jacobi_sweeps_aos = _sweeps, _sweeps_aos
     total_sweeps = args.steps * args.sweeps
     # launches behind one step: on 2-D stencil plans gla_jacobi_sweeps takes the sweeps 5, 4 or 2 at a time in one
     # pass over the data (temporal blocking); the dominant kernel is the one that covers most sweeps

@@ -72,6 +72,17 @@ class JacobiGNN(torch.nn.Module):
 
     def forward(self, n_iters, vertex_attr, edgeij_pair, edge_attr, g, batch=None):
         """n_iters sweeps -> x [n,1] (or [n,1,K] for the multi-RHS extension vertex_attr [n,3,K])."""
+        if vertex_attr.dim() == 2 and int(n_iters) >= 2:
+            # AoS fast path: the first temporally blocked pass reads [A_ii, b, x] rows itself (no separate column split)
+            dev = compute_device(vertex_attr, edgeij_pair, edge_attr)
+            va, ei, ea = to_dev(vertex_attr, dev), to_dev(edgeij_pair, dev), to_dev(edge_attr, dev)
+            float_dtype(va)
+            if va.shape[1] != 3:
+                raise ValueError("vertex_attr must be [n, 3] = [A_ii, b, x]")
+            plan = plan_for(ei, va.shape[0], edge_attr=ea)
+            x = plan.jacobi_sweeps_aos(va, float(g.reshape(-1)[0]), int(n_iters))
+            if x is not None:
+                return back(x, vertex_attr)
         plan, va, ea, diag, b, x, w = _prep(vertex_attr, edgeij_pair, edge_attr, g)
         x = plan.jacobi_sweeps(diag, b, x, w, int(n_iters))
         return back(x if va.dim() == 2 else x.unsqueeze(1), vertex_attr)

@@ -995,12 +995,18 @@ struct DiaCoef {                                  // one row's matrix data
   int m;                                          // diagonal mask | live bit 16
 };
 
-template <typename T, int DMAX, int TS>
+// AOS = true (first pass of gla_jacobi_sweeps_aos): A_ii, b and x^(k) are columns 0, 1, 2 of the reference's row-major
+// vertex attribute tensor (`x` points at it, leading dimension ldva; JacobiGNN.py:104-106); the lane that owns a row also
+// leaves contiguous copies of its A_ii and b in diag_out / b_out for the later passes -- the AoS split costs 16 B per row
+// of extra writes inside this pass instead of a separate 48 B per row pass.
+template <typename T, int DMAX, int TS, bool AOS = false>
 __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv, const T* __restrict__ diag,
                                                                        const T* __restrict__ bvec,
                                                                        const T* __restrict__ x, T* __restrict__ xo, T w,
                                                                        int lines, int nstrips, int64_t nlines, TileMap tm,
-                                                                       int tile_base0, int tile_split, int tile_base1) {
+                                                                       int tile_base0, int tile_split, int tile_base1,
+                                                                       int64_t ldva = 1, T* __restrict__ diag_out = nullptr,
+                                                                       T* __restrict__ b_out = nullptr) {
   constexpr int BW = GLA_BLOCK;                   // window width = lanes
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* ring = reinterpret_cast<T*>(smem_raw);       // [TS][4][BW]: ring t holds four lines of x^(k+t)
@@ -1021,7 +1027,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
   auto x0_at = [&](int jl) -> T {                 // x^(k) at line J0 + jl, this lane's point (clamped: never used dead)
     int64_t flat = (J0 + jl) * dv.S + P0 + tid;
     flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
-    return x[flat];
+    if constexpr (AOS) return x[flat * ldva + 2];
+    else return x[flat];
   };
   auto coef_at = [&](int jl) -> DiaCoef<T, DMAX> {   // row (line J0 + jl, this lane's point); dead rows: mask 0
     const int64_t gj = J0 + jl, gi = P0 + tid, r = gj * dv.S + gi;
@@ -1030,8 +1037,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
     DiaCoef<T, DMAX> c;
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) c.v[d] = val[(int64_t)min(d, dv.D - 1) * dv.n_rows + rc];
-    c.b = bvec[rc];
-    c.dg = diag[rc];
+    if constexpr (AOS) { c.dg = x[rc * ldva]; c.b = x[rc * ldva + 1]; }
+    else { c.b = bvec[rc]; c.dg = diag[rc]; }
     c.m = live ? ((int)dv.mask[rc] | 0x10000) : 0;
     return c;
   };
@@ -1064,6 +1071,13 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
     ring[((jl + 1 + 8) & 3) * BW + tid] = xpre;
     if (jl + 2 <= j_last + 1) xpre = x0_at(jl + 2);                // prefetch for the next step
     if (jl + 1 <= j_last) nxt = coef_at(jl + 1);
+    if constexpr (AOS) {                           // the row's owner leaves contiguous copies of A_ii and b (c[0]: line jl)
+      if (jl >= 0 && jl < L && (c[0].m & 0x10000) && tid >= halo && tid < BW - halo) {
+        const int64_t r = (J0 + jl) * dv.S + P0 + tid;
+        diag_out[r] = c[0].dg;
+        b_out[r] = c[0].b;
+      }
+    }
 #pragma unroll
     for (int t = 1; t <= TS; ++t) {
       __syncthreads();
@@ -1088,7 +1102,8 @@ bool jacobi_fused_ok(const gla_csr* A) {
 }
 
 template <typename T, int TS>
-int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0) {
+int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
+                        int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr) {
   Dia2D dv;
   dv.val = A->dia_val;
   dv.mask = A->dia_mask;
@@ -1129,7 +1144,14 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   set_tile_mapping(tm);
   const size_t lds = (size_t)TS * 4 * GLA_BLOCK * sizeof(T);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
-  if (A->dia_D <= 5)
+  if (ldva > 0) {                                   // x = the AoS vertex attributes (first pass of gla_jacobi_sweeps_aos)
+    if (A->dia_D <= 5)
+      hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS, true>), grid, block, lds, st, dv, diag, b, x, xo, w, lines,
+                         nstrips, nlines, tm, base0, split, base1, ldva, diag_out, b_out);
+    else
+      hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 9, TS, true>), grid, block, lds, st, dv, diag, b, x, xo, w, lines,
+                         nstrips, nlines, tm, base0, split, base1, ldva, diag_out, b_out);
+  } else if (A->dia_D <= 5)
     hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips,
                        nlines, tm, base0, split, base1);
   else
@@ -1322,6 +1344,30 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   return GLA_OK;
 }
 
+template <typename T>
+int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T* Xout, T* Xtmp, T w,
+                             const int steps[4], hipStream_t st) {
+  const int n_launch = steps[0] + steps[1] + steps[2] + steps[3];
+  const T* src = va;
+  for (int i = 1; i <= n_launch; ++i) {
+    T* dst = ((n_launch - i) % 2 == 0) ? Xout : Xtmp;
+    const int ts = i <= steps[0] ? 5 : (i <= steps[0] + steps[1] ? 4 : (i <= steps[0] + steps[1] + steps[2] ? 2 : 1));
+    int rc;
+    if (i == 1) {                                   // reads the AoS rows, writes the contiguous A_ii / b copies
+      if (ts == 5) rc = launch_jacobi_fused<T, 5>(A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
+      else if (ts == 4) rc = launch_jacobi_fused<T, 4>(A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
+      else rc = launch_jacobi_fused<T, 2>(A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
+    } else if (ts > 1) {
+      rc = gla_jacobi_fused(A, sizeof(T) == 8 ? GLA_F64 : GLA_F32, dwork, bwork, src, dst, (double)w, ts, 0, st);
+    } else {
+      rc = gla_jacobi_sweep(A, sizeof(T) == 8 ? GLA_F64 : GLA_F32, 1, dwork, bwork, 1, src, 1, dst, 1, (double)w, 0, st);
+    }
+    if (rc) return rc;
+    src = dst;
+  }
+  return GLA_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1409,6 +1455,24 @@ int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, co
   if (sweeps == 5) return launch_jacobi_fused<float, 5>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
   if (sweeps == 4) return launch_jacobi_fused<float, 4>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
   return launch_jacobi_fused<float, 2>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
+}
+
+int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, void* diag_work, void* b_work,
+                          void* Xout, void* Xtmp, double w, int n_iters, gla_stream_t stream) {
+  if (!A || !vertex_attr || ld < 3 || !diag_work || !b_work || !Xout || n_iters < 1 || Xout == Xtmp ||
+      (dtype != GLA_F32 && dtype != GLA_F64) || A->n_rows != A->n_cols)
+    return GLA_ERR_INVALID_ARG;
+  if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
+  if (A->n_rows == 0) return GLA_OK;
+  int steps[4];
+  jacobi_schedule(A, dtype, true, n_iters, steps);
+  if (steps[0] + steps[1] + steps[2] == 0) return GLA_ERR_UNSUPPORTED;      // no fused first pass: split and call gla_jacobi_sweeps
+  if (steps[0] + steps[1] + steps[2] + steps[3] > 1 && !Xtmp) return GLA_ERR_INVALID_ARG;
+  if (dtype == GLA_F64)
+    return jacobi_sweeps_aos<double>(A, (const double*)vertex_attr, ld, (double*)diag_work, (double*)b_work, (double*)Xout,
+                                     (double*)Xtmp, (double)w, steps, (hipStream_t)stream);
+  return jacobi_sweeps_aos<float>(A, (const float*)vertex_attr, ld, (float*)diag_work, (float*)b_work, (float*)Xout,
+                                  (float*)Xtmp, (float)w, steps, (hipStream_t)stream);
 }
 
 int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X0,

@@ -198,6 +198,25 @@ class CsrPlan:
                                       ptr(Xout), ptr(Xtmp), K, float(w), int(n_iters), stream_ptr(self.device)))
         return Xout
 
+    @_on_device
+    def jacobi_sweeps_aos(self, vertex_attr, w, n_iters):
+        """JacobiGNN.forward from the AoS tensor vertex_attr [n, 3] = [A_ii, b, x] without a separate column split;
+        returns x after n_iters sweeps as [n, 1], or None when the plan / count has no fused first pass (the caller
+        splits the columns and uses jacobi_sweeps)."""
+        va = vertex_attr
+        assert self.n_rows == self.n_cols and va.dim() == 2 and va.shape == (self.n_rows, 3) and va.is_cuda
+        if va.stride(1) != 1 or self.n_rows == 0 or int(n_iters) < 2:
+            return None
+        self._need(va.dtype)
+        if sum(self.jacobi_schedule(n_iters, va.dtype)[:3]) == 0:
+            return None
+        Xout = torch.empty((self.n_rows, 1), dtype=va.dtype, device=self.device)
+        Xtmp = torch.empty_like(Xout)
+        dwork, bwork = torch.empty_like(Xout), torch.empty_like(Xout)
+        check(lib().gla_jacobi_sweeps_aos(self._h, dtype_code(va.dtype), ptr(va), va.stride(0), ptr(dwork), ptr(bwork),
+                                          ptr(Xout), ptr(Xtmp), float(w), int(n_iters), stream_ptr(self.device)))
+        return Xout
+
     def jacobi_schedule(self, n_iters, dtype=torch.float64):
         """(launches of 5 sweeps, of 4, of 2, of 1) gla_jacobi_sweeps uses for n_iters sweeps on one contiguous rhs."""
         out = (ctypes.c_int * 4)()

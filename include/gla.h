@@ -136,6 +136,15 @@ int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void
 int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb,
                       const void* X0, int64_t ldx0, void* Xout, void* Xtmp, int64_t ldw, double w,
                       int n_iters, gla_stream_t stream);
+/* JacobiGNN.forward straight from the reference's vertex attribute tensor: vertex_attr [n, 3] row-major = [A_ii, b, x]
+ * (leading dimension ld >= 3; JacobiGNN.py:104-106,138-148).  Same result as splitting the columns and calling
+ * gla_jacobi_sweeps, but the first temporally blocked pass reads the AoS rows itself and leaves contiguous copies of
+ * A_ii and b in diag_work / b_work [n] for the later passes (16 B per row of extra writes instead of a 48 B per row
+ * split pass).  The iterate after n_iters sweeps lands in Xout; Xtmp as in gla_jacobi_sweeps.  Returns
+ * GLA_ERR_UNSUPPORTED when the first launch of the schedule would not be a fused pass (plan without a 2-D stencil
+ * reading, n_iters = 1, option jacobi_fuse = 0): split and use gla_jacobi_sweeps then. */
+int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, void* diag_work, void* b_work,
+                          void* Xout, void* Xtmp, double w, int n_iters, gla_stream_t stream);
 /* On 2-D stencil plans (diagonal layout whose offsets read as a * S + b on a grid of line length S) with one
  * contiguous right-hand side, gla_jacobi_sweeps takes the sweeps 5, 4 or 2 at a time in ONE pass over the data
  * (temporal blocking: the intermediate iterates stay in LDS; same arithmetic per row, bit-identical results; option

@@ -1088,6 +1088,15 @@ def test_jacobi_temporal_blocking_bit_identical():
                         check(lib().gla_set_option(b"jacobi_fuse", 1))
                         check(lib().gla_set_option(b"jacobi_lines", 0))
                     assert torch.equal(got, want), (name, dtype, its, fuse, lines, float((got - want).abs().max()))
+                # the AoS entry point (first pass reads [A_ii, b, x] rows itself): packed rows and rows of a wider tensor
+                va = torch.stack([diag, b.reshape(-1), x.reshape(-1)], 1)
+                wide = torch.zeros(n, 5, dtype=dtype, device=DEV)
+                wide[:, 1:4] = va
+                for vattr in (va, wide[:, 1:4]):
+                    got = plan.jacobi_sweeps_aos(vattr, 0.7, its)
+                    assert (got is None) == (its < 2), its
+                    if got is not None:
+                        assert torch.equal(got, want), (name, dtype, its, "aos", vattr.stride())
 
 
 def test_col16_columns_bit_identical():
