@@ -43,8 +43,8 @@ HBM_PEAK = 8e12          # B/s, MI355X_MICROARCH.md
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid lines per rank and vertices per line")
     ap.add_argument("--sweeps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -10,11 +10,11 @@ no CPU fallback.
 """
 from . import _lib  # noqa: F401
 from .meta import MetaLayer  # noqa: F401
-from .plan import CsrPlan, plan_for, col_dot, col_scale_rsqrt  # noqa: F401
+from .plan import CsrPlan, plan_for, col_dot, col_scale_rsqrt, invalidate  # noqa: F401
 from . import sparse_ops  # noqa: F401
 from . import autograd  # noqa: F401
 from . import (UtilsGNN, MatVecGNN, GNNResidual, JacobiGNN, ChebyGNN, PowerMethodGNN, SOCClassicGNN,  # noqa: F401
                DirectInterpGNN, SOCSAGNN, MatrixWeightedNorm, VCycle, TrainableJacobiDiag)
 
-__all__ = ["MetaLayer", "CsrPlan", "plan_for", "UtilsGNN", "MatVecGNN", "GNNResidual", "JacobiGNN", "ChebyGNN",
+__all__ = ["MetaLayer", "CsrPlan", "plan_for", "invalidate", "UtilsGNN", "MatVecGNN", "GNNResidual", "JacobiGNN", "ChebyGNN",
            "PowerMethodGNN", "SOCClassicGNN", "DirectInterpGNN", "SOCSAGNN", "MatrixWeightedNorm", "VCycle", "TrainableJacobiDiag", "autograd"]

@@ -122,6 +122,7 @@ class CsrPlan:
             self.set_values(edge_attr)
             self._val_key = key
             self._val_ref = weakref.ref(edge_attr)
+            _PLANS_WITH_VALUES.add(weakref.ref(self))
 
     @_on_device
     def arrays(self):
@@ -404,6 +405,32 @@ def col_scale_rsqrt(X, sumsq, out=None):
         check(lib().gla_col_scale_rsqrt(dtype_code(X.dtype), n, K, ptr(X), ldx, ptr(sumsq), ptr(Y2), ldy,
                                         stream_ptr(X.device)))
     return Y
+
+
+def invalidate(*tensors):
+    """Drop everything this package cached ON the given tensors: the CSR plan of an `edgeij_pair`, the CSR-ordered copy
+    of an `edge_attr`'s values (the plan re-gathers them on the next call), the GPU copy of a CPU operand.  The caches
+    are keyed on tensor identity plus torch's in-place version counter, which does NOT see writes made through a raw
+    pointer, a NumPy view sharing the memory, or `.data`: after such a write call this (or pass a fresh tensor)."""
+    for t in tensors:
+        cached_copy = getattr(t, "_gla_dev_copy", None)
+        if cached_copy is not None:
+            invalidate(cached_copy[1])
+        for attr in ("_gla_plan", "_gla_dev_copy", "_gla_gnn_input"):
+            if hasattr(t, attr):
+                try:
+                    delattr(t, attr)
+                except Exception:
+                    pass
+    for ref in list(_PLANS_WITH_VALUES):
+        plan = ref()
+        if plan is None:
+            _PLANS_WITH_VALUES.discard(ref)
+        elif plan._val_ref is not None and any(plan._val_ref() is t for t in tensors):
+            plan._val_key = plan._val_ref = None
+
+
+_PLANS_WITH_VALUES = set()
 
 
 # ---- plan cache ---------------------------------------------------------------------------------

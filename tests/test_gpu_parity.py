@@ -1099,6 +1099,28 @@ def test_jacobi_temporal_blocking_bit_identical():
                         assert torch.equal(got, want), (name, dtype, its, "aos", vattr.stride())
 
 
+def test_invalidate_after_untracked_write():
+    """Plans / values are cached on the caller's tensors keyed by identity + version counter; a write torch cannot see
+    (here: through NumPy-shared memory of a CPU operand, and through `.data` on a GPU one) needs gla.invalidate()."""
+    N = 12
+    ei, ev = rp.laplacianfun_torch(N)
+    n = N * N
+    x = torch.rand(n, 1, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    M = gla.MatVecGNN
+    gnn = gla.MetaLayer(M.EdgeUpdate(), M.VertexUpdate(M.edge_to_vertex_aggregation))
+    ev_np = ev.numpy()                                        # shares memory with ev (a CPU operand, copied to the GPU once)
+    y1 = gnn(x, ei, ev, None)[0][:, 1:]
+    ev_np *= 2.0                                              # untracked write: version counter unchanged
+    gla.invalidate(ev)
+    y2 = gnn(x, ei, ev, None)[0][:, 1:]
+    eq(y2, 2.0 * y1)
+    ev_d, ei_d, x_d = d(ev.clone()), d(ei), d(x)
+    y3 = gnn(x_d, ei_d, ev_d, None)[0][:, 1:]
+    ev_d.data.mul_(0.5)
+    gla.invalidate(ev_d)
+    eq(gnn(x_d, ei_d, ev_d, None)[0][:, 1:], 0.5 * y3)
+
+
 def test_col16_columns_bit_identical():
     """The default K = 1 kernels read int16 tile-relative columns (option "col16"); tiles with a far column keep
     int32.  Every fused op must give exactly the int32-column result, tile partition unchanged (also the partials)."""
