@@ -350,92 +350,105 @@ class RowBlockJacobi(RowBlockOps):
         self.ext = dict(plan=plan, S=S, elo=elo, ehi=ehi, n_ext=ehi - elo, off=lo - elo, up=up, down=down,
                         slab=T * S, dtype=all_ev.dtype, dev=dev)
 
-    def _ghost_exchange(self, own, K_unused=1, begin_only=False):
-        """All-gather of every rank's first and last TS_MAX grid lines of `own` ([n_local]); returns (upper, lower) ghost
-        slabs for this rank (None where there is no neighbour).  With the library communicator the gather runs on its
-        side stream: call with begin_only=True, launch work that needs no ghosts, then _ghost_finish()."""
+    def _ghost_exchange(self, owns, begin_only=False):
+        """ONE all-gather of every rank's first and last TS_MAX grid lines of each vector in `owns` ([n_local] each);
+        returns per vector the (upper, lower) ghost slabs for this rank (None where there is no neighbour).  With the
+        library communicator the gather runs on its side stream: call with begin_only=True, launch work that needs no
+        ghosts, then _ghost_finish()."""
         e, p = self.ext, self.part
-        m = e["slab"]
-        send = torch.cat([own[:m], own[-m:]])
-        recv = torch.empty(p.world * 2 * m, dtype=own.dtype, device=own.device)
+        m, nv = e["slab"], len(owns)
+        send = torch.cat([piece for own in owns for piece in (own[:m], own[-m:])])
+        recv = torch.empty(p.world * 2 * m * nv, dtype=send.dtype, device=send.device)
         if self.comm is not None:
             from ._lib import check, dtype_code, lib, ptr, stream_ptr
-            check(lib().gla_comm_all_gather_begin(self.comm._h, dtype_code(own.dtype), ptr(send), ptr(recv), 2 * m,
-                                                  stream_ptr(own.device)))
-            self._ghost_pending = (send, recv)              # keep the buffers alive until the gather has been waited for
-            if begin_only:
-                return None
-            return self._ghost_finish()
-        if own.is_cuda and dist.get_backend(p.group) == "gloo":        # rehearsal route: gloo moves host memory
-            recv_h = torch.empty(p.world * 2 * m, dtype=own.dtype)
-            dist.all_gather_into_tensor(recv_h, send.cpu(), group=p.group)
-            recv = recv_h.to(own.device)
+            check(lib().gla_comm_all_gather_begin(self.comm._h, dtype_code(send.dtype), ptr(send), ptr(recv),
+                                                  2 * m * nv, stream_ptr(send.device)))
+            self._ghost_pending = (send, recv, nv, True)    # keep the buffers alive until the gather has been waited for
         else:
-            dist.all_gather_into_tensor(recv, send, group=p.group)
-        self._ghost_pending = (send, recv)
-        return None if begin_only else self._ghost_finish(wait=False)
+            if send.is_cuda and dist.get_backend(p.group) == "gloo":   # rehearsal route: gloo moves host memory
+                recv_h = torch.empty(recv.numel(), dtype=send.dtype)
+                dist.all_gather_into_tensor(recv_h, send.cpu(), group=p.group)
+                recv = recv_h.to(send.device)
+            else:
+                dist.all_gather_into_tensor(recv, send, group=p.group)
+            self._ghost_pending = (send, recv, nv, False)
+        return None if begin_only else self._ghost_finish()
 
-    def _ghost_finish(self, wait=True):
+    def _ghost_finish(self):
         e, p = self.ext, self.part
         m = e["slab"]
-        send, recv = self._ghost_pending
-        if wait and self.comm is not None:
+        send, recv, nv, on_side_stream = self._ghost_pending
+        if on_side_stream:
             from ._lib import check, lib, stream_ptr
             check(lib().gla_halo_end(self.comm._h, stream_ptr(recv.device)))
-        upper = recv[(p.rank - 1) * 2 * m + m:(p.rank - 1) * 2 * m + 2 * m] if e["up"] else None      # neighbour's LAST lines
-        lower = recv[(p.rank + 1) * 2 * m:(p.rank + 1) * 2 * m + m] if e["down"] else None             # neighbour's FIRST lines
-        return upper, lower
+        chunk = 2 * m * nv                                   # a rank's chunk: per vector [first m | last m]
+        out = []
+        for v in range(nv):
+            up = recv[(p.rank - 1) * chunk + v * 2 * m + m:(p.rank - 1) * chunk + (v + 1) * 2 * m] if e["up"] else None
+            lo = recv[(p.rank + 1) * chunk + v * 2 * m:(p.rank + 1) * chunk + v * 2 * m + m] if e["down"] else None
+            out.append((up, lo))                             # the neighbour above's LAST lines / below's FIRST lines
+        return out
 
-    def _fill_ghosts(self, ext_vec, slabs):
+    def _fill_ghosts(self, ext_vecs, slabs):
         e = self.ext
-        upper, lower = slabs
-        if upper is not None:
-            ext_vec[:e["off"]] = upper
-        if lower is not None:
-            ext_vec[e["off"] + self.part.n_local:] = lower
+        for vec, (upper, lower) in zip(ext_vecs, slabs):
+            if upper is not None:
+                vec[:e["off"]] = upper
+            if lower is not None:
+                vec[e["off"] + self.part.n_local:] = lower
 
-    def _forward_temporal(self, n_iters, diag, b, x0, w):
+    def _forward_temporal(self, n_iters, va, w):
+        import ctypes
         from ._lib import check, dtype_code, lib, ptr, stream_ptr
         e, p = self.ext, self.part
         n_ext, off, nl = e["n_ext"], e["off"], p.n_local
-        dev, dt = x0.device, x0.dtype
+        dev, dt = va.device, va.dtype
         code, st, h = dtype_code(dt), stream_ptr(dev), e["plan"]._h
-
-        def extended(own, fill):
-            v = torch.full((n_ext,), fill, dtype=dt, device=dev)
-            v[off:off + nl] = own
-            self._fill_ghosts(v, self._ghost_exchange(own))
-            return v
-        d_ext = extended(diag, 1.0)                          # ghost rows of b and A_ii: once per forward
-        b_ext = extended(b, 0.0)
-        cur = torch.zeros(n_ext, dtype=dt, device=dev)
-        nxt = torch.zeros(n_ext, dtype=dt, device=dev)
-        cur[off:off + nl] = x0
+        buf = e.get("buffers")
+        if buf is None:                                      # persistent extended vectors: A_ii, b, two x buffers
+            buf = e["buffers"] = (torch.ones(n_ext, dtype=dt, device=dev), torch.zeros(n_ext, dtype=dt, device=dev),
+                                  torch.zeros(n_ext, dtype=dt, device=dev), torch.zeros(n_ext, dtype=dt, device=dev))
+        d_ext, b_ext, cur, nxt = buf
+        own = lambda v: v[off:off + nl]                      # noqa: E731
+        # the AoS rows [A_ii, b, x] of this rank go straight into the own part of the extended vectors (one pass)
+        outs = (ctypes.c_void_p * 3)(own(d_ext).data_ptr(), own(b_ext).data_ptr(), own(cur).data_ptr())
+        check(lib().gla_split_columns(code, nl, 3, ptr(va), va.stride(0) if nl > 1 else 3, outs, st))
+        first = True
         n5, n4, n2, n1 = self._sched(int(n_iters), dt)       # the single-GPU path's launch plan (fewest passes)
-        for ts in [5] * n5 + [4] * n4 + [2] * n2 + [1] * n1:
-            own = cur[off:off + nl]
+        passes = [5] * n5 + [4] * n4 + [2] * n2 + [1] * n1
+        spare = nxt
+        for i, ts in enumerate(passes):
+            if i == len(passes) - 1:                         # the last pass writes into a fresh buffer the caller keeps
+                nxt = torch.empty(n_ext, dtype=dt, device=dev)
+            # ghost lines of x every pass; those of A_ii and b ride along in the first exchange of the call
+            vecs = [d_ext, b_ext, cur] if first else [cur]
+            owns = [own(v) for v in vecs]
+            first = False
             if ts == 1:                                      # one ordinary sweep of the extended block
-                self._fill_ghosts(cur, self._ghost_exchange(own))
+                self._fill_ghosts(vecs, self._ghost_exchange(owns))
                 check(lib().gla_jacobi_sweep(h, code, 1, ptr(d_ext), ptr(b_ext), 1, ptr(cur), 1, ptr(nxt), 1, w, 0, st))
             elif self.comm is not None and self.overlap:
-                self._ghost_exchange(own, begin_only=True)   # ghost lines in flight on the side stream ...
+                self._ghost_exchange(owns, begin_only=True)  # ghost lines in flight on the side stream ...
                 check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, st))
-                self._fill_ghosts(cur, self._ghost_finish())  # ... while the interior line blocks run
+                self._fill_ghosts(vecs, self._ghost_finish())  # ... while the interior line blocks run
                 check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 2, st))
             else:
-                self._fill_ghosts(cur, self._ghost_exchange(own))
+                self._fill_ghosts(vecs, self._ghost_exchange(owns))
                 check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 0, st))
             cur, nxt = nxt, cur
+        # cur = the result (fresh buffer); the two persistent x buffers stay with the driver
+        e["buffers"] = (d_ext, b_ext, nxt, spare if len(passes) % 2 == 1 else buf[2])
         self._ghost_pending = None
-        return cur[off:off + nl].reshape(-1, 1).clone()
+        return own(cur).reshape(-1, 1)
 
     def forward(self, n_iters, vertex_attr, g):
         p = self.part
         va = vertex_attr
         K = 1 if va.dim() == 2 else va.shape[2]
         if self.ext is not None and K == 1 and va.dim() == 2 and va.dtype == self.ext["dtype"] and int(n_iters) > 0:
-            return self._forward_temporal(int(n_iters), va[:, 0].contiguous(), va[:, 1].contiguous(),
-                                          va[:, 2].contiguous(), float(g.reshape(-1)[0]))
+            if va.stride(1) != 1:
+                va = va.contiguous()
+            return self._forward_temporal(int(n_iters), va, float(g.reshape(-1)[0]))
         diag = (va[:, 0] if va.dim() == 2 else va[:, 0, 0]).contiguous()
         B = (va[:, 1].reshape(-1, 1) if va.dim() == 2 else va[:, 1, :]).contiguous()
         w = float(g.reshape(-1)[0])
