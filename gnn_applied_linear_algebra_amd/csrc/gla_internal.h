@@ -71,6 +71,8 @@ struct gla_tuning {
   int dia = 1;              // stencil matrices (<= 16 diagonals): K = 1 kernels use the diagonal layout
   int jacobi_fuse = 1;      // gla_jacobi_sweeps on 2-D stencil plans: 0 one sweep per pass, 1 up to four (temporal blocking), 2 up to two
   int jacobi_lines = 0;     // grid lines a workgroup of the fused kernel marches through (0 = one resident round of workgroups)
+  int64_t jacobi_min_rows = 1 << 20;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
+                                       // is faster: a 768^2 grid takes 9 us per sweep either way, a 512^2 grid 5 vs 9 us)
 };
 extern gla_tuning g_tuning;
 

@@ -1121,7 +1121,7 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     const int64_t slots = 256 * (sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5));
     const int64_t blocks = slots / nstrips > 0 ? slots / nstrips : 1;
     int64_t l = (nlines + blocks - 1) / blocks;
-    if (l < 8 * TS) l = 8 * TS;
+    if (l < 2 * TS) l = 2 * TS;                    // (also what the interior / boundary split of the multi-GPU route needs)
     if (l > 1024) l = 1024;
     lines = (int)l;
   }
@@ -1415,7 +1415,7 @@ int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void
 // the fewest passes over the data, and among those the fewest unfused single sweeps (6 = 4 + 2, not 5 + 1)
 static void jacobi_schedule(gla_csr* A, int dtype, bool contiguous_k1, int n_iters, int steps[4]) {
   int tmax = 1;
-  if (contiguous_k1 && n_iters >= 2 && A->n_rows > 0 && A->val_dtype == dtype &&
+  if (contiguous_k1 && n_iters >= 2 && A->n_rows > 0 && A->n_rows >= g_tuning.jacobi_min_rows && A->val_dtype == dtype &&
       (dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A)))
     tmax = g_tuning.jacobi_fuse == 2 ? 2 : 5;
   steps[0] = steps[1] = steps[2] = 0;

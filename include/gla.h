@@ -148,7 +148,8 @@ int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64
 /* On 2-D stencil plans (diagonal layout whose offsets read as a * S + b on a grid of line length S) with one
  * contiguous right-hand side, gla_jacobi_sweeps takes the sweeps 5, 4 or 2 at a time in ONE pass over the data
  * (temporal blocking: the intermediate iterates stay in LDS; same arithmetic per row, bit-identical results; option
- * "jacobi_fuse": 0 off, 1 default, 2 at most two per pass; "jacobi_lines": grid lines per workgroup, 0 = automatic).
+ * "jacobi_fuse": 0 off, 1 default, 2 at most two per pass; "jacobi_lines": grid lines per workgroup, 0 = automatic;
+ * "jacobi_min_rows": matrices with fewer rows, default 2^20, keep one sweep per launch, which is faster there).
  * This reports the launches it will use for n_iters sweeps: out[0] of five sweeps, out[1] of four, out[2] of two,
  * out[3] of one (the fewest passes; 20 = 4 x 5, 6 = 4 + 2). */
 int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_5_4_2_1_host);

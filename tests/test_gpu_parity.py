@@ -1099,6 +1099,24 @@ def test_jacobi_temporal_blocking_bit_identical():
                         assert torch.equal(got, want), (name, dtype, its, "aos", vattr.stride())
 
 
+def test_jacobi_fusion_size_threshold():
+    """Below option jacobi_min_rows (default 2^20 rows) gla_jacobi_sweeps keeps one sweep per launch (faster there)."""
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(300, device=DEV)
+    plan = gla.CsrPlan(ei, 90000)
+    plan.set_values(ev)
+    assert plan.jacobi_schedule(20) == (4, 0, 0, 0)               # the test session runs with jacobi_min_rows = 0
+    try:
+        check(lib().gla_set_option(b"jacobi_min_rows", 1 << 20))
+        assert plan.jacobi_schedule(20) == (0, 0, 0, 20)
+        ei2, ev2 = gla.UtilsGNN.laplacianfun_torch(1024, device=DEV)
+        plan2 = gla.CsrPlan(ei2, 1 << 20)
+        plan2.set_values(ev2)
+        assert plan2.jacobi_schedule(20) == (4, 0, 0, 0) and plan2.jacobi_schedule(6) == (0, 1, 1, 0)
+    finally:
+        check(lib().gla_set_option(b"jacobi_min_rows", 0))
+
+
 def test_invalidate_after_untracked_write():
     """Plans / values are cached on the caller's tensors keyed by identity + version counter; a write torch cannot see
     (here: through NumPy-shared memory of a CPU operand, and through `.data` on a GPU one) needs gla.invalidate()."""
