@@ -57,6 +57,8 @@ struct gla_csr {
   // 2-D reading of the diagonal set for the blocked K > 1 kernel: off[d] = dia_a[d] * dia_S + dia_b[d] with a grid-line
   // stride S and small |a| <= dia_A, |b| <= dia_B (5-point: S = N, a in {-1,0,1}, b in {-1,0,1}); dia_S = 0: none
   int32_t dia_S = 0, dia_A = 0, dia_B = 0;
+  int32_t dia_nowrap = 0;       // 1: no entry leaves its grid line in this reading ((r % S) + b stays in [0, S)): rows of a
+                                // line depend only on rows of the lines a = -A..A -- what the temporally blocked kernel needs
   int8_t dia_a[16] = {0}, dia_b[16] = {0};
   int64_t int_row_lo = -1, int_row_hi = -1; // rows of the interior tiles when they form one contiguous run
 };

@@ -416,6 +416,25 @@ DiaOffsets dia_offsets_of(const gla_csr* p) {
   return o;
 }
 
+// does any present entry (row r, diagonal d) leave its grid line under the reading off_d = a_d * S + b_d, i.e. is
+// (r % S) + b_d outside [0, S)?  (True 2-D grids never do: a vertex in the first / last column has no left / right
+// neighbour.  A reading with the wrong S -- the offsets -33, -32, -1, 0, 1, 32, 33 read with S = 32 as well as with the
+// grid's 33 -- does.)
+struct DiaB { int8_t b[GLA_DIA_MAX]; int32_t D; };
+__global__ __launch_bounds__(GLA_BLOCK) void dia_wrap_kernel(const uint16_t* __restrict__ mask, int64_t n_rows, int32_t S,
+                                                             DiaB db, int* __restrict__ wraps) {
+  int bad = 0;
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK) {
+    const unsigned m = mask[r];
+    if (m == 0xFFFFu) continue;                      // row outside the stencil range (halo rows of a row block)
+    const int gi = (int)(r % S);
+#pragma unroll
+    for (int d = 0; d < GLA_DIA_MAX; ++d)
+      if (d < db.D && ((m >> d) & 1u) && (gi + db.b[d] < 0 || gi + db.b[d] >= S)) bad = 1;
+  }
+  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(wraps, 1);
+}
+
 // Structure side, at plan creation: does every nonzero lie on one of <= 16 diagonals, rows in ascending order?
 int build_dia(gla_csr* p, hipStream_t st) {
   p->dia_state = -1;
@@ -456,11 +475,15 @@ int build_dia(gla_csr* p, hipStream_t st) {
     return GLA_OK;
   }
   p->dia_state = 1;
-  // 2-D reading of the offsets (blocked multi-rhs kernel): the line stride S is the far offset that splits every
-  // diagonal into a * S + b with the smallest max |b| (|a| <= 2, |b| <= 3)
+  // 2-D reading of the offsets: off = a * S + b with a line stride S among the far offsets, |a| <= 2, |b| <= 3.  Preferred:
+  // a reading in which no entry leaves its grid line (the temporally blocked Jacobi kernel needs that; the blocked
+  // multi-rhs kernel works with any reading), then the smallest max |b|.
   p->dia_S = 0;
+  p->dia_nowrap = 0;
   {
-    int best_b = 1 << 30;
+    int* d_wrap = nullptr;
+    DK(hipMalloc(&d_wrap, sizeof(int)));
+    int best_b = 1 << 30, best_nowrap = -1;
     for (int c = 0; c < D; ++c) {
       const int64_t S = p->dia_off[c];
       if (S <= 8) continue;
@@ -476,14 +499,28 @@ int build_dia(gla_csr* p, hipStream_t st) {
         maxa = std::max(maxa, (int)(a < 0 ? -a : a));
         maxb = std::max(maxb, (int)(b < 0 ? -b : b));
       }
-      if (ok && maxb < best_b) {
+      if (!ok) continue;
+      DiaB db;
+      db.D = D;
+      for (int i = 0; i < GLA_DIA_MAX; ++i) db.b[i] = i < D ? tb[i] : 0;
+      int h_wrap = 0;
+      DK(hipMemsetAsync(d_wrap, 0, sizeof(int), st));
+      hipLaunchKernelGGL(dia_wrap_kernel, dim3(grid_for(p->n_rows)), dim3(GLA_BLOCK), 0, st, p->dia_mask, p->n_rows, (int32_t)S,
+                         db, d_wrap);
+      DK(hipMemcpyAsync(&h_wrap, d_wrap, sizeof(int), hipMemcpyDeviceToHost, st));
+      DK(hipStreamSynchronize(st));
+      const int nowrap = h_wrap ? 0 : 1;
+      if (nowrap > best_nowrap || (nowrap == best_nowrap && maxb < best_b)) {
+        best_nowrap = nowrap;
         best_b = maxb;
         p->dia_S = (int32_t)S;
         p->dia_A = maxa;
         p->dia_B = maxb;
+        p->dia_nowrap = nowrap;
         for (int i = 0; i < D; ++i) { p->dia_a[i] = ta[i]; p->dia_b[i] = tb[i]; }
       }
     }
+    (void)hipFree(d_wrap);
   }
   return GLA_OK;
 #undef DK

@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
 template <typename T>
 bool jacobi_fused_ok(const gla_csr* A) {
   return g_tuning.jacobi_fuse && g_tuning.dia && g_tuning.spmv_variant == 0 && A->dia_state == 1 && A->dia_val &&
-         A->dia_S > 0 && A->dia_A == 1 && A->dia_B >= 1 && A->dia_B <= 2 && A->dia_D <= 9 && A->dia_row_lo == 0 &&
+         A->dia_S > 0 && A->dia_nowrap && A->dia_A == 1 && A->dia_B >= 1 && A->dia_B <= 2 && A->dia_D <= 9 && A->dia_row_lo == 0 &&
          A->dia_row_hi == A->n_rows && A->n_rows == A->n_cols && !(g_tuning.compress && (A->dia_const || A->packed));
 }
 

@@ -1099,6 +1099,77 @@ def test_jacobi_temporal_blocking_bit_identical():
                         assert torch.equal(got, want), (name, dtype, its, "aos", vattr.stride())
 
 
+def _stencil_matrix(Nx, Ny, offsets_ab, gen, holes=0.0):
+    """Row-sorted COO of a stencil on an Ny x Nx grid (vertex k = j*Nx + i): entry (k, k + a*Nx + b) for every (a, b)
+    whose neighbour exists; random values; a fraction `holes` of the off-diagonal entries removed at random."""
+    k = torch.arange(Nx * Ny)
+    i, j = k % Nx, k // Nx
+    rows, cols = [], []
+    for a, b in sorted(offsets_ab, key=lambda ab: ab[0] * Nx + ab[1]):
+        ok = (i + b >= 0) & (i + b < Nx) & (j + a >= 0) & (j + a < Ny)
+        if holes and (a, b) != (0, 0):
+            ok &= torch.rand(Nx * Ny, generator=gen) >= holes
+        rows.append(k[ok])
+        cols.append(k[ok] + a * Nx + b)
+    row, col = torch.cat(rows), torch.cat(cols)
+    order = torch.argsort(row * (Nx * Ny) + col)                 # row-major, ascending columns
+    ei = torch.stack([row[order], col[order]])
+    ev = torch.rand(ei.shape[1], 1, generator=gen, dtype=torch.float64) - 0.4
+    return ei, ev
+
+
+def test_generic_stencils_blocked_and_fused_kernels():
+    """The 2-D reading is generic (off = a*S + b, |a| <= 2, |b| <= 3): stencils other than the 5- / 9-point ones --
+    two points either side (B = 2), two lines either side (A = 2: blocked SpMM only, the fused Jacobi needs A = 1),
+    a 5-point pattern with 30 % of its entries missing, a skewed 7-point pattern -- against the CSR kernels (dia = 0),
+    bit for bit: K = 1 ops, fused Jacobi (1 .. 7 sweeps), K = 2 / 16 SpMM family."""
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+    gen = torch.Generator().manual_seed(33)
+    cases = [
+        ("B = 2: (0,+-2) added", 70, 45, [(-1, 0), (0, -2), (0, -1), (0, 0), (0, 1), (0, 2), (1, 0)], 0.0, (1, 2)),
+        ("A = 2: (+-2,0) added", 40, 60, [(-2, 0), (-1, 0), (0, -1), (0, 0), (0, 1), (1, 0), (2, 0)], 0.0, (2, 1)),
+        ("5-point with holes", 64, 50, [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)], 0.3, (1, 1)),
+        ("skewed 7-point", 33, 41, [(-1, 0), (-1, 1), (0, -1), (0, 0), (0, 1), (1, -1), (1, 0)], 0.0, (1, 1)),
+    ]
+    for name, Nx, Ny, offs, holes, (A_, B_) in cases:
+        ei, ev = _stencil_matrix(Nx, Ny, offs, gen, holes)
+        n = Nx * Ny
+        g2 = torch.Generator().manual_seed(n)
+        b1 = d(torch.rand(n, 1, generator=g2, dtype=torch.float64))
+        x1 = d(torch.rand(n, 1, generator=g2, dtype=torch.float64))
+        X = d(torch.rand(n, 16, generator=g2, dtype=torch.float64))
+        Bm = d(torch.rand(n, 16, generator=g2, dtype=torch.float64))
+        diag = d(torch.rand(n, generator=g2, dtype=torch.float64) + 2.0)
+
+        def run():
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev))
+            outs = [plan.spmm(x1), plan.residual(b1, x1)]
+            outs += [plan.jacobi_sweeps(diag, b1, x1, 0.7, its) for its in (1, 2, 5, 7)]
+            for K in (2, 16):
+                outs += [plan.spmm(X[:, :K].contiguous()), plan.jacobi_sweeps(diag, Bm[:, :K].contiguous(), X[:, :K].contiguous(), 0.7, 2)]
+                r, p, xo, p2 = (torch.empty(n, K, dtype=torch.float64, device=DEV) for _ in range(4))
+                plan.cheby_first(Bm[:, :K].contiguous(), X[:, :K].contiguous(), r, p, xo, -0.25)
+                plan.cheby_next(p, p2, r, xo, -0.25, -0.26, 0.1)
+                outs += [r, p2, xo]
+            return plan, outs
+
+        try:
+            check(lib().gla_set_option(b"dia", 0))
+            _, want = run()
+        finally:
+            check(lib().gla_set_option(b"dia", 1))
+        plan, got = run()
+        info = plan.info
+        # (the reading off = a*S + b need not be unique: the skewed pattern -33, -32, -1, 0, 1, 32, 33 reads with S = 32 as
+        # well as with the grid's 33 -- but only with 33 does no entry leave its grid line, which plan creation checks)
+        assert info.dia == len(offs) and info.dia_stride == Nx and (info.dia_A, info.dia_B) == (A_, B_), (name, info.dia, info.dia_stride, info.dia_A, info.dia_B)
+        fused = plan.jacobi_schedule(5)[0] == 1
+        assert fused == (A_ == 1), (name, fused)
+        for i_, (a_, w_) in enumerate(zip(got, want)):
+            assert torch.equal(a_, w_), (name, i_, float((a_ - w_).abs().max()))
+
+
 def test_jacobi_fusion_size_threshold():
     """Below option jacobi_min_rows (default 2^20 rows) gla_jacobi_sweeps keeps one sweep per launch (faster there)."""
     from gnn_applied_linear_algebra_amd._lib import lib, check
