@@ -63,6 +63,22 @@ def _worker(rank, world, port, overlap, q):
             assert torch.equal(jac.forward(its, va1_loc, g), gla.JacobiGNN.JacobiGNN()(its, va1, ei, ea, g)[lo:hi]), its
         jac_ps = RowBlockJacobi(ei_l, ev_l, n, lo, hi, overlap=overlap, temporal=False)      # exchange per sweep
         assert jac_ps.ext is None and torch.equal(jac_ps.forward(6, va1_loc, g), x1_ref[lo:hi]), "jacobi per-sweep route"
+        # the same routes on the 9-point Q1 FEM operator (random positive diagonal, 63 lines of 63 points)
+        from gnn_applied_linear_algebra_amd.dist_amg import _row_slice
+        m9 = 63
+        n9 = m9 * m9
+        ei9, ev9 = gla.UtilsGNN.heateqnfem2dfun([m9 + 1, m9 + 1], [1.0, 2.0], device=dev)
+        cuts9 = [0, 30, m9] if world == 2 else [0, 9, 20, 41, m9]
+        lo9, hi9 = cuts9[rank] * m9, cuts9[rank + 1] * m9
+        va9 = torch.cat([torch.rand(n9, 1, generator=gen, dtype=torch.float64) + 2.0,
+                         torch.rand(n9, 2, generator=gen, dtype=torch.float64)], 1).to(dev)
+        ea9 = torch.cat([ev9, torch.zeros_like(ev9)], 1)
+        e9_l, v9_l = _row_slice(ei9, ev9, lo9, hi9)
+        jac9 = RowBlockJacobi(e9_l, v9_l.reshape(-1, 1), n9, lo9, hi9, overlap=overlap)
+        assert jac9.ext is not None, "FEM blocks of >= 5 lines take the temporally blocked route"
+        for its in (3, 5, 9):
+            assert torch.equal(jac9.forward(its, va9[lo9:hi9].contiguous(), g),
+                               gla.JacobiGNN.JacobiGNN()(its, va9, ei9, ea9, g)[lo9:hi9]), ("fem", its)
         info = jac.plan.info                                   # the block's own rows are stencil rows, its halo rows not
         assert info.dia == 5 or hi - lo <= 2 * Nx, info.dia
         if info.dia:
