@@ -11,32 +11,62 @@ import torch
 from ._common import aggregate, back, cols, compute_device, float_dtype, plan_for, split_cols, stack_cols, to_dev
 
 
-def chebyshev_relax(plan, b, x0, g, deg, out=None):
+FUSED_MAX = 4          # gla_cheby_fused takes the first 2 .. 4 steps in one pass over the data
+
+
+def chebyshev_relax(plan, b, x0, g, deg, out=None, need_gathered=True, b_copy=None):
     """Core of ChebyRelaxGNN on SoA operands: b, x0 [n, K] (row-major, any leading dimension), g = [c, d] (any
-    device).  Runs `deg` fused steps on `plan` and returns (x, r, p, gathered, g_out) where `gathered` is the vector
+    device).  Runs `deg` steps on `plan` and returns (x, r, p, gathered, g_out) where `gathered` is the vector
     the last SpMV read (x0 for deg 1, the previous p otherwise -- the z_ij = A_ij * gathered_j of the returned edge
-    attributes).  out = (x, r, p): caller-owned destinations (e.g. column views of the AoS result) the final
-    iterates are written into directly."""
+    attributes; None when need_gathered is False and the fused path did not materialise it).  out = (x, r, p):
+    caller-owned destinations (e.g. column views of the AoS result) the final iterates are written into directly;
+    b_copy: where the module's [b, x, r, p] result wants its copy of b (written by the fused pass, else copied here).
+    On 2-D stencil plans with K a multiple of the 16-byte vector the first min(deg, 4) steps run as ONE temporally
+    blocked pass (gla_cheby_fused, bit-identical); the rest, and every other case, one fused kernel per step."""
     gh = g.detach().to("cpu")
     c, d = gh[0], gh[1]
-    alpha = 1 / d                                                    # ChebyGNN.py:137
-    beta = None
+    # the scalar recurrences of the global updates, all steps up front (they do not depend on the vectors)
+    alphas, betas = [1 / d], [None]                                  # ChebyGNN.py:137
+    for it in range(2, deg + 1):
+        a_prev = alphas[-1]
+        beta = 0.5 * (c * a_prev) ** 2 if it == 2 else ((c * a_prev) / 2) ** 2      # :262 / :282
+        alphas.append(1 / (d - beta / a_prev))                                      # :263 / :283
+        betas.append(beta)
     if out is None:
-        r, p, x = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
-        p_next = torch.empty_like(p) if deg > 1 else None
+        r, p_final, x = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
     else:
         x, r, p_final = out
-        scratch = torch.empty((b.shape[0], b.shape[1]), dtype=b.dtype, device=b.device) if deg > 1 else None
-        # p ping-pongs deg - 1 times: start so that the last one lands in the caller's buffer
-        p, p_next = (p_final, scratch) if (deg - 1) % 2 == 0 else (scratch, p_final)
-    plan.cheby_first(b, x0, r, p, x, float(alpha))
     gathered = x0
-    for it in range(2, deg + 1):
-        beta = 0.5 * (c * alpha) ** 2 if it == 2 else ((c * alpha) / 2) ** 2      # :262 / :282
-        alpha_new = 1 / (d - beta / alpha)                                          # :263 / :283
-        plan.cheby_next(p, p_next, r, x, float(alpha), float(alpha_new), float(beta))
+    done = 0
+    m = min(deg, FUSED_MAX)
+    if m >= 2:
+        # fused pass for steps 1 .. m.  Its p goes to the caller's buffer when it is the final p, otherwise (more steps
+        # follow) to a scratch chosen so that the ping-pong below ends in the caller's buffer.
+        rest = deg - m
+        scratch = torch.empty((b.shape[0], b.shape[1]), dtype=b.dtype, device=b.device) if rest > 0 or need_gathered else None
+        p_m = p_final if rest % 2 == 0 else scratch
+        p_prev = None
+        if rest == 0 and need_gathered:
+            p_prev = scratch
+        if plan.cheby_fused(b, x0, x, r, p_m, [float(a) for a in alphas[:m]], [0.0] + [float(v) for v in betas[1:m]],
+                            Pprev=p_prev, Bcopy=b_copy):
+            done = m
+            b_copy = None
+            p = p_m
+            p_next = scratch if p_m is p_final else p_final
+            gathered = p_prev if rest == 0 else None
+    if b_copy is not None:
+        b_copy.copy_(b)
+    if done == 0:
+        p_other = torch.empty((b.shape[0], b.shape[1]), dtype=b.dtype, device=b.device) if deg > 1 else None
+        # p ping-pongs deg - 1 times: start so that the last one lands in the caller's buffer
+        p, p_next = (p_final, p_other) if (deg - 1) % 2 == 0 else (p_other, p_final)
+        plan.cheby_first(b, x0, r, p, x, float(alphas[0]))
+        done = 1
+    for it in range(done + 1, deg + 1):
+        plan.cheby_next(p, p_next, r, x, float(alphas[it - 2]), float(alphas[it - 1]), float(betas[it - 1]))
         gathered, p, p_next = p, p_next, p
-        alpha = alpha_new
+    alpha, beta = alphas[-1], betas[-1]
     g_out = torch.hstack([c, d, alpha] if beta is None else [c, d, alpha, beta]).to(g.device)
     return x, r, p, gathered, g_out
 
@@ -62,12 +92,12 @@ class ChebyRelaxGNN(torch.nn.Module):
             # multi-RHS: the kernels take leading dimensions, so b / x0 are read in place from the AoS input and
             # x, r, p are written straight into the AoS result (no split / stack passes over the K-wide vectors)
             res = torch.empty((va.shape[0], 4, va.shape[2]), dtype=va.dtype, device=va.device)
-            res[:, 0, :] = va[:, 0, :]
             _, _, _, gathered, g_out = chebyshev_relax(plan, va[:, 0, :], va[:, 1, :], g, self.deg,
-                                                       out=(res[:, 1, :], res[:, 2, :], res[:, 3, :]))
+                                                       out=(res[:, 1, :], res[:, 2, :], res[:, 3, :]),
+                                                       need_gathered=self.return_edge_attr, b_copy=res[:, 0, :])
         else:
             b, x0 = split_cols(va) if va.dim() == 2 else (cols(va, 0), cols(va, 1))
-            x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg)
+            x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg, need_gathered=self.return_edge_attr)
             res = stack_cols([b, x, r, p], va)
         ea_out = plan.edge_attr(gathered) if self.return_edge_attr else None    # [A_ij, z_ij] in one pass
         return back(res, vertex_attr), back(ea_out, edge_attr), g_out

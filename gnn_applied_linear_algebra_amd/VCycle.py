@@ -339,7 +339,8 @@ class AMGHierarchy:
                 return torch.linalg.lu_solve(self._coarse_lu[0], self._coarse_lu[1], b)
             g = torch.tensor(self.coarse_bounds, dtype=b.dtype)
             for _ in range(self.coarse_sweeps):
-                x = chebyshev_relax(self.plans[level], b.contiguous(), x.contiguous(), g, self.cheby.deg)[0]
+                x = chebyshev_relax(self.plans[level], b.contiguous(), x.contiguous(), g, self.cheby.deg,
+                                    need_gathered=False)[0]
             return x
         x = self._smooth(level, self.n_pre, b, x)
         r = self.residual(b, x, level)

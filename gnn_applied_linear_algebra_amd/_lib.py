@@ -55,6 +55,8 @@ SIGNATURES = {
     "gla_jacobi_fused": (_I, [_P, _I, _P, _P, _P, _P, _D, _I, _I, _P]),
     "gla_cheby_first": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I, _P]),
     "gla_cheby_next": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _D, _D, _I, _P]),
+    "gla_cheby_fused": (_I, [_P, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64,
+                             ctypes.POINTER(_D), ctypes.POINTER(_D), _P]),
     "gla_dot_work_bytes": (_I64, [_I64, _I, _I]),
     "gla_col_dot": (_I, [_I, _I64, _I, _P, _I64, _P, _I64, _P, _P, _P]),
     "gla_col_scale_rsqrt": (_I, [_I, _I64, _I, _P, _I64, _P, _P, _I64, _P]),

@@ -1,0 +1,256 @@
+// libgla_hip.so -- temporally blocked Chebyshev relaxation on 2-D stencil plans, K right-hand sides (gfx950 / MI355X).
+//
+// ChebyRelaxGNN(deg) (pytorch/ChebyGNN.py:287-353) is deg dependent SpMM steps,
+//     step 1     r = b - A x;  p = r;  x += alpha_1 r                         (ChebyGNN.py:49-163)
+//     step k>=2  r -= alpha_{k-1} (A p);  p = r + beta_k p;  x += alpha_k p     (ChebyGNN.py:166-243)
+// each of which streams b / x / r / p (K values per vertex each) through HBM when run as one kernel per step
+// (gla_cheby_first / gla_cheby_next: 11.4 + 13.6 (deg - 1) GB at 4096^2 x 16 fp64).  Only the LAST x, r, p leave the
+// module, so -- exactly like the temporally blocked Jacobi sweeps (gla_rows.hip) -- the steps are fused into ONE pass:
+// a workgroup owns a strip of BP = 256 / KV grid points x K right-hand sides (lanes = (point, 16-byte rhs vector)) and
+// marches down the grid lines; the operand each step gathers (x for step 1, p_{k-1} for step k) lives in a 3-line LDS
+// ring per step, r and x travel from one step to the next in registers (a row meets step k one line step after step
+// k - 1), the coefficients of the last DEG lines stay in registers.  HBM sees b and x once in, x, r, p once out.
+// Step t is valid on the strip minus t * B points either side (strips overlap by 2 DEG B points).
+// Per row the arithmetic is that of the EpiChebyFirst / EpiChebyNext epilogues (in-order masked sum over the diagonals,
+// then the same vector updates, product and sum rounded separately): bit-identical to the step-by-step kernels.
+#include "gla_device.h"
+
+namespace {
+
+constexpr int CH_DMAX = 5;             // 5-point-type stencils (the 9-point FEM operator keeps one kernel per step)
+constexpr int CH_DEG_MAX = 4;
+
+struct Cheb2D {
+  const void* val;                     // [D][n_rows] diagonal-major values
+  const uint16_t* mask;                // [n_rows]
+  int32_t D, S, B;
+  int32_t da[CH_DMAX], db[CH_DMAX];
+  int64_t n_rows, n_cols;
+  double alpha[CH_DEG_MAX], beta[CH_DEG_MAX];      // alpha[k - 1] = alpha_k, beta[k - 1] = beta_k (beta_1 unused)
+};
+
+template <typename T>
+struct ChCoef { T v[CH_DMAX]; int m; };            // one row's diagonal values, mask | live bit 16
+
+template <typename T, int KV, int DEG>
+__global__ __launch_bounds__(GLA_BLOCK) void cheby_fused_dia2d_kernel(
+    Cheb2D cv, const T* __restrict__ bvec, int64_t ldb, const T* __restrict__ x0, int64_t ldx0, T* __restrict__ xout,
+    int64_t ldxo, T* __restrict__ rout, int64_t ldr, T* __restrict__ pout, int64_t ldp, T* __restrict__ pprev,
+    int64_t ldpp, T* __restrict__ bcopy, int64_t ldbc, int lines, int nstrips, int64_t nlines, TileMap tm) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int BP = GLA_BLOCK / KV;               // grid points of a strip
+  typedef T TV __attribute__((ext_vector_type(VW)));
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  TV* ring = reinterpret_cast<TV*>(smem_raw);      // [DEG][3][BP * KV]: ring t = three lines of the operand step t + 1 gathers
+  constexpr int RING = 3 * BP * KV;
+  const int blk = map_tile(tm);
+  if (blk < 0) return;
+  const int B = cv.B, halo = DEG * B, bp_eff = BP - 2 * halo;
+  const int lb = blk / nstrips, strip = blk - lb * nstrips;
+  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bp_eff - halo;
+  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int tid = threadIdx.x, ii = tid / KV, q = tid % KV;
+  const T* __restrict__ val = static_cast<const T*>(cv.val);
+  int da[CH_DMAX], db[CH_DMAX];
+#pragma unroll
+  for (int d = 0; d < CH_DMAX; ++d) { const int dd = min(d, cv.D - 1); da[d] = cv.da[dd]; db[d] = cv.db[dd]; }
+
+  auto slot = [](int line) { return (line + 9) % 3; };
+  auto live_row = [&](int jl, int64_t& r) -> bool {
+    const int64_t gj = J0 + jl, gi = P0 + ii;
+    r = gj * cv.S + gi;
+    return gj >= 0 && gj < nlines && gi >= 0 && gi < cv.S && r < cv.n_rows;
+  };
+  auto x0_at = [&](int jl) -> TV {                 // clamped: values of dead rows are never used
+    int64_t flat = (J0 + jl) * cv.S + P0 + ii;
+    flat = min(max(flat, (int64_t)0), cv.n_cols - 1);
+    return ldv<TV>(x0 + flat * ldx0 + q * VW);
+  };
+  auto b_at = [&](int jl) -> TV {
+    int64_t r;
+    const bool live = live_row(jl, r);
+    return ldv<TV>(bvec + (live ? r : 0) * ldb + q * VW);
+  };
+  auto coef_at = [&](int jl) -> ChCoef<T> {
+    int64_t r;
+    const bool live = live_row(jl, r);
+    const int64_t rc = live ? r : 0;
+    ChCoef<T> c;
+#pragma unroll
+    for (int d = 0; d < CH_DMAX; ++d) c.v[d] = val[(int64_t)min(d, cv.D - 1) * cv.n_rows + rc];
+    c.m = live ? ((int)cv.mask[rc] | 0x10000) : 0;
+    return c;
+  };
+  // in-order masked row sum of A g for this lane's (row, rhs vector) from ring t (lines line - 1 .. line + 1)
+  auto stencil = [&](const ChCoef<T>& c, int t, int line) -> TV {
+    const TV* rg = ring + (size_t)t * RING;
+    TV acc = TV(T(0));
+#pragma unroll
+    for (int d = 0; d < CH_DMAX; ++d) {
+      const int pos = min(max(ii + db[d], 0), BP - 1);             // strip-edge lanes: their results are never used
+      const TV xv = rg[slot(line + da[d]) * BP * KV + pos * KV + q];
+      const TV nxt = acc + c.v[d] * xv;
+      acc = ((c.m >> d) & 1) ? nxt : acc;
+    }
+    return acc;
+  };
+  auto centre = [&](int t, int line) -> TV { return ring[(size_t)t * RING + slot(line) * BP * KV + ii * KV + q]; };
+
+  // step 1 is formed on lines -(DEG-1) .. L-1+(DEG-1): it needs x on lines -DEG .. L-1+DEG
+  const int j_first = -(DEG - 1), j_last = L - 1 + (DEG - 1);
+  ring[slot(j_first - 1) * BP * KV + ii * KV + q] = x0_at(j_first - 1);
+  ring[slot(j_first) * BP * KV + ii * KV + q] = x0_at(j_first);
+  TV xpre = x0_at(j_first + 1), bcur = b_at(j_first), bnxt = bcur;
+  ChCoef<T> c[DEG];                                // c[t]: coefficients of line jl - t
+  c[0] = coef_at(j_first);
+#pragma unroll
+  for (int t = 1; t < DEG; ++t) c[t] = c[0];
+  ChCoef<T> cnxt = c[0];
+  TV cr[DEG], cx[DEG];                             // r and x of the row step t + 1 meets at the NEXT line step (cr[t]: after step t)
+#pragma unroll
+  for (int t = 0; t < DEG; ++t) cr[t] = cx[t] = TV(T(0));
+  const bool interior = ii >= halo && ii < BP - halo;
+#pragma unroll 1
+  for (int jl = j_first; jl <= j_last; ++jl) {
+    ring[slot(jl + 1) * BP * KV + ii * KV + q] = xpre;               // x line jl + 1 joins ring 0
+    if (jl + 2 <= j_last + 1) xpre = x0_at(jl + 2);                  // prefetch for the next line step
+    if (jl + 1 <= j_last) { cnxt = coef_at(jl + 1); bnxt = b_at(jl + 1); }
+    TV in_r = TV(T(0)), in_x = TV(T(0));
+#pragma unroll
+    for (int t = 1; t <= DEG; ++t) {
+      __syncthreads();
+      const int line = jl - (t - 1);
+      const TV use_r = in_r, use_x = in_x;          // what step t - 1 left for THIS row one line step ago
+      if (t < DEG) { in_r = cr[t]; in_x = cx[t]; }  // keep step t's previous results for step t + 1 before overwriting them
+      const TV acc = stencil(c[t - 1], t - 1, line);
+      TV ri, pn, xn;
+      if (t == 1) {                                 // EpiChebyFirst: r = b - A x; p = r; x = x + alpha_1 r
+        if (bcopy) {                                // the caller's [b, x, r, p] result wants b too: it is in a register anyway
+          int64_t rb;
+          if (live_row(line, rb) && interior && line >= 0 && line < L) stv<TV>(bcopy + rb * ldbc + q * VW, bcur);
+        }
+        ri = bcur - acc;
+        pn = ri;
+        xn = centre(0, line) + (T)cv.alpha[0] * ri;
+      } else {                                      // EpiChebyNext: r -= a_old (A p); p = r + beta p; x += a_new p
+        ri = use_r - (T)cv.alpha[t - 2] * acc;
+        pn = ri + (T)cv.beta[t - 1] * centre(t - 1, line);
+        xn = use_x + (T)cv.alpha[t - 1] * pn;
+      }
+      int64_t r;
+      const bool store_ok = live_row(line, r) && interior && line >= 0 && line < L && (c[t - 1].m & 0x10000);
+      if (t < DEG) {
+        ring[(size_t)t * RING + slot(line) * BP * KV + ii * KV + q] = pn;
+        cr[t] = ri;
+        cx[t] = xn;
+        if (t == DEG - 1 && pprev && store_ok) stv<TV>(pprev + r * ldpp + q * VW, pn);   // the operand the last step gathers
+      } else if (store_ok) {
+        stv<TV>(xout + r * ldxo + q * VW, xn);
+        stv<TV>(rout + r * ldr + q * VW, ri);
+        stv<TV>(pout + r * ldp + q * VW, pn);
+      }
+    }
+#pragma unroll
+    for (int t = DEG - 1; t >= 1; --t) c[t] = c[t - 1];
+    c[0] = cnxt;
+    bcur = bnxt;
+  }
+}
+
+template <typename T, int KV, int DEG>
+int launch_cheby_fused(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout,
+                       int64_t ldxo, T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc,
+                       hipStream_t st) {
+  constexpr int BP = GLA_BLOCK / KV;
+  const int bp_eff = BP - 2 * DEG * cv.B;
+  if (bp_eff < 1) return GLA_ERR_UNSUPPORTED;
+  const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
+  const int nstrips = (int)((A->dia_S + bp_eff - 1) / bp_eff);
+  const size_t lds = (size_t)DEG * 3 * BP * KV * 16;
+  // block height: all workgroups resident at once (LDS: 12 KB per fused step and workgroup; registers: 3 waves per SIMD)
+  int lines = g_tuning.jacobi_lines;
+  if (lines <= 0) {
+    const int64_t per_cu = std::min<int64_t>(3, (160 * 1024) / (int64_t)lds);
+    const int64_t slots = 256 * (per_cu > 0 ? per_cu : 1);
+    const int64_t blocks = slots / nstrips > 0 ? slots / nstrips : 1;
+    int64_t l = (nlines + blocks - 1) / blocks;
+    if (l < 2 * DEG) l = 2 * DEG;
+    lines = (int)std::min<int64_t>(l, 1 << 20);
+  }
+  TileMap tm;
+  tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
+  tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
+  set_tile_mapping(tm);
+  hipLaunchKernelGGL((cheby_fused_dia2d_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
+                     st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+template <typename T, int KV>
+int dispatch_deg(int deg, gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout,
+                 int64_t ldxo, T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc,
+                 hipStream_t st) {
+  switch (deg) {
+    case 2: return launch_cheby_fused<T, KV, 2>(A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+    case 3: return launch_cheby_fused<T, KV, 3>(A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+    case 4: return launch_cheby_fused<T, KV, 4>(A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+    default: return GLA_ERR_UNSUPPORTED;
+  }
+}
+
+template <typename T>
+int cheby_fused_impl(gla_csr* A, int K, int deg, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout, int64_t ldxo,
+                     T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc, const double* alpha,
+                     const double* beta, hipStream_t st) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int kv = K / VW;
+  const bool ptr_ok = al16(b) && al16(x0) && al16(xout) && al16(r) && al16(p) && (!pprev || al16(pprev)) &&
+                      (!bcopy || (al16(bcopy) && ldbc % VW == 0)) &&
+                      ldb % VW == 0 && ldx0 % VW == 0 && ldxo % VW == 0 && ldr % VW == 0 && ldp % VW == 0 &&
+                      (!pprev || ldpp % VW == 0);
+  if (K % VW != 0 || !(kv == 1 || kv == 2 || kv == 4 || kv == 8) || !ptr_ok) return GLA_ERR_UNSUPPORTED;
+  Cheb2D cv;
+  cv.val = A->dia_val;
+  cv.mask = A->dia_mask;
+  cv.D = A->dia_D; cv.S = A->dia_S; cv.B = A->dia_B;
+  for (int i = 0; i < CH_DMAX; ++i) { cv.da[i] = i < A->dia_D ? A->dia_a[i] : 0; cv.db[i] = i < A->dia_D ? A->dia_b[i] : 0; }
+  cv.n_rows = A->n_rows; cv.n_cols = A->n_cols;
+  for (int i = 0; i < CH_DEG_MAX; ++i) { cv.alpha[i] = i < deg ? alpha[i] : 0.0; cv.beta[i] = i < deg ? beta[i] : 0.0; }
+  switch (kv) {
+    case 1: return dispatch_deg<T, 1>(deg, A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+    case 2: return dispatch_deg<T, 2>(deg, A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+    case 4: return dispatch_deg<T, 4>(deg, A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+    default: return dispatch_deg<T, 8>(deg, A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gla_cheby_fused(gla_csr_t A, int dtype, int K, int deg, const void* B, int64_t ldb, const void* X0, int64_t ldx0,
+                    void* Xout, int64_t ldxo, void* R, int64_t ldr, void* P, int64_t ldp, void* Pprev, int64_t ldpp,
+                    void* Bcopy, int64_t ldbc, const double* alpha_host, const double* beta_host, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!B || !X0 || !Xout || !R || !P || X0 == Xout || !alpha_host || !beta_host || ldb < K || ldx0 < K || ldxo < K ||
+      ldr < K || ldp < K || (Pprev && ldpp < K) || (Bcopy && ldbc < K))
+    return GLA_ERR_INVALID_ARG;
+  if (deg < 2 || deg > CH_DEG_MAX) return GLA_ERR_UNSUPPORTED;
+  // 2-D stencil plans whose entries never leave their grid line, one line either side, at most five diagonals
+  if (!(g_tuning.dia && g_tuning.jacobi_fuse && A->dia_state == 1 && A->dia_val && A->dia_S > 0 && A->dia_nowrap &&
+        A->dia_A == 1 && A->dia_B >= 1 && A->dia_B <= 2 && A->dia_D <= CH_DMAX && A->dia_row_lo == 0 &&
+        A->dia_row_hi == A->n_rows && A->n_rows == A->n_cols && A->n_rows * (int64_t)K >= g_tuning.jacobi_min_rows))
+    return GLA_ERR_UNSUPPORTED;
+  if (A->n_rows == 0) return GLA_OK;
+  if (dtype == GLA_F64)
+    return cheby_fused_impl<double>(A, K, deg, (const double*)B, ldb, (const double*)X0, ldx0, (double*)Xout, ldxo,
+                                    (double*)R, ldr, (double*)P, ldp, (double*)Pprev, ldpp, (double*)Bcopy, ldbc, alpha_host,
+                                    beta_host, (hipStream_t)stream);
+  return cheby_fused_impl<float>(A, K, deg, (const float*)B, ldb, (const float*)X0, ldx0, (float*)Xout, ldxo, (float*)R,
+                                 ldr, (float*)P, ldp, (float*)Pprev, ldpp, (float*)Bcopy, ldbc, alpha_host, beta_host,
+                                 (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -275,7 +275,8 @@ class RowBlockAMG:
             x_full = self.gather(x, level)
             g = torch.tensor(C.bounds, dtype=b.dtype)
             for _ in range(C.sweeps):
-                x_full = chebyshev_relax(C.plan, b_full.contiguous(), x_full.contiguous(), g, C.deg)[0]
+                x_full = chebyshev_relax(C.plan, b_full.contiguous(), x_full.contiguous(), g, C.deg,
+                                         need_gathered=False)[0]
             return x_full[lo:hi].contiguous()
         x = self.smooth(level, self.n_pre, b, x)
         r = self.residual(b, x, level)

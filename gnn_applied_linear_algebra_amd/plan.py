@@ -253,6 +253,35 @@ class CsrPlan:
                                    stream_ptr(self.device)))
 
     @_on_device
+    def cheby_fused(self, B, X0, Xout, R, P, alphas, betas, Pprev=None, Bcopy=None):
+        """Steps 1 .. len(alphas) (2 .. 4) of the Chebyshev relaxation in ONE pass (gla_cheby_fused).  Returns False when
+        the plan / operands do not qualify (the caller runs cheby_first / cheby_next step by step), True otherwise."""
+        X0, K, ldx0 = _dense(X0, self.n_cols, "X0")
+        B, _, ldb = _dense(B, self.n_rows, "B")
+        Xout, _, ldxo = _dense(Xout, self.n_rows, "Xout")
+        R, _, ldr = _dense(R, self.n_rows, "R")
+        P, _, ldp = _dense(P, self.n_rows, "P")
+        self._need(X0.dtype)
+        assert B.shape[1] == R.shape[1] == P.shape[1] == Xout.shape[1] == K
+        assert B.dtype == R.dtype == P.dtype == Xout.dtype == X0.dtype and X0.data_ptr() != Xout.data_ptr()
+        ldpp = 0
+        if Pprev is not None:
+            Pprev, _, ldpp = _dense(Pprev, self.n_rows, "Pprev")
+        ldbc = 0
+        if Bcopy is not None:
+            Bcopy, _, ldbc = _dense(Bcopy, self.n_rows, "Bcopy")
+        deg = len(alphas)
+        a = (ctypes.c_double * deg)(*[float(v) for v in alphas])
+        bt = (ctypes.c_double * deg)(*[float(v) for v in betas])
+        rc = lib().gla_cheby_fused(self._h, dtype_code(X0.dtype), K, deg, ptr(B), ldb, ptr(X0), ldx0, ptr(Xout), ldxo,
+                                   ptr(R), ldr, ptr(P), ldp, ptr(Pprev), ldpp, ptr(Bcopy), ldbc, a, bt,
+                                   stream_ptr(self.device))
+        if rc == -5:
+            return False
+        check(rc)
+        return True
+
+    @_on_device
     def power_step(self, X, nrm=None, out=None, which=ALL_TILES, work=None, sumsq=None):
         """Fused power-method step: Y = A (X ./ nrm), sumsq[k] = sum_i Y[i,k]^2 (PowerMethodGNN.py:86-207).
         Returns (Y, sumsq, work); raises GlaError(-5) when the plan / K has no fused kernel."""

@@ -173,6 +173,18 @@ int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, vo
                    void* R, int64_t ldr, void* X, int64_t ldx, double alpha_old, double alpha_new, double beta,
                    int which_tiles, gla_stream_t stream);
 
+/* The first `deg` (2 .. 4) Chebyshev steps in ONE pass over the data (temporal blocking, as gla_jacobi_sweeps does for
+ * Jacobi): Xout, R, P = x, r, p after step `deg` of ChebyRelaxGNN (ChebyGNN.py:287-353) started from (B, X0);
+ * alpha_host[k-1] = alpha_k (k = 1 .. deg), beta_host[k-1] = beta_k (k >= 2), the scalars of the global updates
+ * (ChebyGNN.py:123-139, :246-285) evaluated by the caller.  Pprev (may be NULL) receives p after step deg - 1, the vector
+ * the last step gathers (the z_ij of the returned edge attributes); Bcopy (may be NULL) a copy of B (the module returns
+ * [b, x, r, p] and b passes through a register anyway).  Same per-row arithmetic as gla_cheby_first +
+ * gla_cheby_next: bit-identical.  2-D stencil plans with at most five diagonals, K a multiple of the 16-byte vector
+ * (1, 2, 4 or 8 vectors), 16-byte aligned operands; otherwise GLA_ERR_UNSUPPORTED (run the steps one by one). */
+int gla_cheby_fused(gla_csr_t A, int dtype, int K, int deg, const void* B, int64_t ldb, const void* X0, int64_t ldx0,
+                    void* Xout, int64_t ldxo, void* R, int64_t ldr, void* P, int64_t ldp, void* Pprev, int64_t ldpp,
+                    void* Bcopy, int64_t ldbc, const double* alpha_host, const double* beta_host, gla_stream_t stream);
+
 /* Column sums of X .* Y over `n` rows -> out[K] (device, same dtype).  PowerMethodGNN.py:50-61
  * (torch.sum(vertex_attr[:,1]) with y = b*b :124 or y = b*cbar :233).  `work` needs gla_dot_work_bytes(n,K). */
 int64_t gla_dot_work_bytes(int64_t n, int K, int dtype);

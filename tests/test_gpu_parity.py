@@ -1187,6 +1187,59 @@ def test_generic_stencils_blocked_and_fused_kernels():
             assert torch.equal(a_, w_), (name, i_, float((a_ - w_).abs().max()))
 
 
+def test_cheby_fused_pass_bit_identical():
+    """gla_cheby_fused (steps 1 .. deg of ChebyRelaxGNN in ONE pass over the data, deg = 2, 3, 4) against the
+    step-by-step kernels gla_cheby_first + gla_cheby_next: x, r, p and the operand of the last step, bit for bit;
+    K = 1, 2, 4, 8 16-byte vectors, fp64 and fp32, ragged grid sizes, a 5-point pattern with holes, a B = 2 stencil;
+    operands with leading dimensions (columns of an AoS tensor).  9-point plans and K = 1 are declined (False)."""
+    default_layout_only()
+    gen = torch.Generator().manual_seed(91)
+    cases = [("laplacian 300 x 70", *rp.laplacianfun_torch(300, 70), 21000),
+             ("laplacian 50 x 33", *rp.laplacianfun_torch(50, 33), 1650)]
+    ei, ev = _stencil_matrix(64, 50, [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)], gen, 0.3)
+    cases.append(("5-point with holes", ei, ev, 3200))
+    ei, ev = _stencil_matrix(70, 45, [(-1, 0), (0, -2), (0, 0), (0, 2), (1, 0)], gen, 0.0)
+    cases.append(("B = 2", ei, ev, 3150))
+    for name, ei, ev, n in cases:
+        for dtype, Ks in ((torch.float64, (2, 4, 8, 16)), (torch.float32, (4, 8, 16, 32))):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            for K in Ks:
+                g2 = torch.Generator().manual_seed(K)
+                wide_b = d(torch.rand(n, 3, K, generator=g2, dtype=torch.float64).to(dtype))      # b, x0 as AoS columns
+                b, x0 = wide_b[:, 0, :], wide_b[:, 2, :]
+                for deg in (2, 3, 4):
+                    alphas = [-0.25, -0.26, -0.27, -0.255][:deg]
+                    betas = [0.0, 0.1, 0.12, 0.09][:deg]
+                    # step by step
+                    r_w, p_a, x_w, p_b = (torch.empty(n, K, dtype=dtype, device=DEV) for _ in range(4))
+                    plan.cheby_first(b, x0, r_w, p_a, x_w, alphas[0])
+                    prev = None
+                    for k in range(2, deg + 1):
+                        plan.cheby_next(p_a, p_b, r_w, x_w, alphas[k - 2], alphas[k - 1], betas[k - 1])
+                        prev, p_a, p_b = p_a, p_b, p_a
+                    prev = prev.clone()
+                    # one pass, results into AoS columns
+                    res = torch.zeros(n, 4, K, dtype=dtype, device=DEV)
+                    pprev = torch.empty(n, K, dtype=dtype, device=DEV)
+                    assert plan.cheby_fused(b, x0, res[:, 0, :], res[:, 1, :], res[:, 3, :], alphas, betas, Pprev=pprev), (name, K, deg)
+                    for got, want, what in ((res[:, 0, :], x_w, "x"), (res[:, 1, :], r_w, "r"), (res[:, 3, :], p_a, "p"),
+                                            (pprev, prev, "p_prev")):
+                        assert torch.equal(got, want), (name, dtype, K, deg, what, float((got - want).abs().max()))
+                    assert bool((res[:, 2, :] == 0).all())                     # the neighbouring AoS column is untouched
+    # declined: one right-hand side (no 16-byte vector of them), and the 9-point operator
+    ei, ev = rp.laplacianfun_torch(40)
+    plan = gla.CsrPlan(d(ei), 1600)
+    plan.set_values(d(ev))
+    v = [torch.zeros(1600, 1, dtype=torch.float64, device=DEV) for _ in range(5)]
+    assert plan.cheby_fused(v[0], v[1], v[2], v[3], v[4], [-0.25, -0.26], [0.0, 0.1]) is False
+    ei, ev = rp.heateqnfem2dfun([41, 41], [1.0, 1.0])
+    plan = gla.CsrPlan(d(ei), 1600)
+    plan.set_values(d(ev))
+    v = [torch.zeros(1600, 2, dtype=torch.float64, device=DEV) for _ in range(5)]
+    assert plan.cheby_fused(v[0], v[1], v[2], v[3], v[4], [-0.25, -0.26], [0.0, 0.1]) is False
+
+
 def test_jacobi_fusion_size_threshold():
     """Below option jacobi_min_rows (default 2^20 rows) gla_jacobi_sweeps keeps one sweep per launch (faster there)."""
     default_layout_only()
