@@ -453,6 +453,9 @@ def single_gpu(args, gla, dev):
         tc, tpw = median(ms_c) * 1e-3, median(ms_p) * 1e-3
         out["config3_k16"] = {
             "what": f"BASELINE config 3 through the module surface, {Nx}^2 Laplacian, K=16 right-hand sides, fp64",
+            "note": "ChebyRelaxGNN(4) runs as ONE temporally blocked pass (gla_cheby_fused: b, x in; x, r, p out), so "
+                    "SURVEY's per-step byte model can read above the HBM peak; the power method needs a global norm "
+                    "between its iterations and stays one fused kernel per iteration",
             "cheby_deg4_ms": round(tc * 1e3, 3), "cheby_GBps": round(Bc / tc / 1e9, 1),
             "cheby_frac": round(Bc / tc / HBM_PEAK, 4), "cheby_algorithmic_bytes": Bc,
             "power_10its_ms": round(tpw * 1e3, 3), "power_GBps": round(Bp / tpw / 1e9, 1),
