@@ -281,29 +281,33 @@ def single_gpu(args, gla, dev):
     elapsed, step_ms = timed_steps(step, args.steps, 0)
     plan.jacobi_sweeps, plan.jacobi_sweeps_aos = _sweeps, _sweeps_aos
     total_sweeps = args.steps * args.sweeps
-    # launches behind one step: on 2-D stencil plans gla_jacobi_sweeps takes the sweeps 5, 4 or 2 at a time in one
-    # pass over the data (temporal blocking); the dominant kernel is the one that covers most sweeps
-    n5, n4, n2, n1 = plan.jacobi_schedule(args.sweeps)
-    launches = n5 + n4 + n2 + n1
-    spl = 5 if n5 else (4 if n4 else (2 if n2 else 1))      # sweeps per launch of the dominant kernel
+    # launches behind one step: on 2-D stencil plans gla_jacobi_sweeps takes several sweeps in one pass over the data
+    # (temporal blocking; 20 sweeps = passes of 7 + 7 + 6 on the 5-point Laplacian); the dominant kernel is the one that
+    # covers most sweeps
+    sched = plan.jacobi_schedule(args.sweeps)
+    launches = len(sched)
+    spl = max(set(sched), key=lambda ts: (ts * sched.count(ts), ts))      # sweeps per launch of the dominant kernel
     per_call = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in sweep_events]      # seconds per jacobi_sweeps call
-    # every launch of a call is the same kernel when the count divides (20 = 4 x 5: the BASELINE configuration);
-    # otherwise the call's time is apportioned by sweeps (the left-over launches run at a lower rate: a conservative
-    # figure for the dominant kernel)
+    # the events bracket a whole call (its launches are enqueued by one library call); a launch's share of it is taken
+    # proportional to its sweeps.  Passes of fewer sweeps take nearly as long as the dominant ones (a pass is bound by
+    # one trip of the matrix through HBM), so this is a conservative figure for the dominant kernel; the rocprof kernel
+    # stats under profiles/ give each kernel's own average
     per_launch = [t * spl / args.sweeps for t in per_call]
     t_launch = sum(per_launch) / len(per_launch)
     info = plan.info
     B_launch = pr.B * spl                                    # per-sweep bytes x the sweeps of one launch
     fused = spl > 1
-    kname = (f"jacobi_fused_dia2d_kernel<double,{5 if int(info.dia) <= 5 else 9},{spl}>" if fused else
+    march = fused and bool(info.dia_canon5) and plan.jacobi_schedule(3) == (3,)      # (3 per pass: march kernel only)
+    kname = ((f"jacobi_march5_kernel<double,{spl}>" if march else
+              f"jacobi_fused_dia2d_kernel<double,{5 if int(info.dia) <= 5 else 9},{spl}>") if fused else
              "spmv_stream_vec2_kernel<double,EpiJacobi>")
     roof = {"bound": "hbm", "achieved": round(B_launch / t_launch / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(B_launch / t_launch / HBM_PEAK, 4), "traffic": None,
-            "kernel": kname, "sweeps_per_launch": spl, "launches_per_step": launches,
+            "kernel": kname, "sweeps_per_launch": spl, "launches_per_step": launches, "schedule": list(sched),
             "algorithmic_bytes_per_launch": B_launch, "algorithmic_bytes_per_sweep": pr.B,
             "avg_launch_us": round(t_launch * 1e6, 2), "median_launch_us": round(median(per_launch) * 1e6, 2)}
     if fused:
-        roof["note"] = (f"{spl} sweeps per pass over the data (temporal blocking: the intermediate iterates stay in LDS, "
+        roof["note"] = (f"{spl} sweeps per pass over the data (temporal blocking: the intermediate iterates stay on chip, "
                         "matrix, b and A_ii are read once per pass), so SURVEY's per-sweep byte model x the sweeps of a "
                         "launch exceeds what HBM has to deliver and frac > 1 is expected; `traffic` and "
                         "`hbm_utilisation_by_traffic` are the bytes really moved")

@@ -27,7 +27,7 @@ class CsrInfo(ctypes.Structure):
                 ("long_rows", ctypes.c_int32), ("val_dtype", ctypes.c_int32), ("packed", ctypes.c_int32),
                 ("col16", ctypes.c_int32), ("col16_wide_tiles", ctypes.c_int32), ("dia", ctypes.c_int32),
                 ("dia_stride", ctypes.c_int32), ("dia_row_lo", ctypes.c_int64), ("dia_row_hi", ctypes.c_int64),
-                ("dia_A", ctypes.c_int32), ("dia_B", ctypes.c_int32)]
+                ("dia_A", ctypes.c_int32), ("dia_B", ctypes.c_int32), ("dia_canon5", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p
@@ -51,7 +51,7 @@ SIGNATURES = {
     "gla_jacobi_sweep": (_I, [_P, _I, _I, _P, _P, _I64, _P, _I64, _P, _I64, _D, _I, _P]),
     "gla_jacobi_sweeps": (_I, [_P, _I, _I, _P, _P, _I64, _P, _I64, _P, _P, _I64, _D, _I, _P]),
     "gla_jacobi_sweeps_aos": (_I, [_P, _I, _P, _I64, _P, _P, _P, _P, _D, _I, _P]),
-    "gla_jacobi_sweeps_schedule": (_I, [_P, _I, _I, ctypes.POINTER(_I)]),
+    "gla_jacobi_sweeps_schedule": (_I, [_P, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "gla_jacobi_fused": (_I, [_P, _I, _P, _P, _P, _P, _D, _I, _I, _P]),
     "gla_cheby_first": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _I, _P]),
     "gla_cheby_next": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _D, _D, _I, _P]),

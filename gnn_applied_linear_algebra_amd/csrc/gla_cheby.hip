@@ -30,7 +30,8 @@ struct Cheb2D {
 };
 
 template <typename T>
-struct ChCoef { T v[CH_DMAX]; int m; };            // one row's diagonal values, mask | live bit 16
+struct ChCoef { T v[CH_DMAX]; int m, lv; };        // one row's diagonal values, mask as loaded (untouched until its first
+                                                   // use, so that the load stays in flight across the line step), row exists
 
 template <typename T, int KV, int DEG>
 __global__ __launch_bounds__(GLA_BLOCK) void cheby_fused_dia2d_kernel(
@@ -78,19 +79,21 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_fused_dia2d_kernel(
     ChCoef<T> c;
 #pragma unroll
     for (int d = 0; d < CH_DMAX; ++d) c.v[d] = val[(int64_t)min(d, cv.D - 1) * cv.n_rows + rc];
-    c.m = live ? ((int)cv.mask[rc] | 0x10000) : 0;
+    c.m = (int)cv.mask[rc];
+    c.lv = live;
     return c;
   };
   // in-order masked row sum of A g for this lane's (row, rhs vector) from ring t (lines line - 1 .. line + 1)
   auto stencil = [&](const ChCoef<T>& c, int t, int line) -> TV {
     const TV* rg = ring + (size_t)t * RING;
     TV acc = TV(T(0));
+    const int m = c.lv ? c.m : 0;
 #pragma unroll
     for (int d = 0; d < CH_DMAX; ++d) {
       const int pos = min(max(ii + db[d], 0), BP - 1);             // strip-edge lanes: their results are never used
       const TV xv = rg[slot(line + da[d]) * BP * KV + pos * KV + q];
       const TV nxt = acc + c.v[d] * xv;
-      acc = ((c.m >> d) & 1) ? nxt : acc;
+      acc = ((m >> d) & 1) ? nxt : acc;
     }
     return acc;
   };
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_fused_dia2d_kernel(
         xn = use_x + (T)cv.alpha[t - 1] * pn;
       }
       int64_t r;
-      const bool store_ok = live_row(line, r) && interior && line >= 0 && line < L && (c[t - 1].m & 0x10000);
+      const bool store_ok = live_row(line, r) && interior && line >= 0 && line < L && c[t - 1].lv;
       if (t < DEG) {
         ring[(size_t)t * RING + slot(line) * BP * KV + ii * KV + q] = pn;
         cr[t] = ri;

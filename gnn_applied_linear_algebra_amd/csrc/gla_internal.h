@@ -73,10 +73,21 @@ struct gla_tuning {
   int dia = 1;              // stencil matrices (<= 16 diagonals): K = 1 kernels use the diagonal layout
   int jacobi_fuse = 1;      // gla_jacobi_sweeps on 2-D stencil plans: 0 one sweep per pass, 1 up to four (temporal blocking), 2 up to two
   int jacobi_lines = 0;     // grid lines a workgroup of the fused kernel marches through (0 = one resident round of workgroups)
+  int jacobi_ts_max = 8;    // canonical 5-point plans: most sweeps per pass (2 .. 8)
+  int jacobi_march = 1;     // canonical 5-point plans: 1 = the register-history march kernel, 0 = the generic LDS-ring kernel
   int64_t jacobi_min_rows = 1 << 20;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
                                        // is faster: a 768^2 grid takes 9 us per sweep either way, a 512^2 grid 5 vs 9 us)
 };
 extern gla_tuning g_tuning;
+
+// the 2-D reading is the canonical 5-point pattern: diagonals (-1,0) (0,-1) (0,0) (0,1) (1,0) in this order
+inline bool gla_dia_canon5(const gla_csr* A) {
+  static const int ca[5] = {-1, 0, 0, 0, 1}, cb[5] = {0, -1, 0, 1, 0};
+  if (A->dia_state != 1 || A->dia_S <= 0 || A->dia_D != 5 || A->dia_A != 1 || A->dia_B != 1) return false;
+  for (int d = 0; d < 5; ++d)
+    if (A->dia_a[d] != ca[d] || A->dia_b[d] != cb[d]) return false;
+  return true;
+}
 
 // plan.hip
 int gla_sort_rows_stable(int64_t nnz, int64_t n_rows, const int64_t* row, int32_t* perm_out,

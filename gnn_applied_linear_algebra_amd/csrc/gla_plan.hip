@@ -725,7 +725,7 @@ gla_tuning g_tuning;
 
 extern "C" {
 
-int gla_version(void) { return 120; }   // 100: round-1 core; 110: + edge_attr, segment_stats, edge_dot, mlp_relu3
+int gla_version(void) { return 130; }   // 100: round-1 core; 110: + edge_attr, segment_stats, edge_dot, mlp_relu3
 
 int gla_set_option(const char* name, int64_t value) {
   if (!name) return GLA_ERR_INVALID_ARG;
@@ -735,6 +735,8 @@ int gla_set_option(const char* name, int64_t value) {
   if (!strcmp(name, "dia")) { g_tuning.dia = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "jacobi_fuse")) { if (value < 0 || value > 2) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_fuse = (int)value; return GLA_OK; }
   if (!strcmp(name, "jacobi_min_rows")) { if (value < 0) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_min_rows = value; return GLA_OK; }
+  if (!strcmp(name, "jacobi_ts_max")) { if (value < 2 || value > 8) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_ts_max = (int)value; return GLA_OK; }
+  if (!strcmp(name, "jacobi_march")) { g_tuning.jacobi_march = (int)value; return GLA_OK; }
   if (!strcmp(name, "jacobi_lines")) { if (value < 0 || value == 1 || value > 4096) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_lines = (int)value; return GLA_OK; }
   if (!strcmp(name, "compress")) { g_tuning.compress = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "spmm_variant")) { g_tuning.spmm_variant = (int)value; return GLA_OK; }
@@ -981,6 +983,7 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->dia_row_hi = info->dia ? p->dia_row_hi : 0;
   info->dia_A = info->dia ? p->dia_A : 0;
   info->dia_B = info->dia ? p->dia_B : 0;
+  info->dia_canon5 = info->dia && gla_dia_canon5(p) ? 1 : 0;
   return GLA_OK;
 }
 

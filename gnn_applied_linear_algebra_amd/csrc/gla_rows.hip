@@ -992,8 +992,8 @@ inline int64_t dia2d_blocks_bound(const gla_csr* A) {
 template <typename T, int DMAX>
 struct DiaCoef {                                  // one row's matrix data
   T v[DMAX], b, dg;
-  int m;                                          // diagonal mask | live bit 16
-};
+  int m, lv;                                      // diagonal mask exactly as loaded (no arithmetic on it before its first use: the
+};                                                // load must stay in flight across the line step); lv = row exists
 
 // AOS = true (first pass of gla_jacobi_sweeps_aos): A_ii, b and x^(k) are columns 0, 1, 2 of the reference's row-major
 // vertex attribute tensor (`x` points at it, leading dimension ldva; JacobiGNN.py:104-106); the lane that owns a row also
@@ -1039,18 +1039,20 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
     for (int d = 0; d < DMAX; ++d) c.v[d] = val[(int64_t)min(d, dv.D - 1) * dv.n_rows + rc];
     if constexpr (AOS) { c.dg = x[rc * ldva]; c.b = x[rc * ldva + 1]; }
     else { c.b = bvec[rc]; c.dg = diag[rc]; }
-    c.m = live ? ((int)dv.mask[rc] | 0x10000) : 0;
+    c.m = (int)dv.mask[rc];
+    c.lv = live;
     return c;
   };
   // one Jacobi update of this lane's row on line jl from ring r (lines jl - 1 .. jl + 1; slot of line j: (j + 8) & 3)
   auto update = [&](const DiaCoef<T, DMAX>& c, const T* r, int jl) -> T {
     T acc = T(0);
+    const int m = c.lv ? c.m : 0;
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) {
       const int pos = min(max(tid + db[d], 0), BW - 1);            // window edge lanes: their results are never used
       const T xv = r[((jl + da[d] + 8) & 3) * BW + pos];
       const T nxt = acc + c.v[d] * xv;
-      acc = ((c.m >> d) & 1) ? nxt : acc;
+      acc = ((m >> d) & 1) ? nxt : acc;
     }
     const T xc = r[((jl + 8) & 3) * BW + tid];
     return xc + (w * (c.b - acc)) / c.dg;
@@ -1072,7 +1074,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
     if (jl + 2 <= j_last + 1) xpre = x0_at(jl + 2);                // prefetch for the next step
     if (jl + 1 <= j_last) nxt = coef_at(jl + 1);
     if constexpr (AOS) {                           // the row's owner leaves contiguous copies of A_ii and b (c[0]: line jl)
-      if (jl >= 0 && jl < L && (c[0].m & 0x10000) && tid >= halo && tid < BW - halo) {
+      if (jl >= 0 && jl < L && c[0].lv && tid >= halo && tid < BW - halo) {
         const int64_t r = (J0 + jl) * dv.S + P0 + tid;
         diag_out[r] = c[0].dg;
         b_out[r] = c[0].b;
@@ -1085,12 +1087,157 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
       if (line >= -(TS - t) && line <= L - 1 + (TS - t)) {
         const T xn = update(c[t - 1], ring + (size_t)(t - 1) * 4 * BW, line);
         if (t < TS) ring[(size_t)t * 4 * BW + ((line + 8) & 3) * BW + tid] = xn;
-        else if ((c[t - 1].m & 0x10000) && tid >= halo && tid < BW - halo) xo[(J0 + line) * dv.S + P0 + tid] = xn;
+        else if (c[t - 1].lv && tid >= halo && tid < BW - halo) xo[(J0 + line) * dv.S + P0 + tid] = xn;
       }
     }
 #pragma unroll
     for (int t = TS - 1; t >= 1; --t) c[t] = c[t - 1];
     c[0] = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same pass for the canonical 5-point pattern (diagonals (-1,0) (0,-1) (0,0) (0,1) (1,0) in that order, B = 1), built
+// around what bounded the generic kernel above: instruction issue (~335 VALU instructions per line step, of which a third
+// masks, a tenth register rotation and a tenth LDS addressing; rocprof + ISA count).  Here
+//   * the j -/+ 1 neighbours and the centre are the lane's OWN values of the last three line steps -> registers (h[t][0..2]);
+//     LDS only carries the i -/+ 1 neighbours: one padded line per level and line parity, one write + two reads per update,
+//     and since a level reads what the level below wrote a step EARLIER, ONE barrier per line step;
+//   * the line loop is unrolled over the TS + 1 coefficient sets (and the line parity), so sets and LDS slots have static names:
+//     no register rotation, no address arithmetic;
+//   * a wave whose 64 rows all carry the full pattern (wave-uniform flag per coefficient set) skips the mask selects; any other
+//     wave takes the masked in-order sum.  Both are the arithmetic of spmv_dia_kernel + EpiJacobi: bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TS, bool AOS = false>
+__global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, const T* __restrict__ diag,
+                                                                  const T* __restrict__ bvec, const T* __restrict__ x,
+                                                                  T* __restrict__ xo, T w, int lines, int nstrips,
+                                                                  int64_t nlines, TileMap tm, int tile_base0, int tile_split,
+                                                                  int tile_base1, int64_t ldva = 1,
+                                                                  T* __restrict__ diag_out = nullptr,
+                                                                  T* __restrict__ b_out = nullptr) {
+  constexpr int BW = GLA_BLOCK, LW = BW + 2;      // a line in LDS: lane tid at [1 + tid], one pad either side
+  constexpr int NC = TS + 1;                      // coefficient sets in flight (lines jl + 1 .. jl - TS + 1)
+  constexpr int U = NC;                           // unroll: static set index
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* buf = reinterpret_cast<T*>(smem_raw);        // [TS][2][LW]: buf[t][p] = the latest line of parity p of x^(k+t)
+  const int slot = map_tile(tm);
+  if (slot < 0) return;
+  const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
+  constexpr int halo = TS, bi_eff = BW - 2 * halo;
+  const int lb = blk / nstrips, strip = blk - lb * nstrips;
+  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bi_eff - halo;
+  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int tid = threadIdx.x;
+  const T* __restrict__ val = static_cast<const T*>(dv.val);
+  const int64_t gi = P0 + tid;
+  const bool in_i = gi >= 0 && gi < dv.S;
+  const bool owner = tid >= halo && tid < BW - halo;
+
+  auto x0_at = [&](int jl) -> T {
+    int64_t flat = (J0 + jl) * dv.S + gi;
+    flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
+    if constexpr (AOS) return x[flat * ldva + 2];
+    else return x[flat];
+  };
+  auto coef_at = [&](int jl) -> DiaCoef<T, 5> {
+    const int64_t gj = J0 + jl, r = gj * dv.S + gi;
+    const bool live = in_i && gj >= 0 && gj < nlines && r < dv.n_rows;
+    const int64_t rc = live ? r : 0;
+    DiaCoef<T, 5> c;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
+    if constexpr (AOS) { c.dg = x[rc * ldva]; c.b = x[rc * ldva + 1]; }
+    else { c.b = bvec[rc]; c.dg = diag[rc]; }
+    c.m = (int)dv.mask[rc];
+    c.lv = live;
+    return c;
+  };
+  auto update = [&](const DiaCoef<T, 5>& c, bool full, T up, T left, T ctr, T right, T down) -> T {
+    T acc = T(0);
+    if (full) {
+      acc = acc + c.v[0] * up;
+      acc = acc + c.v[1] * left;
+      acc = acc + c.v[2] * ctr;
+      acc = acc + c.v[3] * right;
+      acc = acc + c.v[4] * down;
+    } else {
+      const T xs[5] = {up, left, ctr, right, down};
+      const int m = c.lv ? c.m : 0;
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const T nxt = acc + c.v[d] * xs[d];
+        acc = ((m >> d) & 1) ? nxt : acc;
+      }
+    }
+    return ctr + (w * (c.b - acc)) / c.dg;
+  };
+
+  constexpr int j_first = -(TS - 1);
+  const int j_last = L - 1 + (TS - 1);
+  T h[TS][3];                                      // h[t]: x^(k+t) of this lane on the last three lines level t produced
+#pragma unroll
+  for (int t = 0; t < TS; ++t) h[t][0] = h[t][1] = h[t][2] = T(0);
+  h[0][1] = x0_at(j_first - 1);
+  h[0][2] = x0_at(j_first);
+  buf[((j_first + 64) & 1) * LW + 1 + tid] = h[0][2];
+  T xpre = x0_at(j_first + 1);
+  DiaCoef<T, 5> c[NC];                             // set of line j_first + s lives in c[s % NC]
+  bool cfull[NC];
+  c[0] = coef_at(j_first);
+#pragma unroll
+  for (int s = 1; s < NC; ++s) c[s] = c[0];
+#pragma unroll
+  for (int s = 0; s < NC; ++s) cfull[s] = false;
+
+  // one line step: x^(k) line jl + 1 arrives, levels 1 .. nact advance by one line (level t: line jl - (t - 1)).
+  // u = (jl - j_first) mod NC names the coefficient sets (folds to constants after unrolling); the LDS slot of a line is its
+  // parity: two lane addresses per step, the rest are immediate offsets.
+  auto do_step = [&](const int jl, const int u, const int nact) {
+    __syncthreads();
+    const int pj = (jl + 64) & 1;
+    T* const row_e = buf + pj * LW + tid;          // lines of the parity of jl:     [0] left, [1] own, [2] right
+    T* const row_o = buf + (1 - pj) * LW + tid;    // lines of the other parity
+    h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
+    row_o[1] = xpre;                               // level 0, line jl + 1
+    xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
+    c[(u + 1) % NC] = coef_at(jl + 1);
+    cfull[u % NC] = __all(c[u % NC].lv && (c[u % NC].m & 0x1f) == 0x1f) != 0;   // (at first use: loaded a step ago)
+    if constexpr (AOS) {
+      const DiaCoef<T, 5>& c0 = c[u % NC];
+      if (jl >= 0 && jl < L && c0.lv && owner) {
+        const int64_t r = (J0 + jl) * dv.S + gi;
+        diag_out[r] = c0.dg;
+        b_out[r] = c0.b;
+      }
+    }
+#pragma unroll
+    for (int t = 1; t <= TS; ++t) {
+      if (t <= nact) {
+        T* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LW;   // level t - 1, line jl - (t - 1)
+        const int ci = ((u - (t - 1)) % NC + NC) % NC;
+        const T xn = update(c[ci], cfull[ci], h[t - 1][0], row[0], h[t - 1][1], row[2], h[t - 1][2]);
+        if (t < TS) {
+          h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
+          row[2 * LW + 1] = xn;                    // level t, same line (same parity)
+        } else if (c[ci].lv && owner) {
+          xo[(J0 + jl - (TS - 1)) * dv.S + gi] = xn;
+        }
+      }
+    }
+  };
+  // ramp-up: step s = jl - j_first < 2 (TS - 1) has levels 1 .. (s + 2) / 2 active (x^(k+t) starts on line -(TS - t))
+#pragma unroll
+  for (int s = 0; s < 2 * (TS - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
+  // steady state: lines 0 .. L - 1 leave the last level, one per step
+  constexpr int u0 = (2 * (TS - 1)) % U;
+#pragma unroll 1
+  for (int jl0 = TS - 1;; jl0 += U) {
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      if (jl0 + q > j_last) return;
+      do_step(jl0 + q, (u0 + q) % U, TS);
+    }
   }
 }
 
@@ -1101,9 +1248,31 @@ bool jacobi_fused_ok(const gla_csr* A) {
          A->dia_row_hi == A->n_rows && A->n_rows == A->n_cols && !(g_tuning.compress && (A->dia_const || A->packed));
 }
 
+// the canonical 5-point pattern jacobi_march5_kernel is written for (option jacobi_march = 0: generic kernel instead)
+inline bool jacobi_canon(const gla_csr* A) { return g_tuning.jacobi_march && gla_dia_canon5(A); }
+
+// workgroups of the march kernel a CU holds at once (registers decide: 5 at TS = 2 ... 2 at TS = 8 in fp64)
+template <typename T, int TS, bool AOS>
+int jacobi_march_blocks_per_cu() {
+  static int cached = 0;
+  if (!cached) {
+    int nb = 0;
+    const size_t lds5 = (size_t)TS * 2 * (GLA_BLOCK + 2) * sizeof(T);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, jacobi_march5_kernel<T, TS, AOS>, GLA_BLOCK, lds5) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = 2;
+    }
+    cached = nb;
+  }
+  return cached;
+}
+
 template <typename T, int TS>
 int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
                         int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr) {
+  constexpr bool generic_ts = TS == 2 || TS == 4 || TS == 5;      // what jacobi_fused_dia2d_kernel is instantiated for
+  const bool canon = jacobi_canon(A);
+  if (!canon && !generic_ts) return GLA_ERR_UNSUPPORTED;
   Dia2D dv;
   dv.val = A->dia_val;
   dv.mask = A->dia_mask;
@@ -1117,14 +1286,18 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   int lines = g_tuning.jacobi_lines;
   if (lines <= 0) {
     // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (TS - 1) coefficient
-    // lines) for which all workgroups are resident at once -- 256 CUs x the waves per SIMD the register budget allows
-    const int64_t slots = 256 * (sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5));
+    // lines) for which all workgroups are resident at once -- 256 CUs x the workgroups per CU the register budget allows
+    int64_t per_cu;
+    if (canon) per_cu = ldva > 0 ? jacobi_march_blocks_per_cu<T, TS, true>() : jacobi_march_blocks_per_cu<T, TS, false>();
+    else per_cu = sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5);
+    const int64_t slots = 256 * per_cu;
     const int64_t blocks = slots / nstrips > 0 ? slots / nstrips : 1;
     int64_t l = (nlines + blocks - 1) / blocks;
     if (l < 2 * TS) l = 2 * TS;                    // (also what the interior / boundary split of the multi-GPU route needs)
     if (l > 1024) l = 1024;
     lines = (int)l;
   }
+  if (lines < 2 * TS && canon) lines = 2 * TS;     // the march kernel's ramp-up assumes nothing else, but keep blocks sane
   const int nlb_all = (int)((nlines + lines - 1) / lines);
   // the interior / boundary split only holds when a block is at least 2 TS lines high (block 1 then reads no x from the
   // first TS lines); otherwise every block counts as boundary
@@ -1142,23 +1315,52 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = count;
   set_tile_mapping(tm);
-  const size_t lds = (size_t)TS * 4 * GLA_BLOCK * sizeof(T);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
-  if (ldva > 0) {                                   // x = the AoS vertex attributes (first pass of gla_jacobi_sweeps_aos)
-    if (A->dia_D <= 5)
-      hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS, true>), grid, block, lds, st, dv, diag, b, x, xo, w, lines,
-                         nstrips, nlines, tm, base0, split, base1, ldva, diag_out, b_out);
+  if (canon) {                                      // register-history march for the canonical 5-point pattern
+    const size_t lds5 = (size_t)TS * 2 * (GLA_BLOCK + 2) * sizeof(T);
+    if (ldva > 0)
+      hipLaunchKernelGGL((jacobi_march5_kernel<T, TS, true>), grid, block, lds5, st, dv, diag, b, x, xo, w, lines, nstrips,
+                         nlines, tm, base0, split, base1, ldva, diag_out, b_out);
     else
-      hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 9, TS, true>), grid, block, lds, st, dv, diag, b, x, xo, w, lines,
-                         nstrips, nlines, tm, base0, split, base1, ldva, diag_out, b_out);
-  } else if (A->dia_D <= 5)
-    hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips,
-                       nlines, tm, base0, split, base1);
-  else
-    hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 9, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips,
-                       nlines, tm, base0, split, base1);
-  GLA_LAUNCH_CHECK();
+      hipLaunchKernelGGL((jacobi_march5_kernel<T, TS>), grid, block, lds5, st, dv, diag, b, x, xo, w, lines, nstrips, nlines,
+                         tm, base0, split, base1);
+    GLA_LAUNCH_CHECK();
+    return GLA_OK;
+  }
+  if constexpr (generic_ts) {
+    const size_t lds = (size_t)TS * 4 * GLA_BLOCK * sizeof(T);
+    if (ldva > 0) {                                   // x = the AoS vertex attributes (first pass of gla_jacobi_sweeps_aos)
+      if (A->dia_D <= 5)
+        hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS, true>), grid, block, lds, st, dv, diag, b, x, xo, w, lines,
+                           nstrips, nlines, tm, base0, split, base1, ldva, diag_out, b_out);
+      else
+        hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 9, TS, true>), grid, block, lds, st, dv, diag, b, x, xo, w, lines,
+                           nstrips, nlines, tm, base0, split, base1, ldva, diag_out, b_out);
+    } else if (A->dia_D <= 5)
+      hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 5, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips,
+                         nlines, tm, base0, split, base1);
+    else
+      hipLaunchKernelGGL((jacobi_fused_dia2d_kernel<T, 9, TS>), grid, block, lds, st, dv, diag, b, x, xo, w, lines, nstrips,
+                         nlines, tm, base0, split, base1);
+    GLA_LAUNCH_CHECK();
+  }
   return GLA_OK;
+}
+
+// run-time sweeps-per-pass -> template (2 .. 8; 3, 6, 7, 8 exist for the canonical 5-point pattern only)
+template <typename T>
+int launch_jacobi_fused_ts(int ts, gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
+                           int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr) {
+  switch (ts) {
+    case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
+    case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
+    case 4: return launch_jacobi_fused<T, 4>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
+    case 5: return launch_jacobi_fused<T, 5>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
+    case 6: return launch_jacobi_fused<T, 6>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
+    case 7: return launch_jacobi_fused<T, 7>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
+    case 8: return launch_jacobi_fused<T, 8>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
+    default: return GLA_ERR_UNSUPPORTED;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1344,24 +1546,29 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
   return GLA_OK;
 }
 
+// the launches of a schedule in order: group g = count[g] launches of sweeps[g] sweeps each
+struct JacobiPlan { int count[4], sweeps[4]; };
+inline int jacobi_plan_launches(const JacobiPlan& p) { return p.count[0] + p.count[1] + p.count[2] + p.count[3]; }
+inline int jacobi_plan_ts(const JacobiPlan& p, int i) {      // sweeps of launch i (0-based)
+  for (int g = 0; g < 4; ++g) { if (i < p.count[g]) return p.sweeps[g]; i -= p.count[g]; }
+  return 1;
+}
+
 template <typename T>
 int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T* Xout, T* Xtmp, T w,
-                             const int steps[4], hipStream_t st) {
-  const int n_launch = steps[0] + steps[1] + steps[2] + steps[3];
+                      const JacobiPlan& plan, hipStream_t st) {
+  const int n_launch = jacobi_plan_launches(plan);
   const T* src = va;
   for (int i = 1; i <= n_launch; ++i) {
     T* dst = ((n_launch - i) % 2 == 0) ? Xout : Xtmp;
-    const int ts = i <= steps[0] ? 5 : (i <= steps[0] + steps[1] ? 4 : (i <= steps[0] + steps[1] + steps[2] ? 2 : 1));
+    const int ts = jacobi_plan_ts(plan, i - 1);
     int rc;
-    if (i == 1) {                                   // reads the AoS rows, writes the contiguous A_ii / b copies
-      if (ts == 5) rc = launch_jacobi_fused<T, 5>(A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
-      else if (ts == 4) rc = launch_jacobi_fused<T, 4>(A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
-      else rc = launch_jacobi_fused<T, 2>(A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
-    } else if (ts > 1) {
-      rc = gla_jacobi_fused(A, sizeof(T) == 8 ? GLA_F64 : GLA_F32, dwork, bwork, src, dst, (double)w, ts, 0, st);
-    } else {
+    if (i == 1)                                     // reads the AoS rows, writes the contiguous A_ii / b copies
+      rc = launch_jacobi_fused_ts<T>(ts, A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
+    else if (ts > 1)
+      rc = launch_jacobi_fused_ts<T>(ts, A, dwork, bwork, src, dst, w, st, 0);
+    else
       rc = gla_jacobi_sweep(A, sizeof(T) == 8 ? GLA_F64 : GLA_F32, 1, dwork, bwork, 1, src, 1, dst, 1, (double)w, 0, st);
-    }
     if (rc) return rc;
     src = dst;
   }
@@ -1411,50 +1618,62 @@ int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void
   })
 }
 
-// launches of 5, 4, 2 and 1 sweeps that gla_jacobi_sweeps uses for n_iters sweeps on contiguous single-rhs operands:
-// the fewest passes over the data, and among those the fewest unfused single sweeps (6 = 4 + 2, not 5 + 1)
-static void jacobi_schedule(gla_csr* A, int dtype, bool contiguous_k1, int n_iters, int steps[4]) {
-  int tmax = 1;
-  if (contiguous_k1 && n_iters >= 2 && A->n_rows > 0 && A->n_rows >= g_tuning.jacobi_min_rows && A->val_dtype == dtype &&
-      (dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A)))
-    tmax = g_tuning.jacobi_fuse == 2 ? 2 : 5;
-  steps[0] = steps[1] = steps[2] = 0;
-  steps[3] = n_iters;
-  if (tmax == 2) { steps[2] = n_iters / 2; steps[3] = n_iters % 2; return; }
-  if (tmax < 5) return;
+// The launches gla_jacobi_sweeps uses for n_iters sweeps on contiguous single-rhs operands.  A pass costs about the same
+// whatever it carries (it is bound by one trip of the matrix through HBM), so: the fewest passes.  Canonical 5-point plans
+// (jacobi_march5_kernel, 2 .. jacobi_ts_max = 8 sweeps per pass): ceil(n / 8) passes of equal size +- 1 (20 = 7 + 7 + 6).
+// Other 2-D stencil plans (jacobi_fused_dia2d_kernel: 5, 4 or 2): the fewest passes, and among those the fewest unfused
+// single sweeps (6 = 4 + 2, not 5 + 1).
+static void jacobi_schedule(gla_csr* A, int dtype, bool contiguous_k1, int n_iters, JacobiPlan& p) {
+  for (int g = 0; g < 4; ++g) { p.count[g] = 0; p.sweeps[g] = 1; }
+  p.count[3] = n_iters;
+  if (!(contiguous_k1 && n_iters >= 2 && A->n_rows > 0 && A->n_rows >= g_tuning.jacobi_min_rows && A->val_dtype == dtype &&
+        (dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A))))
+    return;
+  if (g_tuning.jacobi_fuse == 2) {
+    p.count[2] = n_iters / 2; p.sweeps[2] = 2; p.count[3] = n_iters % 2;
+    return;
+  }
+  if (jacobi_canon(A)) {
+    const int tmax = g_tuning.jacobi_ts_max;
+    const int k = (n_iters + tmax - 1) / tmax, base = n_iters / k, r = n_iters % k;
+    p.count[0] = r; p.sweeps[0] = base + 1;
+    p.count[1] = k - r; p.sweeps[1] = base;
+    p.count[3] = 0;
+    return;
+  }
+  p.sweeps[0] = 5; p.sweeps[1] = 4; p.sweeps[2] = 2;
   int best = 1 << 30;
   for (int a = n_iters / 5; a >= 0 && a >= n_iters / 5 - 3; --a) {
     int rem = n_iters - 5 * a;
     const int b = rem / 4; rem %= 4;
     const int c = rem / 2; rem %= 2;
     const int cost = 2 * (a + b + c + rem) + rem;          // passes first, then single sweeps
-    if (cost < best) { best = cost; steps[0] = a; steps[1] = b; steps[2] = c; steps[3] = rem; }
+    if (cost < best) { best = cost; p.count[0] = a; p.count[1] = b; p.count[2] = c; p.count[3] = rem; }
   }
 }
 
-int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* launches_5_4_2_1_host) {
-  if (!A || n_iters < 0 || !launches_5_4_2_1_host || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
-  jacobi_schedule(A, dtype, true, n_iters, launches_5_4_2_1_host);
+int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* counts4_host, int* sweeps4_host) {
+  if (!A || n_iters < 0 || !counts4_host || !sweeps4_host || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  JacobiPlan p;
+  jacobi_schedule(A, dtype, true, n_iters, p);
+  for (int g = 0; g < 4; ++g) { counts4_host[g] = p.count[g]; sweeps4_host[g] = p.sweeps[g]; }
   return GLA_OK;
 }
 
 int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
                      int sweeps, int part, gla_stream_t stream) {
-  if (!A || !diag || !B || !X || !Xout || X == Xout || (sweeps != 2 && sweeps != 4 && sweeps != 5) || part < 0 || part > 2 ||
+  if (!A || !diag || !B || !X || !Xout || X == Xout || sweeps < 2 || sweeps > 8 || part < 0 || part > 2 ||
       (dtype != GLA_F32 && dtype != GLA_F64))
     return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
   if (A->n_rows == 0) return GLA_OK;
   if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A))) return GLA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == GLA_F64) {
-    if (sweeps == 5) return launch_jacobi_fused<double, 5>(A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st, part);
-    if (sweeps == 4) return launch_jacobi_fused<double, 4>(A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st, part);
-    return launch_jacobi_fused<double, 2>(A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st, part);
-  }
-  if (sweeps == 5) return launch_jacobi_fused<float, 5>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
-  if (sweeps == 4) return launch_jacobi_fused<float, 4>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
-  return launch_jacobi_fused<float, 2>(A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part);
+  if (dtype == GLA_F64)
+    return launch_jacobi_fused_ts<double>(sweeps, A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout,
+                                          (double)w, st, part);
+  return launch_jacobi_fused_ts<float>(sweeps, A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w,
+                                       st, part);
 }
 
 int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, void* diag_work, void* b_work,
@@ -1464,15 +1683,15 @@ int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64
     return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
   if (A->n_rows == 0) return GLA_OK;
-  int steps[4];
-  jacobi_schedule(A, dtype, true, n_iters, steps);
-  if (steps[0] + steps[1] + steps[2] == 0) return GLA_ERR_UNSUPPORTED;      // no fused first pass: split and call gla_jacobi_sweeps
-  if (steps[0] + steps[1] + steps[2] + steps[3] > 1 && !Xtmp) return GLA_ERR_INVALID_ARG;
+  JacobiPlan plan;
+  jacobi_schedule(A, dtype, true, n_iters, plan);
+  if (jacobi_plan_ts(plan, 0) < 2) return GLA_ERR_UNSUPPORTED;              // no fused first pass: split and call gla_jacobi_sweeps
+  if (jacobi_plan_launches(plan) > 1 && !Xtmp) return GLA_ERR_INVALID_ARG;
   if (dtype == GLA_F64)
     return jacobi_sweeps_aos<double>(A, (const double*)vertex_attr, ld, (double*)diag_work, (double*)b_work, (double*)Xout,
-                                     (double*)Xtmp, (double)w, steps, (hipStream_t)stream);
+                                     (double*)Xtmp, (double)w, plan, (hipStream_t)stream);
   return jacobi_sweeps_aos<float>(A, (const float*)vertex_attr, ld, (float*)diag_work, (float*)b_work, (float*)Xout,
-                                  (float*)Xtmp, (float)w, steps, (hipStream_t)stream);
+                                  (float*)Xtmp, (float)w, plan, (hipStream_t)stream);
 }
 
 int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X0,
@@ -1482,17 +1701,17 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
   if (A->n_rows != A->n_cols) return GLA_ERR_INVALID_ARG;
   if (n_iters == 0) return GLA_OK;
   if (!Xout || (n_iters > 1 && !Xtmp) || Xout == Xtmp) return GLA_ERR_INVALID_ARG;
-  // 2-D stencil plans, single right-hand side, contiguous vectors: the sweeps are taken 5, 4 or 2 at a time by the
-  // temporally blocked kernel (the intermediate iterates stay on chip); what is left over runs as an ordinary sweep.
-  // Same arithmetic per row: bit-identical.  Option "jacobi_fuse": 0 off, 1 (default) up to 5, 2 up to 2 per pass.
-  int steps[4];                                    // launches of 5, 4, 2 and 1 sweeps
-  jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && diag && B && X0, n_iters, steps);
-  const int n_launch = steps[0] + steps[1] + steps[2] + steps[3];
+  // 2-D stencil plans, single right-hand side, contiguous vectors: the sweeps are taken several at a time by the temporally
+  // blocked kernels (the intermediate iterates stay on chip; jacobi_schedule); what is left over runs as an ordinary sweep.
+  // Same arithmetic per row: bit-identical.  Option "jacobi_fuse": 0 off, 1 (default), 2 at most two per pass.
+  JacobiPlan plan;
+  jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && diag && B && X0, n_iters, plan);
+  const int n_launch = jacobi_plan_launches(plan);
   const void* src = X0;
   int64_t lds_ = ldx0;
   for (int i = 1; i <= n_launch; ++i) {
     void* dst = ((n_launch - i) % 2 == 0) ? Xout : Xtmp;
-    const int ts = i <= steps[0] ? 5 : (i <= steps[0] + steps[1] ? 4 : (i <= steps[0] + steps[1] + steps[2] ? 2 : 1));
+    const int ts = jacobi_plan_ts(plan, i - 1);
     int rc;
     if (ts > 1)
       rc = gla_jacobi_fused(A, dtype, diag, B, src, dst, w, ts, 0, stream);

@@ -292,7 +292,7 @@ class RowBlockJacobi(RowBlockOps):
     blocks of one GPU).  The ghost rows of the matrix are fetched once at construction, those of b and A_ii once per
     forward().  Same per-row arithmetic: bit-identical to route (1) and to the single-GPU module."""
 
-    TS_MAX = 5
+    TS_MAX = 8                                               # most sweeps a pass carries (gla.h: gla_jacobi_sweeps_schedule)
     ext = None                                               # set by _setup_temporal when the route applies
 
     def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None,
@@ -302,7 +302,7 @@ class RowBlockJacobi(RowBlockOps):
         if temporal and col_blocks is None and self.part.world > 1 and edgeij_pair.is_cuda:
             self._setup_temporal(edgeij_pair, edge_attr)
         if self.ext is not None:
-            self.mode = ("temporally blocked: one ghost-line exchange per pass of 5 (4, 2) sweeps, "
+            self.mode = ("temporally blocked: one ghost-line exchange per pass of up to 8 sweeps, "
                          + ("libgla_hip RCCL all-gather on a side stream, interior / boundary line blocks overlapped"
                             if self.comm is not None else "torch.distributed all-gather (host-ordered)"))
 
@@ -339,7 +339,8 @@ class RowBlockJacobi(RowBlockOps):
         if good:
             plan = CsrPlan(all_ei - elo, ehi - elo, ehi - elo)
             plan.set_values(all_ev)
-            good = int(plan.jacobi_schedule(T, all_ev.dtype)[0] == 1 and int(plan.info.dia_stride) == S)
+            sched = plan.jacobi_schedule(4 * T, all_ev.dtype)
+            good = int(1 < max(sched) <= T and int(plan.info.dia_stride) == S)
             self._sched = plan.jacobi_schedule
         goods = [None] * p.world
         dist.all_gather_object(goods, good, group=p.group)
@@ -414,8 +415,7 @@ class RowBlockJacobi(RowBlockOps):
         outs = (ctypes.c_void_p * 3)(own(d_ext).data_ptr(), own(b_ext).data_ptr(), own(cur).data_ptr())
         check(lib().gla_split_columns(code, nl, 3, ptr(va), va.stride(0) if nl > 1 else 3, outs, st))
         first = True
-        n5, n4, n2, n1 = self._sched(int(n_iters), dt)       # the single-GPU path's launch plan (fewest passes)
-        passes = [5] * n5 + [4] * n4 + [2] * n2 + [1] * n1
+        passes = list(self._sched(int(n_iters), dt))         # the single-GPU path's launch plan (fewest passes)
         spare = nxt
         for i, ts in enumerate(passes):
             if i == len(passes) - 1:                         # the last pass writes into a fresh buffer the caller keeps

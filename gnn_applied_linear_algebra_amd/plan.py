@@ -209,7 +209,7 @@ class CsrPlan:
         if va.stride(1) != 1 or self.n_rows == 0 or int(n_iters) < 2:
             return None
         self._need(va.dtype)
-        if sum(self.jacobi_schedule(n_iters, va.dtype)[:3]) == 0:
+        if self.jacobi_schedule(n_iters, va.dtype)[0] < 2:
             return None
         Xout = torch.empty((self.n_rows, 1), dtype=va.dtype, device=self.device)
         Xtmp = torch.empty_like(Xout)
@@ -219,10 +219,11 @@ class CsrPlan:
         return Xout
 
     def jacobi_schedule(self, n_iters, dtype=torch.float64):
-        """(launches of 5 sweeps, of 4, of 2, of 1) gla_jacobi_sweeps uses for n_iters sweeps on one contiguous rhs."""
-        out = (ctypes.c_int * 4)()
-        check(lib().gla_jacobi_sweeps_schedule(self._h, dtype_code(dtype), int(n_iters), out))
-        return tuple(out)
+        """Sweeps per launch, in launch order, that gla_jacobi_sweeps uses for n_iters sweeps on one contiguous rhs:
+        (7, 7, 6) for 20 sweeps on a canonical 5-point plan, (5, 5, 5, 5) on other 2-D stencils, (1,) * 20 unfused."""
+        counts, sweeps = (ctypes.c_int * 4)(), (ctypes.c_int * 4)()
+        check(lib().gla_jacobi_sweeps_schedule(self._h, dtype_code(dtype), int(n_iters), counts, sweeps))
+        return tuple(ts for c, ts in zip(counts, sweeps) for _ in range(c))
 
     @_on_device
     def cheby_first(self, B, X, R, P, Xout, alpha, which=ALL_TILES):

@@ -1056,10 +1056,12 @@ def test_dia_layout_bit_identical():
 
 
 def test_jacobi_temporal_blocking_bit_identical():
-    """gla_jacobi_sweeps on 2-D stencil plans takes the sweeps five, four or two at a time (temporal blocking: the
-    intermediate iterates stay in LDS, the matrix is read once per pass).  Same per-row arithmetic: bit-identical to
-    single sweeps for every sweep count (5 / 4 / 2 / 1 combinations), block height, 5- and 9-point stencils, grids that are
-    not multiples of the strip width or narrower than a strip, fp64 and fp32."""
+    """gla_jacobi_sweeps on 2-D stencil plans takes several sweeps per pass (temporal blocking: the intermediate iterates
+    stay on chip, the matrix is read once per pass): 2 .. 8 on the canonical 5-point pattern (jacobi_march5_kernel), 5 / 4 /
+    2 on other stencils (jacobi_fused_dia2d_kernel).  Same per-row arithmetic: bit-identical to single sweeps for every
+    sweep count (all pass sizes and their combinations), block height, both kernels on the 5-point pattern, a 5-point
+    pattern with holes (masked rows inside full waves), 9-point stencils, grids that are not multiples of the strip width
+    or narrower than a strip, fp64 and fp32."""
     default_layout_only()
     from gnn_applied_linear_algebra_amd._lib import lib, check
     cases = []
@@ -1067,46 +1069,63 @@ def test_jacobi_temporal_blocking_bit_identical():
     cases.append(("laplacian 300^2", ei, ev, 90000))
     ei, ev = rp.laplacianfun_torch(50, 33)                                   # 33 lines of 50 points
     cases.append(("laplacian 50 x 33", ei, ev, 1650))
-    ei, ev = rp.laplacianfun_torch(1000, 9)                                  # 4 strips, fewer lines than a block
+    ei, ev = rp.laplacianfun_torch(1000, 9)                                  # 5 strips, fewer lines than a block
     cases.append(("laplacian 1000 x 9", ei, ev, 9000))
     ei, ev = rp.heateqnfem2dfun([71, 59], [1.0, 4.0])
     cases.append(("fem 9-point 70 x 58", ei, ev, 70 * 58))
     gen = torch.Generator().manual_seed(21)
     ei, ev = rp.laplacianfun_torch(64)
     cases.append(("random values on the 5-point pattern", ei, torch.rand(ei.shape[1], 1, generator=gen, dtype=torch.float64) - 0.3, 4096))
+    ei, ev = _stencil_matrix(300, 40, [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)], gen, 0.2)
+    cases.append(("5-point pattern with holes", ei, ev, 12000))
+    options = ("jacobi_fuse", "jacobi_lines", "jacobi_march", "jacobi_ts_max")
+    defaults = (1, 0, 1, 8)
     for name, ei, ev, n in cases:
         for dtype in (torch.float64, torch.float32):
             plan = gla.CsrPlan(d(ei), n)
             plan.set_values(d(ev.to(dtype)))
             assert plan.info.dia in (5, 9), name
+            canon = bool(plan.info.dia_canon5)
+            assert canon == (plan.info.dia == 5), name
+            assert plan.jacobi_schedule(20, dtype) == ((7, 7, 6) if canon else (5, 5, 5, 5)), name
+            assert plan.jacobi_schedule(9, dtype) == ((5, 4) if canon else (5, 4)), name
+            assert plan.jacobi_schedule(3, dtype) == ((3,) if canon else (2, 1)), name
             g2 = torch.Generator().manual_seed(n)
             b = d(torch.rand(n, 1, generator=g2, dtype=torch.float64).to(dtype))
             x = d(torch.rand(n, 1, generator=g2, dtype=torch.float64).to(dtype))
             diag = d((torch.rand(n, generator=g2, dtype=torch.float64) + 3.0).to(dtype))
-            for its in (1, 2, 3, 5, 6, 7, 13, 20):
+            for its in (1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 20, 23):
                 try:
                     check(lib().gla_set_option(b"jacobi_fuse", 0))
                     want = plan.jacobi_sweeps(diag, b, x, 0.7, its)
                 finally:
                     check(lib().gla_set_option(b"jacobi_fuse", 1))
-                for fuse, lines in ((1, 64), (1, 5), (2, 32), (2, 3)):
+                variants = [(1, 64, 1, 8), (1, 5, 1, 8), (1, 64, 0, 8), (1, 5, 0, 8), (2, 32, 1, 8), (2, 3, 0, 8)]
+                if canon:
+                    variants += [(1, 0, 1, 3), (1, 17, 1, 4), (1, 0, 1, 6)]
+                for var in variants:
                     try:
-                        check(lib().gla_set_option(b"jacobi_fuse", fuse))
-                        check(lib().gla_set_option(b"jacobi_lines", lines))
+                        for o, v in zip(options, var):
+                            check(lib().gla_set_option(o.encode(), v))
                         got = plan.jacobi_sweeps(diag, b, x, 0.7, its)
                     finally:
-                        check(lib().gla_set_option(b"jacobi_fuse", 1))
-                        check(lib().gla_set_option(b"jacobi_lines", 0))
-                    assert torch.equal(got, want), (name, dtype, its, fuse, lines, float((got - want).abs().max()))
+                        for o, v in zip(options, defaults):
+                            check(lib().gla_set_option(o.encode(), v))
+                    assert torch.equal(got, want), (name, dtype, its, var, float((got - want).abs().max()))
                 # the AoS entry point (first pass reads [A_ii, b, x] rows itself): packed rows and rows of a wider tensor
                 va = torch.stack([diag, b.reshape(-1), x.reshape(-1)], 1)
                 wide = torch.zeros(n, 5, dtype=dtype, device=DEV)
                 wide[:, 1:4] = va
                 for vattr in (va, wide[:, 1:4]):
-                    got = plan.jacobi_sweeps_aos(vattr, 0.7, its)
-                    assert (got is None) == (its < 2), its
-                    if got is not None:
-                        assert torch.equal(got, want), (name, dtype, its, "aos", vattr.stride())
+                    for march in ((1, 0) if canon else (1,)):
+                        try:
+                            check(lib().gla_set_option(b"jacobi_march", march))
+                            got = plan.jacobi_sweeps_aos(vattr, 0.7, its)
+                        finally:
+                            check(lib().gla_set_option(b"jacobi_march", 1))
+                        assert (got is None) == (its < 2), its
+                        if got is not None:
+                            assert torch.equal(got, want), (name, dtype, its, "aos", march, vattr.stride())
 
 
 def _stencil_matrix(Nx, Ny, offsets_ab, gen, holes=0.0):
@@ -1181,7 +1200,7 @@ def test_generic_stencils_blocked_and_fused_kernels():
         # (the reading off = a*S + b need not be unique: the skewed pattern -33, -32, -1, 0, 1, 32, 33 reads with S = 32 as
         # well as with the grid's 33 -- but only with 33 does no entry leave its grid line, which plan creation checks)
         assert info.dia == len(offs) and info.dia_stride == Nx and (info.dia_A, info.dia_B) == (A_, B_), (name, info.dia, info.dia_stride, info.dia_A, info.dia_B)
-        fused = plan.jacobi_schedule(5)[0] == 1
+        fused = plan.jacobi_schedule(5) == (5,)
         assert fused == (A_ == 1 and B_ <= 2), (name, fused)        # the fused Jacobi kernel takes A = 1, B <= 2
         for i_, (a_, w_) in enumerate(zip(got, want)):
             assert torch.equal(a_, w_), (name, i_, float((a_ - w_).abs().max()))
@@ -1247,14 +1266,19 @@ def test_jacobi_fusion_size_threshold():
     ei, ev = gla.UtilsGNN.laplacianfun_torch(300, device=DEV)
     plan = gla.CsrPlan(ei, 90000)
     plan.set_values(ev)
-    assert plan.jacobi_schedule(20) == (4, 0, 0, 0)               # the test session runs with jacobi_min_rows = 0
+    assert plan.jacobi_schedule(20) == (7, 7, 6)                  # the test session runs with jacobi_min_rows = 0
     try:
         check(lib().gla_set_option(b"jacobi_min_rows", 1 << 20))
-        assert plan.jacobi_schedule(20) == (0, 0, 0, 20)
+        assert plan.jacobi_schedule(20) == (1,) * 20
         ei2, ev2 = gla.UtilsGNN.laplacianfun_torch(1024, device=DEV)
         plan2 = gla.CsrPlan(ei2, 1 << 20)
         plan2.set_values(ev2)
-        assert plan2.jacobi_schedule(20) == (4, 0, 0, 0) and plan2.jacobi_schedule(6) == (0, 1, 1, 0)
+        assert plan2.jacobi_schedule(20) == (7, 7, 6) and plan2.jacobi_schedule(6) == (6,) and plan2.jacobi_schedule(16) == (8, 8)
+        try:
+            check(lib().gla_set_option(b"jacobi_march", 0))
+            assert plan2.jacobi_schedule(20) == (5, 5, 5, 5) and plan2.jacobi_schedule(6) == (4, 2)
+        finally:
+            check(lib().gla_set_option(b"jacobi_march", 1))
     finally:
         check(lib().gla_set_option(b"jacobi_min_rows", 0))
 
