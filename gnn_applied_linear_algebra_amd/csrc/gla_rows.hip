@@ -1288,7 +1288,12 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (TS - 1) coefficient
     // lines) for which all workgroups are resident at once -- 256 CUs x the workgroups per CU the register budget allows
     int64_t per_cu;
-    if (canon) per_cu = ldva > 0 ? jacobi_march_blocks_per_cu<T, TS, true>() : jacobi_march_blocks_per_cu<T, TS, false>();
+    if (canon) {
+      // measured (tools/ab_jacobi_march.py): two workgroups per CU beat three or four even where the registers allow more
+      // (TS = 5: 252 vs 315 us) -- fewer, longer streams, less overlap between blocks; one per CU cannot hide a line step
+      per_cu = ldva > 0 ? jacobi_march_blocks_per_cu<T, TS, true>() : jacobi_march_blocks_per_cu<T, TS, false>();
+      if (per_cu > 2) per_cu = 2;
+    }
     else per_cu = sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5);
     const int64_t slots = 256 * per_cu;
     const int64_t blocks = slots / nstrips > 0 ? slots / nstrips : 1;
