@@ -458,7 +458,7 @@ def single_gpu(args, gla, dev):
         out["config3_k16"] = {
             "what": f"BASELINE config 3 through the module surface, {Nx}^2 Laplacian, K=16 right-hand sides, fp64",
             "note": "ChebyRelaxGNN(4) runs as ONE temporally blocked pass (gla_cheby_fused: b, x in; x, r, p out), so "
-                    "SURVEY's per-step byte model can read above the HBM peak; the power method needs a global norm "
+                    "SURVEY's per-step byte model reads above the HBM peak (the pass moves b, x in and x, r, p out once: 11.4 GB); the power method needs a global norm "
                     "between its iterations and stays one fused kernel per iteration",
             "cheby_deg4_ms": round(tc * 1e3, 3), "cheby_GBps": round(Bc / tc / 1e9, 1),
             "cheby_frac": round(Bc / tc / HBM_PEAK, 4), "cheby_algorithmic_bytes": Bc,

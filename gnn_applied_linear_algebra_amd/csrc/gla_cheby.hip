@@ -30,7 +30,7 @@ struct Cheb2D {
 };
 
 template <typename T>
-struct ChCoef { T v[CH_DMAX]; int m, lv; };        // one row's diagonal values, mask as loaded (untouched until its first
+struct ChCoef { T v[CH_DMAX]; int m, lv, pad_; };        // one row's diagonal values, mask as loaded (untouched until its first
                                                    // use, so that the load stays in flight across the line step), row exists
 
 template <typename T, int KV, int DEG>
@@ -160,6 +160,164 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_fused_dia2d_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pass for the canonical 5-point pattern (diagonals (-1,0) (0,-1) (0,0) (0,1) (1,0), B = 1), organised like
+// jacobi_march5_kernel (gla_rows.hip): the j -/+ 1 neighbours and the centre of the operand a step gathers are the lane's
+// OWN values of the last three line steps (registers, h[t][0..2]); LDS only carries the i -/+ 1 neighbours -- one padded
+// line per step and line parity, one 16-byte write + two 16-byte reads per update -- and since a step reads what the step
+// below wrote one line step EARLIER there is ONE barrier per line step; the line loop is unrolled over the DEG + 1
+// coefficient sets (static names, no register rotation); a wave whose rows all carry the full pattern skips the mask
+// selects.  Same arithmetic per (row, rhs) as the kernel above and as the step-by-step epilogues: bit-identical.
+// Rows above a step's first valid line carry garbage through the first line steps; it never reaches a stored value
+// (step t is valid from line -(DEG - t) on, and a valid line only reads valid lines of the step below).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int KV, int DEG>
+__global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
+    Cheb2D cv, const T* __restrict__ bvec, int64_t ldb, const T* __restrict__ x0, int64_t ldx0, T* __restrict__ xout,
+    int64_t ldxo, T* __restrict__ rout, int64_t ldr, T* __restrict__ pout, int64_t ldp, T* __restrict__ pprev,
+    int64_t ldpp, T* __restrict__ bcopy, int64_t ldbc, int lines, int nstrips, int64_t nlines, TileMap tm) {
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int BP = GLA_BLOCK / KV;               // grid points of a strip
+  constexpr int LWV = (BP + 2) * KV;               // 16-byte vectors of a line in LDS: point ii at [(1 + ii) * KV + q]
+  constexpr int NC = DEG + 1, U = NC;
+  typedef T TV __attribute__((ext_vector_type(VW)));
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  TV* buf = reinterpret_cast<TV*>(smem_raw);       // [DEG][2][LWV]: buf[t][p] = latest line of parity p of the operand of step t + 1
+  const int blk = map_tile(tm);
+  if (blk < 0) return;
+  constexpr int halo = DEG, bp_eff = BP - 2 * halo;
+  const int lb = blk / nstrips, strip = blk - lb * nstrips;
+  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bp_eff - halo;
+  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int tid = threadIdx.x, ii = tid / KV, q = tid % KV;
+  const T* __restrict__ val = static_cast<const T*>(cv.val);
+  const int64_t gi = P0 + ii;
+  const bool in_i = gi >= 0 && gi < cv.S;
+  const bool interior = ii >= halo && ii < BP - halo;
+
+  auto live_row = [&](int jl, int64_t& r) -> bool {
+    const int64_t gj = J0 + jl;
+    r = gj * cv.S + gi;
+    return in_i && gj >= 0 && gj < nlines && r < cv.n_rows;
+  };
+  auto x0_at = [&](int jl) -> TV {                 // clamped: values of dead rows are never used
+    int64_t flat = (J0 + jl) * cv.S + gi;
+    flat = min(max(flat, (int64_t)0), cv.n_cols - 1);
+    return ldv<TV>(x0 + flat * ldx0 + q * VW);
+  };
+  auto b_at = [&](int jl) -> TV {
+    int64_t r;
+    const bool live = live_row(jl, r);
+    return ldv<TV>(bvec + (live ? r : 0) * ldb + q * VW);
+  };
+  auto coef_at = [&](int jl) -> ChCoef<T> {
+    int64_t r;
+    const bool live = live_row(jl, r);
+    const int64_t rc = live ? r : 0;
+    ChCoef<T> c;
+#pragma unroll
+    for (int d = 0; d < CH_DMAX; ++d) c.v[d] = val[(int64_t)d * cv.n_rows + rc];
+    c.m = (int)cv.mask[rc];
+    c.lv = live;
+    return c;
+  };
+  auto stencil = [&](const ChCoef<T>& c, bool full, TV up, TV left, TV ctr, TV right, TV down) -> TV {
+    TV acc = TV(T(0));
+    if (full) {
+      acc = acc + c.v[0] * up;
+      acc = acc + c.v[1] * left;
+      acc = acc + c.v[2] * ctr;
+      acc = acc + c.v[3] * right;
+      acc = acc + c.v[4] * down;
+    } else {
+      const TV xs[5] = {up, left, ctr, right, down};
+      const int m = c.lv ? c.m : 0;
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const TV nxt = acc + c.v[d] * xs[d];
+        acc = ((m >> d) & 1) ? nxt : acc;
+      }
+    }
+    return acc;
+  };
+
+  constexpr int j_first = -(DEG - 1);
+  const int j_last = L - 1 + (DEG - 1);
+  TV h[DEG][3];                                    // h[t]: the operand of step t + 1 (x for t = 0, p_t after) of this lane on
+#pragma unroll                                     // the last three lines it was produced on
+  for (int t = 0; t < DEG; ++t) h[t][0] = h[t][1] = h[t][2] = TV(T(0));
+  h[0][1] = x0_at(j_first - 1);
+  h[0][2] = x0_at(j_first);
+  buf[((j_first + 64) & 1) * LWV + (1 + ii) * KV + q] = h[0][2];
+  TV xpre = x0_at(j_first + 1), bq = b_at(j_first);
+  ChCoef<T> c[NC];                                 // set of line j_first + s lives in c[s % NC]
+  bool cfull[NC];
+  c[0] = coef_at(j_first);
+#pragma unroll
+  for (int s = 1; s < NC; ++s) c[s] = c[0];
+#pragma unroll
+  for (int s = 0; s < NC; ++s) cfull[s] = false;
+  TV cr[DEG], cx[DEG];                             // r and x step t left for this lane's row one line step ago
+#pragma unroll
+  for (int t = 0; t < DEG; ++t) cr[t] = cx[t] = TV(T(0));
+
+  auto do_step = [&](const int jl, const int u) {
+    __syncthreads();
+    const int pj = (jl + 64) & 1;
+    TV* const row_e = buf + pj * LWV + ii * KV + q;          // lines of the parity of jl: [0] left, [KV] own, [2 KV] right
+    TV* const row_o = buf + (1 - pj) * LWV + ii * KV + q;    // lines of the other parity
+    h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
+    row_o[KV] = xpre;                              // x, line jl + 1
+    const TV bnow = bq;                            // b of line jl (loaded a step ago)
+    xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
+    bq = b_at(jl + 1);
+    c[(u + 1) % NC] = coef_at(jl + 1);
+    cfull[u % NC] = __all(c[u % NC].lv && (c[u % NC].m & 0x1f) == 0x1f) != 0;   // (at first use: loaded a step ago)
+    TV in_r = TV(T(0)), in_x = TV(T(0));
+#pragma unroll
+    for (int t = 1; t <= DEG; ++t) {
+      const int line = jl - (t - 1);
+      TV* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LWV;   // operand of step t, line `line`
+      const int ci = ((u - (t - 1)) % NC + NC) % NC;
+      const TV use_r = in_r, use_x = in_x;         // what step t - 1 left for THIS row one line step ago
+      if (t < DEG) { in_r = cr[t]; in_x = cx[t]; } // keep step t's previous results for step t + 1 before overwriting them
+      const TV acc = stencil(c[ci], cfull[ci], h[t - 1][0], row[0], h[t - 1][1], row[2 * KV], h[t - 1][2]);
+      int64_t r;
+      const bool store_ok = live_row(line, r) && interior && line >= 0 && line < L;
+      TV ri, pn, xn;
+      if (t == 1) {                                // EpiChebyFirst: r = b - A x; p = r; x = x + alpha_1 r
+        if (bcopy && store_ok) stv<TV>(bcopy + r * ldbc + q * VW, bnow);
+        ri = bnow - acc;
+        pn = ri;
+        xn = h[0][1] + (T)cv.alpha[0] * ri;
+      } else {                                     // EpiChebyNext: r -= a_old (A p); p = r + beta p; x += a_new p
+        ri = use_r - (T)cv.alpha[t - 2] * acc;
+        pn = ri + (T)cv.beta[t - 1] * h[t - 1][1];
+        xn = use_x + (T)cv.alpha[t - 1] * pn;
+      }
+      if (t < DEG) {
+        h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = pn;
+        row[2 * LWV + KV] = pn;                    // operand of step t + 1, same line (same parity)
+        cr[t] = ri;
+        cx[t] = xn;
+        if (t == DEG - 1 && pprev && store_ok) stv<TV>(pprev + r * ldpp + q * VW, pn);   // the operand the last step gathers
+      } else if (store_ok) {
+        stv<TV>(xout + r * ldxo + q * VW, xn);
+        stv<TV>(rout + r * ldr + q * VW, ri);
+        stv<TV>(pout + r * ldp + q * VW, pn);
+      }
+    }
+  };
+#pragma unroll 1
+  for (int jl0 = j_first;; jl0 += U) {
+#pragma unroll
+    for (int qq = 0; qq < U; ++qq) {
+      if (jl0 + qq > j_last) return;
+      do_step(jl0 + qq, qq);
+    }
+  }
+}
+
 template <typename T, int KV, int DEG>
 int launch_cheby_fused(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout,
                        int64_t ldxo, T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc,
@@ -169,23 +327,25 @@ int launch_cheby_fused(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, co
   if (bp_eff < 1) return GLA_ERR_UNSUPPORTED;
   const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
   const int nstrips = (int)((A->dia_S + bp_eff - 1) / bp_eff);
-  const size_t lds = (size_t)DEG * 3 * BP * KV * 16;
-  // block height: all workgroups resident at once (LDS: 12 KB per fused step and workgroup; registers: 3 waves per SIMD)
+  const bool canon = g_tuning.jacobi_march && gla_dia_canon5(A);
+  const size_t lds = canon ? (size_t)DEG * 2 * (BP + 2) * KV * 16 : (size_t)DEG * 3 * BP * KV * 16;
+  // block height: all workgroups resident at once (LDS: 12 KB per fused step and workgroup; registers: 3 waves per SIMD;
+  // the march kernel: two workgroups per CU, as for the Jacobi march)
   int lines = g_tuning.jacobi_lines;
   if (lines <= 0) {
-    const int64_t per_cu = std::min<int64_t>(3, (160 * 1024) / (int64_t)lds);
-    const int64_t slots = 256 * (per_cu > 0 ? per_cu : 1);
-    const int64_t blocks = slots / nstrips > 0 ? slots / nstrips : 1;
-    int64_t l = (nlines + blocks - 1) / blocks;
-    if (l < 2 * DEG) l = 2 * DEG;
-    lines = (int)std::min<int64_t>(l, 1 << 20);
+    const int64_t per_cu = canon ? 2 : std::min<int64_t>(3, (160 * 1024) / (int64_t)lds);
+    lines = gla_pick_block_lines(nlines, nstrips, 256 * (per_cu > 0 ? per_cu : 1), 2 * (DEG - 1), 2 * DEG);
   }
   TileMap tm;
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
   set_tile_mapping(tm);
-  hipLaunchKernelGGL((cheby_fused_dia2d_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
-                     st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
+  if (canon)
+    hipLaunchKernelGGL((cheby_march5_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
+                       st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
+  else
+    hipLaunchKernelGGL((cheby_fused_dia2d_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
+                       st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }

@@ -75,10 +75,29 @@ struct gla_tuning {
   int jacobi_lines = 0;     // grid lines a workgroup of the fused kernel marches through (0 = one resident round of workgroups)
   int jacobi_ts_max = 8;    // canonical 5-point plans: most sweeps per pass (2 .. 8)
   int jacobi_march = 1;     // canonical 5-point plans: 1 = the register-history march kernel, 0 = the generic LDS-ring kernel
-  int64_t jacobi_min_rows = 1 << 20;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
-                                       // is faster: a 768^2 grid takes 9 us per sweep either way, a 512^2 grid 5 vs 9 us)
+  int64_t jacobi_min_rows = 1 << 19;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
+                                       // is faster: 512^2 takes 4.5 us per sweep single vs 5.9 fused, 768^2 8.4 vs 6.0)
 };
 extern gla_tuning g_tuning;
+
+// Grid lines per workgroup of a line-marching kernel (temporally blocked Jacobi / Chebyshev): `nstrips` strips side by side,
+// `slots` workgroups resident on the chip at once, `ramp` extra line steps every block pays.  One resident round of
+// workgroups when that fills the chip (fewest blocks, least overlap); when the strip count quantises badly (171 strips on 512
+// slots: 342 or 513 workgroups) several rounds of shorter blocks.  Cost model: rounds x (lines + ramp).
+inline int gla_pick_block_lines(int64_t nlines, int64_t nstrips, int64_t slots, int ramp, int min_lines) {
+  int64_t best_cost = -1, best_l = nlines;
+  for (int rounds = 1; rounds <= 8; ++rounds) {
+    int64_t blocks = rounds * slots / nstrips;
+    if (blocks < 1) blocks = 1;
+    int64_t l = (nlines + blocks - 1) / blocks;
+    if (l < min_lines) l = min_lines;
+    const int64_t nb = (nlines + l - 1) / l;
+    const int64_t r = (nb * nstrips + slots - 1) / slots;
+    const int64_t cost = r * (l + ramp);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_l = l; }
+  }
+  return (int)(best_l > (1 << 20) ? (1 << 20) : best_l);
+}
 
 // the 2-D reading is the canonical 5-point pattern: diagonals (-1,0) (0,-1) (0,0) (0,1) (1,0) in this order
 inline bool gla_dia_canon5(const gla_csr* A) {

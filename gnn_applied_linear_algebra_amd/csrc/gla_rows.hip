@@ -1295,12 +1295,8 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
       if (per_cu > 2) per_cu = 2;
     }
     else per_cu = sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5);
-    const int64_t slots = 256 * per_cu;
-    const int64_t blocks = slots / nstrips > 0 ? slots / nstrips : 1;
-    int64_t l = (nlines + blocks - 1) / blocks;
-    if (l < 2 * TS) l = 2 * TS;                    // (also what the interior / boundary split of the multi-GPU route needs)
-    if (l > 1024) l = 1024;
-    lines = (int)l;
+    lines = gla_pick_block_lines(nlines, nstrips, 256 * per_cu, 2 * (TS - 1), 2 * TS);   // (2 TS lines at least: also what the
+    if (lines > 1024) lines = 1024;                                                       // multi-GPU interior / boundary split needs)
   }
   if (lines < 2 * TS && canon) lines = 2 * TS;     // the march kernel's ramp-up assumes nothing else, but keep blocks sane
   const int nlb_all = (int)((nlines + lines - 1) / lines);

@@ -153,7 +153,7 @@ int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64
  * other stencils 5, 4 or 2 (20 = 4 x 5, 6 = 4 + 2).  Options: "jacobi_fuse" 0 off, 1 default, 2 at most two per pass;
  * "jacobi_ts_max" most sweeps per pass on canonical plans (2 .. 8, default 8); "jacobi_march" 0 = canonical plans use the
  * generic stencil kernel too; "jacobi_lines" grid lines per workgroup, 0 = automatic; "jacobi_min_rows": matrices with
- * fewer rows, default 2^20, keep one sweep per launch, which is faster there.
+ * fewer rows, default 2^19, keep one sweep per launch, which is faster there.
  * This reports the launches gla_jacobi_sweeps will use for n_iters sweeps, in order: counts4_host[g] launches of
  * sweeps4_host[g] sweeps each, g = 0 .. 3 (unused groups have count 0). */
 int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* counts4_host, int* sweeps4_host);

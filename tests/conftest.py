@@ -9,7 +9,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 sys.dont_write_bytecode = True
-# gla_jacobi_sweeps only fuses sweeps (temporal blocking) on matrices of >= 2^20 rows, where it wins; the parity tests use
+# gla_jacobi_sweeps only fuses sweeps (temporal blocking) on matrices of >= 2^19 rows, where it wins; the parity tests use
 # small grids, so the threshold is lifted for every test process (the spawned multi-rank workers inherit the environment)
 _opts = os.environ.get("GLA_OPTIONS", "")
 if "jacobi_min_rows" not in _opts:

@@ -1260,7 +1260,7 @@ def test_cheby_fused_pass_bit_identical():
 
 
 def test_jacobi_fusion_size_threshold():
-    """Below option jacobi_min_rows (default 2^20 rows) gla_jacobi_sweeps keeps one sweep per launch (faster there)."""
+    """Below option jacobi_min_rows (default 2^19 rows) gla_jacobi_sweeps keeps one sweep per launch (faster there)."""
     default_layout_only()
     from gnn_applied_linear_algebra_amd._lib import lib, check
     ei, ev = gla.UtilsGNN.laplacianfun_torch(300, device=DEV)
