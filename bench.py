@@ -138,9 +138,12 @@ def launch(args, argv):
         out0 = procs[0].stdout.read()
     except Exception:
         out0 = ""
-    if out0:
-        sys.stdout.write(out0)
-        sys.stdout.flush()
+    for line in (out0 or "").splitlines():                # stdout carries the JSON line only; anything else a library
+        if line.lstrip().startswith("{"):                 # printed there (gloo's connection banner) goes to stderr
+            sys.stdout.write(line + "\n")
+        else:
+            sys.stderr.write(line + "\n")
+    sys.stdout.flush()
     worst = 0
     for rc in rcs:
         if rc:
@@ -298,7 +301,7 @@ def single_gpu(args, gla, dev):
     B_launch = pr.B * spl                                    # per-sweep bytes x the sweeps of one launch
     fused = spl > 1
     march = fused and bool(info.dia_canon5) and plan.jacobi_schedule(3) == (3,)      # (3 per pass: march kernel only)
-    kname = ((f"jacobi_march5_kernel<double,{spl}>" if march else
+    kname = ((f"jacobi_march{5 if int(info.dia_canon5) == 1 else 9}_kernel<double,{spl}>" if march else
               f"jacobi_fused_dia2d_kernel<double,{5 if int(info.dia) <= 5 else 9},{spl}>") if fused else
              "spmv_stream_vec2_kernel<double,EpiJacobi>")
     roof = {"bound": "hbm", "achieved": round(B_launch / t_launch / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -74,11 +74,20 @@ struct gla_tuning {
   int jacobi_fuse = 1;      // gla_jacobi_sweeps on 2-D stencil plans: 0 one sweep per pass, 1 up to four (temporal blocking), 2 up to two
   int jacobi_lines = 0;     // grid lines a workgroup of the fused kernel marches through (0 = one resident round of workgroups)
   int jacobi_ts_max = 8;    // canonical 5-point plans: most sweeps per pass (2 .. 8)
+  int jacobi_ts_max9 = 5;   // canonical 9-point plans: most sweeps per pass (2 .. 6)
   int jacobi_march = 1;     // canonical 5-point plans: 1 = the register-history march kernel, 0 = the generic LDS-ring kernel
   int64_t jacobi_min_rows = 1 << 19;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
                                        // is faster: 512^2 takes 4.5 us per sweep single vs 5.9 fused, 768^2 8.4 vs 6.0)
 };
 extern gla_tuning g_tuning;
+
+// ... or the canonical 9-point pattern (the Q1 FEM operator): all (a, b) in {-1, 0, 1}^2, row-major
+inline bool gla_dia_canon9(const gla_csr* A) {
+  if (A->dia_state != 1 || A->dia_S <= 0 || A->dia_D != 9 || A->dia_A != 1 || A->dia_B != 1) return false;
+  for (int d = 0; d < 9; ++d)
+    if (A->dia_a[d] != d / 3 - 1 || A->dia_b[d] != d % 3 - 1) return false;
+  return true;
+}
 
 // Grid lines per workgroup of a line-marching kernel (temporally blocked Jacobi / Chebyshev): `nstrips` strips side by side,
 // `slots` workgroups resident on the chip at once, `ramp` extra line steps every block pays.  One resident round of

@@ -736,6 +736,7 @@ int gla_set_option(const char* name, int64_t value) {
   if (!strcmp(name, "jacobi_fuse")) { if (value < 0 || value > 2) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_fuse = (int)value; return GLA_OK; }
   if (!strcmp(name, "jacobi_min_rows")) { if (value < 0) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_min_rows = value; return GLA_OK; }
   if (!strcmp(name, "jacobi_ts_max")) { if (value < 2 || value > 8) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_ts_max = (int)value; return GLA_OK; }
+  if (!strcmp(name, "jacobi_ts_max9")) { if (value < 2 || value > 6) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_ts_max9 = (int)value; return GLA_OK; }
   if (!strcmp(name, "jacobi_march")) { g_tuning.jacobi_march = (int)value; return GLA_OK; }
   if (!strcmp(name, "jacobi_lines")) { if (value < 0 || value == 1 || value > 4096) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_lines = (int)value; return GLA_OK; }
   if (!strcmp(name, "compress")) { g_tuning.compress = value ? 1 : 0; return GLA_OK; }
@@ -983,7 +984,7 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->dia_row_hi = info->dia ? p->dia_row_hi : 0;
   info->dia_A = info->dia ? p->dia_A : 0;
   info->dia_B = info->dia ? p->dia_B : 0;
-  info->dia_canon5 = info->dia && gla_dia_canon5(p) ? 1 : 0;
+  info->dia_canon5 = info->dia && gla_dia_canon5(p) ? 1 : (info->dia && gla_dia_canon9(p) ? 9 : 0);
   return GLA_OK;
 }
 

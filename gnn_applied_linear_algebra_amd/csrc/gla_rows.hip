@@ -1241,6 +1241,143 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The march for the canonical 9-point pattern (diagonals (-1,-1) (-1,0) (-1,1) (0,-1) (0,0) (0,1) (1,-1) (1,0) (1,1): the Q1
+// FEM operator of heateqnfem2dfun).  As jacobi_march5_kernel -- own column of every level in registers, static coefficient
+// set names, wave-uniform full-pattern fast path -- but a row also needs the i -/+ 1 neighbours of the line BELOW, which the
+// level underneath produces in the same line step: three lines per level in LDS (slot = line mod 3), one barrier per level
+// and line step, three ds_read2 per update.  Same arithmetic as spmv_dia_kernel + EpiJacobi: bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TS, bool AOS = false>
+__global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, const T* __restrict__ diag,
+                                                                  const T* __restrict__ bvec, const T* __restrict__ x,
+                                                                  T* __restrict__ xo, T w, int lines, int nstrips,
+                                                                  int64_t nlines, TileMap tm, int tile_base0, int tile_split,
+                                                                  int tile_base1, int64_t ldva = 1,
+                                                                  T* __restrict__ diag_out = nullptr,
+                                                                  T* __restrict__ b_out = nullptr) {
+  constexpr int BW = GLA_BLOCK, LW = BW + 2;      // a line in LDS: lane tid at [1 + tid], one pad either side
+  constexpr int NC = TS + 1, U = NC;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* buf = reinterpret_cast<T*>(smem_raw);        // [TS][3][LW]: buf[t][s] = line of x^(k+t) with line mod 3 == s
+  const int slot = map_tile(tm);
+  if (slot < 0) return;
+  const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
+  constexpr int halo = TS, bi_eff = BW - 2 * halo;
+  const int lb = blk / nstrips, strip = blk - lb * nstrips;
+  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bi_eff - halo;
+  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int tid = threadIdx.x;
+  const T* __restrict__ val = static_cast<const T*>(dv.val);
+  const int64_t gi = P0 + tid;
+  const bool in_i = gi >= 0 && gi < dv.S;
+  const bool owner = tid >= halo && tid < BW - halo;
+
+  auto x0_at = [&](int jl) -> T {
+    int64_t flat = (J0 + jl) * dv.S + gi;
+    flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
+    if constexpr (AOS) return x[flat * ldva + 2];
+    else return x[flat];
+  };
+  auto coef_at = [&](int jl) -> DiaCoef<T, 9> {
+    const int64_t gj = J0 + jl, r = gj * dv.S + gi;
+    const bool live = in_i && gj >= 0 && gj < nlines && r < dv.n_rows;
+    const int64_t rc = live ? r : 0;
+    DiaCoef<T, 9> c;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
+    if constexpr (AOS) { c.dg = x[rc * ldva]; c.b = x[rc * ldva + 1]; }
+    else { c.b = bvec[rc]; c.dg = diag[rc]; }
+    c.m = (int)dv.mask[rc];
+    c.lv = live;
+    return c;
+  };
+  // xs: the nine neighbours in diagonal order
+  auto update = [&](const DiaCoef<T, 9>& c, bool full, const T (&xs)[9]) -> T {
+    T acc = T(0);
+    if (full) {
+#pragma unroll
+      for (int d = 0; d < 9; ++d) acc = acc + c.v[d] * xs[d];
+    } else {
+      const int m = c.lv ? c.m : 0;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        const T nxt = acc + c.v[d] * xs[d];
+        acc = ((m >> d) & 1) ? nxt : acc;
+      }
+    }
+    return xs[4] + (w * (c.b - acc)) / c.dg;
+  };
+
+  constexpr int j_first = -(TS - 1);
+  const int j_last = L - 1 + (TS - 1);
+  T h[TS][3];                                      // h[t]: x^(k+t) of this lane on the last three lines level t produced
+#pragma unroll
+  for (int t = 0; t < TS; ++t) h[t][0] = h[t][1] = h[t][2] = T(0);
+  h[0][1] = x0_at(j_first - 1);
+  h[0][2] = x0_at(j_first);
+  buf[((j_first - 1 + 63) % 3) * LW + 1 + tid] = h[0][1];
+  buf[((j_first + 63) % 3) * LW + 1 + tid] = h[0][2];
+  T xpre = x0_at(j_first + 1);
+  DiaCoef<T, 9> c[NC];                             // set of line j_first + s lives in c[s % NC]
+  bool cfull[NC];
+  c[0] = coef_at(j_first);
+#pragma unroll
+  for (int s = 1; s < NC; ++s) c[s] = c[0];
+#pragma unroll
+  for (int s = 0; s < NC; ++s) cfull[s] = false;
+
+  auto do_step = [&](const int jl, const int u, const int nact) {
+    // LDS rows of the lines jl + 1, jl, jl - 1 (mod 3): level t reads lines jl - t + 2, jl - t + 1, jl - t of level t - 1 --
+    // the same three rows rotated by t - 1
+    const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
+    T* const rw[3] = {buf + s1 * LW + tid, buf + s0 * LW + tid, buf + s2 * LW + tid};   // [0] left, [1] own, [2] right
+    h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
+    rw[0][1] = xpre;                               // level 0, line jl + 1
+    xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
+    c[(u + 1) % NC] = coef_at(jl + 1);
+    cfull[u % NC] = __all(c[u % NC].lv && (c[u % NC].m & 0x1ff) == 0x1ff) != 0;   // (at first use: loaded a step ago)
+    if constexpr (AOS) {
+      const DiaCoef<T, 9>& c0 = c[u % NC];
+      if (jl >= 0 && jl < L && c0.lv && owner) {
+        const int64_t r = (J0 + jl) * dv.S + gi;
+        diag_out[r] = c0.dg;
+        b_out[r] = c0.b;
+      }
+    }
+#pragma unroll
+    for (int t = 1; t <= TS; ++t) {
+      __syncthreads();
+      if (t <= nact) {
+        // lines line + 1, line, line - 1 of level t - 1 (line = jl - (t - 1)): rows rotated by t - 1
+        T* const below = rw[(t - 1) % 3] + (t - 1) * 3 * LW;
+        T* const same = rw[t % 3] + (t - 1) * 3 * LW;
+        T* const above = rw[(t + 1) % 3] + (t - 1) * 3 * LW;
+        const int ci = ((u - (t - 1)) % NC + NC) % NC;
+        const T xs[9] = {above[0], h[t - 1][0], above[2], same[0], h[t - 1][1], same[2], below[0], h[t - 1][2], below[2]};
+        const T xn = update(c[ci], cfull[ci], xs);
+        if (t < TS) {
+          h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
+          same[3 * LW + 1] = xn;                   // level t, same line (same slot)
+        } else if (c[ci].lv && owner) {
+          xo[(J0 + jl - (TS - 1)) * dv.S + gi] = xn;
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < 2 * (TS - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
+  constexpr int u0 = (2 * (TS - 1)) % U;
+#pragma unroll 1
+  for (int jl0 = TS - 1;; jl0 += U) {
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      if (jl0 + q > j_last) return;
+      do_step(jl0 + q, (u0 + q) % U, TS);
+    }
+  }
+}
+
 template <typename T>
 bool jacobi_fused_ok(const gla_csr* A) {
   return g_tuning.jacobi_fuse && g_tuning.dia && g_tuning.spmv_variant == 0 && A->dia_state == 1 && A->dia_val &&
@@ -1250,6 +1387,9 @@ bool jacobi_fused_ok(const gla_csr* A) {
 
 // the canonical 5-point pattern jacobi_march5_kernel is written for (option jacobi_march = 0: generic kernel instead)
 inline bool jacobi_canon(const gla_csr* A) { return g_tuning.jacobi_march && gla_dia_canon5(A); }
+// ... and the canonical 9-point pattern of jacobi_march9_kernel (2 .. 6 sweeps per pass)
+inline bool jacobi_canon9(const gla_csr* A) { return g_tuning.jacobi_march && gla_dia_canon9(A); }
+constexpr int JACOBI_TS_MAX9 = 6;
 
 // workgroups of the march kernel a CU holds at once (registers decide: 5 at TS = 2 ... 2 at TS = 8 in fp64)
 template <typename T, int TS, bool AOS>
@@ -1267,12 +1407,28 @@ int jacobi_march_blocks_per_cu() {
   return cached;
 }
 
+template <typename T, int TS, bool AOS>
+int jacobi_march9_blocks_per_cu() {
+  static int cached = 0;
+  if (!cached) {
+    int nb = 0;
+    if constexpr (TS <= JACOBI_TS_MAX9) {
+      const size_t lds9 = (size_t)TS * 3 * (GLA_BLOCK + 2) * sizeof(T);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, jacobi_march9_kernel<T, TS, AOS>, GLA_BLOCK, lds9) != hipSuccess) nb = 0;
+    }
+    if (nb < 1) { (void)hipGetLastError(); nb = 2; }
+    cached = nb;
+  }
+  return cached;
+}
+
 template <typename T, int TS>
 int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
                         int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr) {
   constexpr bool generic_ts = TS == 2 || TS == 4 || TS == 5;      // what jacobi_fused_dia2d_kernel is instantiated for
   const bool canon = jacobi_canon(A);
-  if (!canon && !generic_ts) return GLA_ERR_UNSUPPORTED;
+  const bool canon9 = TS <= JACOBI_TS_MAX9 && jacobi_canon9(A);
+  if (!canon && !canon9 && !generic_ts) return GLA_ERR_UNSUPPORTED;
   Dia2D dv;
   dv.val = A->dia_val;
   dv.mask = A->dia_mask;
@@ -1293,12 +1449,15 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
       // (TS = 5: 252 vs 315 us) -- fewer, longer streams, less overlap between blocks; one per CU cannot hide a line step
       per_cu = ldva > 0 ? jacobi_march_blocks_per_cu<T, TS, true>() : jacobi_march_blocks_per_cu<T, TS, false>();
       if (per_cu > 2) per_cu = 2;
+    } else if (canon9) {
+      per_cu = ldva > 0 ? jacobi_march9_blocks_per_cu<T, TS, true>() : jacobi_march9_blocks_per_cu<T, TS, false>();
+      if (per_cu > 2) per_cu = 2;
     }
     else per_cu = sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5);
     lines = gla_pick_block_lines(nlines, nstrips, 256 * per_cu, 2 * (TS - 1), 2 * TS);   // (2 TS lines at least: also what the
     if (lines > 1024) lines = 1024;                                                       // multi-GPU interior / boundary split needs)
   }
-  if (lines < 2 * TS && canon) lines = 2 * TS;     // the march kernel's ramp-up assumes nothing else, but keep blocks sane
+  if (lines < 2 * TS && (canon || canon9)) lines = 2 * TS;     // the march kernel's ramp-up assumes nothing else, but keep blocks sane
   const int nlb_all = (int)((nlines + lines - 1) / lines);
   // the interior / boundary split only holds when a block is at least 2 TS lines high (block 1 then reads no x from the
   // first TS lines); otherwise every block counts as boundary
@@ -1327,6 +1486,19 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
                          tm, base0, split, base1);
     GLA_LAUNCH_CHECK();
     return GLA_OK;
+  }
+  if constexpr (TS <= JACOBI_TS_MAX9) {
+    if (canon9) {                                   // the same march for the canonical 9-point pattern
+      const size_t lds9 = (size_t)TS * 3 * (GLA_BLOCK + 2) * sizeof(T);
+      if (ldva > 0)
+        hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, true>), grid, block, lds9, st, dv, diag, b, x, xo, w, lines, nstrips,
+                           nlines, tm, base0, split, base1, ldva, diag_out, b_out);
+      else
+        hipLaunchKernelGGL((jacobi_march9_kernel<T, TS>), grid, block, lds9, st, dv, diag, b, x, xo, w, lines, nstrips, nlines,
+                           tm, base0, split, base1);
+      GLA_LAUNCH_CHECK();
+      return GLA_OK;
+    }
   }
   if constexpr (generic_ts) {
     const size_t lds = (size_t)TS * 4 * GLA_BLOCK * sizeof(T);
@@ -1634,8 +1806,8 @@ static void jacobi_schedule(gla_csr* A, int dtype, bool contiguous_k1, int n_ite
     p.count[2] = n_iters / 2; p.sweeps[2] = 2; p.count[3] = n_iters % 2;
     return;
   }
-  if (jacobi_canon(A)) {
-    const int tmax = g_tuning.jacobi_ts_max;
+  if (jacobi_canon(A) || jacobi_canon9(A)) {
+    const int tmax = jacobi_canon(A) ? g_tuning.jacobi_ts_max : std::min(g_tuning.jacobi_ts_max, g_tuning.jacobi_ts_max9);
     const int k = (n_iters + tmax - 1) / tmax, base = n_iters / k, r = n_iters % k;
     p.count[0] = r; p.sweeps[0] = base + 1;
     p.count[1] = k - r; p.sweeps[1] = base;

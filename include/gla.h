@@ -100,7 +100,8 @@ typedef struct {
   int64_t dia_row_lo, dia_row_hi;   /* rows [lo, hi) that fit the diagonal set (all rows on one GPU; a row block's
                                      * halo rows at either end do not and stay on the CSR kernels) */
   int32_t dia_A, dia_B;     /* max |a| (grid lines) and max |b| (points) of the 2-D reading */
-  int32_t dia_canon5;       /* 1: the reading is the canonical 5-point pattern -S, -1, 0, +1, +S (march kernel, 2 .. 8 sweeps per pass) */
+  int32_t dia_canon5;       /* 1: the reading is the canonical 5-point pattern -S, -1, 0, +1, +S (march kernel, 2 .. 8 sweeps per
+                             * pass); 9: the canonical 9-point pattern (a, b) in {-1, 0, 1}^2 (march kernel, 2 .. 6); 0: neither */
 } gla_csr_info_t;
 int gla_csr_info(gla_csr_t plan, gla_csr_info_t* info_host);
 
@@ -150,15 +151,16 @@ int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64
  * contiguous right-hand side, gla_jacobi_sweeps takes several sweeps in ONE pass over the data (temporal blocking: the
  * intermediate iterates stay on chip; same arithmetic per row, bit-identical results).  Canonical 5-point plans
  * (diagonals -S, -1, 0, +1, +S) take 2 .. 8 sweeps per pass, ceil(n_iters / 8) passes of equal size +- 1 (20 = 7 + 7 + 6);
- * other stencils 5, 4 or 2 (20 = 4 x 5, 6 = 4 + 2).  Options: "jacobi_fuse" 0 off, 1 default, 2 at most two per pass;
- * "jacobi_ts_max" most sweeps per pass on canonical plans (2 .. 8, default 8); "jacobi_march" 0 = canonical plans use the
+ * canonical 9-point plans ((a, b) in {-1, 0, 1}^2: the Q1 FEM operator) 2 .. 6, by default at most 5 (20 = 4 x 5, 3 = 3);
+ * other stencils 5, 4 or 2 (6 = 4 + 2, 3 = 2 + 1).  Options: "jacobi_fuse" 0 off, 1 default, 2 at most two per pass;
+ * "jacobi_ts_max" / "jacobi_ts_max9" most sweeps per pass on canonical 5- / 9-point plans (2 .. 8, default 8 / 2 .. 6, default 5); "jacobi_march" 0 = canonical plans use the
  * generic stencil kernel too; "jacobi_lines" grid lines per workgroup, 0 = automatic; "jacobi_min_rows": matrices with
  * fewer rows, default 2^19, keep one sweep per launch, which is faster there.
  * This reports the launches gla_jacobi_sweeps will use for n_iters sweeps, in order: counts4_host[g] launches of
  * sweeps4_host[g] sweeps each, g = 0 .. 3 (unused groups have count 0). */
 int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* counts4_host, int* sweeps4_host);
 /* ONE temporally blocked launch: Xout = `sweeps` Jacobi sweeps of X (contiguous vectors, K = 1); sweeps = 2 .. 8 on
- * canonical 5-point plans, 2, 4 or 5 on other 2-D stencil plans (GLA_ERR_UNSUPPORTED otherwise, and when the plan has
+ * canonical 5-point plans, 2 .. 6 on canonical 9-point plans, 2, 4 or 5 on other 2-D stencil plans (GLA_ERR_UNSUPPORTED otherwise, and when the plan has
  * no 2-D stencil reading).
  * part: 0 = every block of grid lines; 1 = the blocks that touch neither the first nor the last block of lines
  * (they read no x from the first / last `sweeps` grid lines: multi-GPU, while the ghost lines are in flight);

@@ -1078,18 +1078,23 @@ def test_jacobi_temporal_blocking_bit_identical():
     cases.append(("random values on the 5-point pattern", ei, torch.rand(ei.shape[1], 1, generator=gen, dtype=torch.float64) - 0.3, 4096))
     ei, ev = _stencil_matrix(300, 40, [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)], gen, 0.2)
     cases.append(("5-point pattern with holes", ei, ev, 12000))
-    options = ("jacobi_fuse", "jacobi_lines", "jacobi_march", "jacobi_ts_max")
-    defaults = (1, 0, 1, 8)
+    options = ("jacobi_fuse", "jacobi_lines", "jacobi_march", "jacobi_ts_max", "jacobi_ts_max9")
+    defaults = (1, 0, 1, 8, 5)
     for name, ei, ev, n in cases:
         for dtype in (torch.float64, torch.float32):
             plan = gla.CsrPlan(d(ei), n)
             plan.set_values(d(ev.to(dtype)))
             assert plan.info.dia in (5, 9), name
-            canon = bool(plan.info.dia_canon5)
-            assert canon == (plan.info.dia == 5), name
+            canon = plan.info.dia_canon5 == 1               # 5-point march kernel; 9: the 9-point march kernel
+            assert plan.info.dia_canon5 == (1 if plan.info.dia == 5 else 9), name
             assert plan.jacobi_schedule(20, dtype) == ((7, 7, 6) if canon else (5, 5, 5, 5)), name
-            assert plan.jacobi_schedule(9, dtype) == ((5, 4) if canon else (5, 4)), name
-            assert plan.jacobi_schedule(3, dtype) == ((3,) if canon else (2, 1)), name
+            assert plan.jacobi_schedule(9, dtype) == (5, 4), name
+            assert plan.jacobi_schedule(3, dtype) == (3,), name
+            try:
+                check(lib().gla_set_option(b"jacobi_march", 0))
+                assert plan.jacobi_schedule(3, dtype) == (2, 1) and plan.jacobi_schedule(20, dtype) == (5, 5, 5, 5), name
+            finally:
+                check(lib().gla_set_option(b"jacobi_march", 1))
             g2 = torch.Generator().manual_seed(n)
             b = d(torch.rand(n, 1, generator=g2, dtype=torch.float64).to(dtype))
             x = d(torch.rand(n, 1, generator=g2, dtype=torch.float64).to(dtype))
@@ -1101,8 +1106,9 @@ def test_jacobi_temporal_blocking_bit_identical():
                 finally:
                     check(lib().gla_set_option(b"jacobi_fuse", 1))
                 variants = [(1, 64, 1, 8), (1, 5, 1, 8), (1, 64, 0, 8), (1, 5, 0, 8), (2, 32, 1, 8), (2, 3, 0, 8)]
-                if canon:
-                    variants += [(1, 0, 1, 3), (1, 17, 1, 4), (1, 0, 1, 6)]
+                variants += [(1, 0, 1, 3), (1, 17, 1, 4), (1, 0, 1, 6)]       # (6: 5-point only; 9-point passes stay <= 5)
+                if not canon:
+                    variants += [(1, 0, 1, 8, 6), (1, 13, 1, 8, 6)]               # 9-point passes of up to 6 sweeps
                 for var in variants:
                     try:
                         for o, v in zip(options, var):
@@ -1117,7 +1123,7 @@ def test_jacobi_temporal_blocking_bit_identical():
                 wide = torch.zeros(n, 5, dtype=dtype, device=DEV)
                 wide[:, 1:4] = va
                 for vattr in (va, wide[:, 1:4]):
-                    for march in ((1, 0) if canon else (1,)):
+                    for march in (1, 0):
                         try:
                             check(lib().gla_set_option(b"jacobi_march", march))
                             got = plan.jacobi_sweeps_aos(vattr, 0.7, its)
