@@ -989,6 +989,16 @@ inline int64_t dia2d_blocks_bound(const gla_csr* A) {
 //   step jl:  ring[0] <- x^(k) line jl + 1 (prefetched) | prefetch x^(k) line jl + 2, coefficients of line jl + 1 |
 //             for t = 1 .. TS:  sync;  x^(k+t) on line jl - (t - 1) from ring[t - 1] lines -1 .. +1 -> ring[t] (t = TS: HBM)
 // ------------------------------------------------------------------------------------------------
+// Line block lb of a marching kernel -> first line and height.  edge = 0: uniform blocks of `lines` lines.  edge > 0 (the
+// multi-GPU interior / boundary split): the first and the last block are `edge` lines high, the nlb - 2 blocks between them
+// `lines` -- the two edge blocks are all that has to wait for the ghost lines, so they are kept as short as the split allows.
+__device__ __forceinline__ void march_block(int lb, int lines, int edge, int nlb, int64_t nlines, int64_t& J0, int& L) {
+  if (edge == 0) { J0 = (int64_t)lb * lines; L = (int)min((int64_t)lines, nlines - J0); }
+  else if (lb == 0) { J0 = 0; L = edge; }
+  else if (lb == nlb - 1) { J0 = nlines - edge; L = edge; }
+  else { J0 = edge + (int64_t)(lb - 1) * lines; L = (int)min((int64_t)lines, nlines - edge - J0); }
+}
+
 template <typename T, int DMAX>
 struct DiaCoef {                                  // one row's matrix data
   T v[DMAX], b, dg;
@@ -1016,8 +1026,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
   const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
   const int B = dv.B, halo = TS * B, bi_eff = BW - 2 * halo;
   const int lb = blk / nstrips, strip = blk - lb * nstrips;
-  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bi_eff - halo;   // lane tid <-> point P0 + tid
-  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int64_t P0 = (int64_t)strip * bi_eff - halo;   // lane tid <-> point P0 + tid
+  int64_t J0;
+  int L;
+  march_block(lb, lines, dv.nbi, dv.nbj, nlines, J0, L);
   const int tid = threadIdx.x;
   const T* __restrict__ val = static_cast<const T*>(dv.val);
   int da[DMAX], db[DMAX];
@@ -1126,8 +1138,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
   const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
   constexpr int halo = TS, bi_eff = BW - 2 * halo;
   const int lb = blk / nstrips, strip = blk - lb * nstrips;
-  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bi_eff - halo;
-  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int64_t P0 = (int64_t)strip * bi_eff - halo;
+  int64_t J0;
+  int L;
+  march_block(lb, lines, dv.nbi, dv.nbj, nlines, J0, L);
   const int tid = threadIdx.x;
   const T* __restrict__ val = static_cast<const T*>(dv.val);
   const int64_t gi = P0 + tid;
@@ -1265,8 +1279,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
   const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
   constexpr int halo = TS, bi_eff = BW - 2 * halo;
   const int lb = blk / nstrips, strip = blk - lb * nstrips;
-  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bi_eff - halo;
-  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int64_t P0 = (int64_t)strip * bi_eff - halo;
+  int64_t J0;
+  int L;
+  march_block(lb, lines, dv.nbi, dv.nbj, nlines, J0, L);
   const int tid = threadIdx.x;
   const T* __restrict__ val = static_cast<const T*>(dv.val);
   const int64_t gi = P0 + tid;
@@ -1424,11 +1440,12 @@ int jacobi_march9_blocks_per_cu() {
 
 template <typename T, int TS>
 int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
-                        int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr) {
+                        int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = TS) {
   constexpr bool generic_ts = TS == 2 || TS == 4 || TS == 5;      // what jacobi_fused_dia2d_kernel is instantiated for
   const bool canon = jacobi_canon(A);
   const bool canon9 = TS <= JACOBI_TS_MAX9 && jacobi_canon9(A);
   if (!canon && !canon9 && !generic_ts) return GLA_ERR_UNSUPPORTED;
+  if (part < 0 || part > 2 || ghost < TS) return GLA_ERR_INVALID_ARG;
   Dia2D dv;
   dv.val = A->dia_val;
   dv.mask = A->dia_mask;
@@ -1439,6 +1456,12 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
   const int bi_eff = GLA_BLOCK - 2 * TS * dv.B;
   const int nstrips = (int)((A->dia_S + bi_eff - 1) / bi_eff);
+  // Interior / boundary split (part 1 / 2, the multi-GPU route): the first and the last `ghost` grid lines of x arrive while
+  // the interior blocks run, so no interior block may read them: the first and the last line block are ghost + TS lines
+  // high (an interior block reads x from TS lines above its first line), everything between is split as for part 0.
+  // Grids too short for that (fewer than 2 edge blocks + 1 line) count as boundary as a whole.
+  const int edge = part != 0 && nlines > 2 * (int64_t)(ghost + TS) ? ghost + TS : 0;
+  const int64_t inner_lines = nlines - 2 * edge;
   int lines = g_tuning.jacobi_lines;
   if (lines <= 0) {
     // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (TS - 1) coefficient
@@ -1454,22 +1477,19 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
       if (per_cu > 2) per_cu = 2;
     }
     else per_cu = sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5);
-    lines = gla_pick_block_lines(nlines, nstrips, 256 * per_cu, 2 * (TS - 1), 2 * TS);   // (2 TS lines at least: also what the
-    if (lines > 1024) lines = 1024;                                                       // multi-GPU interior / boundary split needs)
+    lines = gla_pick_block_lines(inner_lines, nstrips, 256 * per_cu, 2 * (TS - 1), 2 * TS);
+    if (lines > 1024) lines = 1024;
   }
-  if (lines < 2 * TS && (canon || canon9)) lines = 2 * TS;     // the march kernel's ramp-up assumes nothing else, but keep blocks sane
-  const int nlb_all = (int)((nlines + lines - 1) / lines);
-  // the interior / boundary split only holds when a block is at least 2 TS lines high (block 1 then reads no x from the
-  // first TS lines); otherwise every block counts as boundary
-  const int nlb = (part != 0 && lines < 2 * TS) ? 1 : nlb_all;
+  if (lines < 2 * TS && (canon || canon9)) lines = 2 * TS;
+  const int nlb_all = (int)((inner_lines + lines - 1) / lines) + (edge ? 2 : 0);
+  dv.nbi = edge;
+  dv.nbj = nlb_all;
   int base0 = 0, split = nlb_all * nstrips, base1 = 0, count = nlb_all * nstrips;
   if (part == 1) {                                  // line blocks 1 .. nlb - 2
-    if (nlb < 3) return GLA_OK;
-    base0 = nstrips; count = split = (nlb - 2) * nstrips;
-  } else if (part == 2) {                           // the first and the last line block (all of them when nlb < 3)
-    if (nlb >= 3) { base0 = 0; split = nstrips; base1 = (nlb - 1) * nstrips; count = 2 * nstrips; }
-  } else if (part != 0) {
-    return GLA_ERR_INVALID_ARG;
+    if (!edge) return GLA_OK;
+    base0 = nstrips; count = split = (nlb_all - 2) * nstrips;
+  } else if (part == 2) {                           // the first and the last line block (all of them on short grids)
+    if (edge) { base0 = 0; split = nstrips; base1 = (nlb_all - 1) * nstrips; count = 2 * nstrips; }
   }
   TileMap tm;
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
@@ -1523,15 +1543,16 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
 // run-time sweeps-per-pass -> template (2 .. 8; 3, 6, 7, 8 exist for the canonical 5-point pattern only)
 template <typename T>
 int launch_jacobi_fused_ts(int ts, gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
-                           int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr) {
+                           int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = -1) {
+  if (ghost < 0) ghost = ts;
   switch (ts) {
-    case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
-    case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
-    case 4: return launch_jacobi_fused<T, 4>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
-    case 5: return launch_jacobi_fused<T, 5>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
-    case 6: return launch_jacobi_fused<T, 6>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
-    case 7: return launch_jacobi_fused<T, 7>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
-    case 8: return launch_jacobi_fused<T, 8>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out);
+    case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
+    case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
+    case 4: return launch_jacobi_fused<T, 4>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
+    case 5: return launch_jacobi_fused<T, 5>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
+    case 6: return launch_jacobi_fused<T, 6>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
+    case 7: return launch_jacobi_fused<T, 7>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
+    case 8: return launch_jacobi_fused<T, 8>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
     default: return GLA_ERR_UNSUPPORTED;
   }
 }
@@ -1833,10 +1854,10 @@ int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* counts4
   return GLA_OK;
 }
 
-int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
-                     int sweeps, int part, gla_stream_t stream) {
+int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
+                           int sweeps, int part, int ghost_lines, gla_stream_t stream) {
   if (!A || !diag || !B || !X || !Xout || X == Xout || sweeps < 2 || sweeps > 8 || part < 0 || part > 2 ||
-      (dtype != GLA_F32 && dtype != GLA_F64))
+      ghost_lines < sweeps || (dtype != GLA_F32 && dtype != GLA_F64))
     return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
   if (A->n_rows == 0) return GLA_OK;
@@ -1844,9 +1865,14 @@ int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, co
   hipStream_t st = (hipStream_t)stream;
   if (dtype == GLA_F64)
     return launch_jacobi_fused_ts<double>(sweeps, A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout,
-                                          (double)w, st, part);
+                                          (double)w, st, part, 0, nullptr, nullptr, ghost_lines);
   return launch_jacobi_fused_ts<float>(sweeps, A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w,
-                                       st, part);
+                                       st, part, 0, nullptr, nullptr, ghost_lines);
+}
+
+int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
+                     int sweeps, int part, gla_stream_t stream) {
+  return gla_jacobi_fused_parts(A, dtype, diag, B, X, Xout, w, sweeps, part, sweeps, stream);
 }
 
 int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, void* diag_work, void* b_work,

@@ -385,8 +385,9 @@ class RowBlockJacobi(RowBlockOps):
         chunk = 2 * m * nv                                   # a rank's chunk: per vector [first m | last m]
         out = []
         for v in range(nv):
-            up = recv[(p.rank - 1) * chunk + v * 2 * m + m:(p.rank - 1) * chunk + (v + 1) * 2 * m] if e["up"] else None
-            lo = recv[(p.rank + 1) * chunk + v * 2 * m:(p.rank + 1) * chunk + v * 2 * m + m] if e["down"] else None
+            ru, rd = e.get("up_src", p.rank - 1), e.get("down_src", p.rank + 1)      # (overridable: one-rank self-halo tests)
+            up = recv[ru * chunk + v * 2 * m + m:ru * chunk + (v + 1) * 2 * m] if e["up"] else None
+            lo = recv[rd * chunk + v * 2 * m:rd * chunk + v * 2 * m + m] if e["down"] else None
             out.append((up, lo))                             # the neighbour above's LAST lines / below's FIRST lines
         return out
 
@@ -428,10 +429,22 @@ class RowBlockJacobi(RowBlockOps):
                 self._fill_ghosts(vecs, self._ghost_exchange(owns))
                 check(lib().gla_jacobi_sweep(h, code, 1, ptr(d_ext), ptr(b_ext), 1, ptr(cur), 1, ptr(nxt), 1, w, 0, st))
             elif self.comm is not None and self.overlap:
-                self._ghost_exchange(owns, begin_only=True)  # ghost lines in flight on the side stream ...
-                check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, st))
-                self._fill_ghosts(vecs, self._ghost_finish())  # ... while the interior line blocks run
-                check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 2, st))
+                # ghost lines in flight on the communicator's stream while the interior line blocks run on this one; a
+                # second stream waits for the gather, fills the ghost lines and runs the (short) first / last line block
+                # CONCURRENTLY with the interior launch -- the two launches write disjoint lines of nxt
+                T = self.TS_MAX
+                main = torch.cuda.current_stream(dev)
+                side = e.get("side_stream")
+                if side is None:
+                    side = e["side_stream"] = torch.cuda.Stream(device=dev)
+                self._ghost_exchange(owns, begin_only=True)
+                side.wait_stream(main)                        # cur / nxt as the previous pass left them
+                check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, T, st))
+                with torch.cuda.stream(side):
+                    self._fill_ghosts(vecs, self._ghost_finish())
+                    check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 2, T,
+                                                       stream_ptr(dev)))
+                main.wait_stream(side)
             else:
                 self._fill_ghosts(vecs, self._ghost_exchange(owns))
                 check(lib().gla_jacobi_fused(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 0, st))

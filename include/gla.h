@@ -160,11 +160,15 @@ int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64
  * sweeps4_host[g] sweeps each, g = 0 .. 3 (unused groups have count 0). */
 int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* counts4_host, int* sweeps4_host);
 /* ONE temporally blocked launch: Xout = `sweeps` Jacobi sweeps of X (contiguous vectors, K = 1); sweeps = 2 .. 8 on
- * canonical 5-point plans, 2 .. 6 on canonical 9-point plans, 2, 4 or 5 on other 2-D stencil plans (GLA_ERR_UNSUPPORTED otherwise, and when the plan has
- * no 2-D stencil reading).
- * part: 0 = every block of grid lines; 1 = the blocks that touch neither the first nor the last block of lines
- * (they read no x from the first / last `sweeps` grid lines: multi-GPU, while the ghost lines are in flight);
- * 2 = the first and the last block. */
+ * canonical 5-point plans, 2 .. 6 on canonical 9-point plans, 2, 4 or 5 on other 2-D stencil plans (GLA_ERR_UNSUPPORTED otherwise,
+ * and when the plan has no 2-D stencil reading).
+ * part: 0 = every block of grid lines.  1 / 2 = the multi-GPU split of the same pass: the first and the last `ghost_lines`
+ * grid lines of X (>= sweeps) may still be in flight while part 1 runs -- part 1 is every line block that reads none of them,
+ * part 2 the first and the last line block (ghost_lines + sweeps lines high each, so that they are short; on grids of
+ * fewer than 2 (ghost_lines + sweeps) + 1 lines part 1 is empty and part 2 everything).  Part 1 + part 2 write exactly what
+ * part 0 writes.  gla_jacobi_fused(.., part, ..) is gla_jacobi_fused_parts with ghost_lines = sweeps. */
+int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
+                           int sweeps, int part, int ghost_lines, gla_stream_t stream);
 int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
                      int sweeps, int part, gla_stream_t stream);
 

@@ -400,7 +400,7 @@ def test_jacobi_fused_parts_and_library_all_gather():
     x = torch.rand(n, generator=gen, dtype=torch.float64).to(dev)
     diag = torch.full((n,), -4.0, dtype=torch.float64, device=dev)
     st, code = stream_ptr(dev), dtype_code(torch.float64)
-    for ts in (5, 4, 2):
+    for ts in (8, 7, 6, 5, 4, 3, 2):
         try:
             check(lib().gla_set_option(b"jacobi_fuse", 0))
             want = plan.jacobi_sweeps(diag, b.reshape(-1, 1), x.reshape(-1, 1), 0.7, ts).reshape(-1)
@@ -417,8 +417,16 @@ def test_jacobi_fused_parts_and_library_all_gather():
             finally:
                 check(lib().gla_set_option(b"jacobi_lines", 0))
             assert torch.equal(whole, want) and torch.equal(parts, want), (ts, lines)
-            if lines == 40:                                    # the interior launch alone leaves the outer blocks alone
-                assert bool((mid[:40 * Nx] == 0).all()) and bool((mid[-20 * Nx:] == 0).all()) and bool((mid[40 * Nx:80 * Nx] != 0).all())
+            # the explicit form: 8 ghost lines at either end whatever the pass carries (what dist.RowBlockJacobi uses)
+            parts8 = torch.zeros_like(x)
+            check(lib().gla_jacobi_fused_parts(plan._h, code, ptr(diag), ptr(b), ptr(x), ptr(parts8), 0.7, ts, 1, 8, st))
+            mid8 = parts8.clone()
+            check(lib().gla_jacobi_fused_parts(plan._h, code, ptr(diag), ptr(b), ptr(x), ptr(parts8), 0.7, ts, 2, 8, st))
+            assert torch.equal(parts8, want), (ts, lines, "ghost 8")
+            # the interior launch wrote nothing into the first / last 8 + ts lines (it read no x from the first / last 8)
+            assert bool((mid8[:(8 + ts) * Nx] == 0).all()) and bool((mid8[-(8 + ts) * Nx:] == 0).all()), (ts, lines)
+            if lines == 40:                                    # the interior launch alone leaves the two edge blocks alone
+                assert bool((mid[:2 * ts * Nx] == 0).all()) and bool((mid[-2 * ts * Nx:] == 0).all()) and bool((mid[2 * ts * Nx:40 * Nx] != 0).all())
     comm = LibComm()
     send = torch.arange(1000, dtype=torch.float64, device=dev)
     recv = torch.zeros(1000, dtype=torch.float64, device=dev)
@@ -426,3 +434,50 @@ def test_jacobi_fused_parts_and_library_all_gather():
     check(lib().gla_halo_end(comm._h, st))
     torch.cuda.synchronize()
     assert torch.equal(recv, send)
+
+
+@pytest.mark.parametrize("Nx,Ny", [(300, 200), (70, 40)])
+def test_temporal_route_self_halo_rccl(Nx, Ny):
+    """dist.RowBlockJacobi._forward_temporal with a REAL (one-rank) RCCL communicator: the rank's upper and lower neighbour
+    are the rank itself (a grid periodic in the line direction), so every pass goes through pack -> ncclAllGather on the
+    library's stream -> interior line blocks on the compute stream, ghost fill + first / last line block on a second
+    stream -> join.  Reference: the same extended plan, one ordinary sweep at a time with the ghost lines refreshed by
+    hand -- identical per-row arithmetic, so bit for bit."""
+    import types
+    import gnn_applied_linear_algebra_amd as gla
+    from gnn_applied_linear_algebra_amd._lib import check, lib
+    from gnn_applied_linear_algebra_amd.dist import LibComm, RowBlockJacobi
+    dev = torch.device("cuda:0")
+    T = RowBlockJacobi.TS_MAX
+    n, n_ext, off = Nx * Ny, Nx * (Ny + 2 * T), Nx * T
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(Nx, Ny=Ny + 2 * T, device=dev)
+    plan = gla.CsrPlan(ei, n_ext)
+    plan.set_values(ev)
+    assert plan.info.dia_stride == Nx and max(plan.jacobi_schedule(4 * T)) <= T
+    drv = RowBlockJacobi.__new__(RowBlockJacobi)
+    drv.comm, drv.overlap, drv._ghost_pending = LibComm(), True, None
+    drv.part = types.SimpleNamespace(world=1, rank=0, n_local=n, group=None)
+    drv._sched = plan.jacobi_schedule
+    drv.ext = dict(plan=plan, S=Nx, n_ext=n_ext, off=off, up=True, down=True, slab=T * Nx, dtype=torch.float64, dev=dev,
+                   up_src=0, down_src=0)
+    gen = torch.Generator().manual_seed(5)
+    va = torch.rand(n, 3, generator=gen, dtype=torch.float64).to(dev)
+    va[:, 0] += 3.0
+    g = torch.tensor([0.7], dtype=torch.float64)
+
+    def periodic(own):                                   # [own's last T lines | own | own's first T lines]
+        return torch.cat([own[-off:], own, own[:off]])
+    d_e, b_e = periodic(va[:, 0].contiguous()), periodic(va[:, 1].contiguous())
+    for its in (2, 7, 9, 20):
+        x = va[:, 2].contiguous()
+        try:
+            check(lib().gla_set_option(b"jacobi_fuse", 0))
+            for _ in range(its):
+                x = plan.jacobi_sweeps(d_e, b_e.reshape(-1, 1), periodic(x).reshape(-1, 1), 0.7, 1).reshape(-1)[off:off + n]
+        finally:
+            check(lib().gla_set_option(b"jacobi_fuse", 1))
+        for overlap in (True, False):
+            drv.overlap = overlap
+            got = drv.forward(its, va, g)
+            assert torch.equal(got.reshape(-1), x), (its, overlap, float((got.reshape(-1) - x).abs().max()))
+    torch.cuda.synchronize()
