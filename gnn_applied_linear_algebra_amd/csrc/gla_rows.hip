@@ -686,7 +686,8 @@ struct Dia2D {
   int32_t nci, nchunks;       // chunks (8 x 8 blocks) per row of chunks, chunks in all
   uint32_t w_magic;           // ceil(2^32 / W): x / W == umulhi(x, w_magic) for x < 2^16
   int64_t part_off;           // reducing epilogues: block (jb, ib) writes partials[(part_off + jb * nbi + ib) * K + k]
-};
+  int64_t aos_off, aos_rows;  // marching Jacobi kernels, AoS first pass: plan row r is row r - aos_off of an AoS tensor of
+};                            // aos_rows rows (multi-GPU: the plan covers the rank's rows plus ghost lines, the tensor its own rows)
 
 template <typename T, class Epi, int KV, int DMAX, int BJ>
 __global__ __launch_bounds__(GLA_BLOCK) void spmm_dia2d_kernel(Dia2D dv, const T* __restrict__ X, int64_t ldx, Epi epi) {
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
   auto x0_at = [&](int jl) -> T {                 // x^(k) at line J0 + jl, this lane's point (clamped: never used dead)
     int64_t flat = (J0 + jl) * dv.S + P0 + tid;
     flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
-    if constexpr (AOS) return x[flat * ldva + 2];
+    if constexpr (AOS) return x[min(max(flat - dv.aos_off, (int64_t)0), dv.aos_rows - 1) * ldva + 2];
     else return x[flat];
   };
   auto coef_at = [&](int jl) -> DiaCoef<T, DMAX> {   // row (line J0 + jl, this lane's point); dead rows: mask 0
@@ -1049,7 +1050,11 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
     DiaCoef<T, DMAX> c;
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) c.v[d] = val[(int64_t)min(d, dv.D - 1) * dv.n_rows + rc];
-    if constexpr (AOS) { c.dg = x[rc * ldva]; c.b = x[rc * ldva + 1]; }
+    if constexpr (AOS) {
+      const int64_t ra = min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1);
+      c.dg = x[ra * ldva];
+      c.b = x[ra * ldva + 1];
+    }
     else { c.b = bvec[rc]; c.dg = diag[rc]; }
     c.m = (int)dv.mask[rc];
     c.lv = live;
@@ -1151,7 +1156,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
   auto x0_at = [&](int jl) -> T {
     int64_t flat = (J0 + jl) * dv.S + gi;
     flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
-    if constexpr (AOS) return x[flat * ldva + 2];
+    if constexpr (AOS) return x[min(max(flat - dv.aos_off, (int64_t)0), dv.aos_rows - 1) * ldva + 2];
     else return x[flat];
   };
   auto coef_at = [&](int jl) -> DiaCoef<T, 5> {
@@ -1161,7 +1166,11 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
     DiaCoef<T, 5> c;
 #pragma unroll
     for (int d = 0; d < 5; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
-    if constexpr (AOS) { c.dg = x[rc * ldva]; c.b = x[rc * ldva + 1]; }
+    if constexpr (AOS) {
+      const int64_t ra = min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1);
+      c.dg = x[ra * ldva];
+      c.b = x[ra * ldva + 1];
+    }
     else { c.b = bvec[rc]; c.dg = diag[rc]; }
     c.m = (int)dv.mask[rc];
     c.lv = live;
@@ -1292,7 +1301,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
   auto x0_at = [&](int jl) -> T {
     int64_t flat = (J0 + jl) * dv.S + gi;
     flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
-    if constexpr (AOS) return x[flat * ldva + 2];
+    if constexpr (AOS) return x[min(max(flat - dv.aos_off, (int64_t)0), dv.aos_rows - 1) * ldva + 2];
     else return x[flat];
   };
   auto coef_at = [&](int jl) -> DiaCoef<T, 9> {
@@ -1302,7 +1311,11 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
     DiaCoef<T, 9> c;
 #pragma unroll
     for (int d = 0; d < 9; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
-    if constexpr (AOS) { c.dg = x[rc * ldva]; c.b = x[rc * ldva + 1]; }
+    if constexpr (AOS) {
+      const int64_t ra = min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1);
+      c.dg = x[ra * ldva];
+      c.b = x[ra * ldva + 1];
+    }
     else { c.b = bvec[rc]; c.dg = diag[rc]; }
     c.m = (int)dv.mask[rc];
     c.lv = live;
@@ -1440,7 +1453,8 @@ int jacobi_march9_blocks_per_cu() {
 
 template <typename T, int TS>
 int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
-                        int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = TS) {
+                        int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = TS, int64_t aos_off = 0,
+                        int64_t aos_rows = -1) {
   constexpr bool generic_ts = TS == 2 || TS == 4 || TS == 5;      // what jacobi_fused_dia2d_kernel is instantiated for
   const bool canon = jacobi_canon(A);
   const bool canon9 = TS <= JACOBI_TS_MAX9 && jacobi_canon9(A);
@@ -1453,6 +1467,8 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   for (int i = 0; i < GLA_DIA_MAX; ++i) { dv.da[i] = i < A->dia_D ? A->dia_a[i] : 0; dv.db[i] = i < A->dia_D ? A->dia_b[i] : 0; }
   dv.n_rows = A->n_rows; dv.n_cols = A->n_cols;
   dv.nbi = dv.nbj = dv.nci = dv.nchunks = 0; dv.w_magic = 0; dv.part_off = 0;
+  dv.aos_off = aos_off;
+  dv.aos_rows = aos_rows >= 0 ? aos_rows : A->n_rows;
   const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
   const int bi_eff = GLA_BLOCK - 2 * TS * dv.B;
   const int nstrips = (int)((A->dia_S + bi_eff - 1) / bi_eff);
@@ -1543,16 +1559,17 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
 // run-time sweeps-per-pass -> template (2 .. 8; 3, 6, 7, 8 exist for the canonical 5-point pattern only)
 template <typename T>
 int launch_jacobi_fused_ts(int ts, gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
-                           int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = -1) {
+                           int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = -1, int64_t aos_off = 0,
+                           int64_t aos_rows = -1) {
   if (ghost < 0) ghost = ts;
   switch (ts) {
-    case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
-    case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
-    case 4: return launch_jacobi_fused<T, 4>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
-    case 5: return launch_jacobi_fused<T, 5>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
-    case 6: return launch_jacobi_fused<T, 6>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
-    case 7: return launch_jacobi_fused<T, 7>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
-    case 8: return launch_jacobi_fused<T, 8>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost);
+    case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
+    case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
+    case 4: return launch_jacobi_fused<T, 4>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
+    case 5: return launch_jacobi_fused<T, 5>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
+    case 6: return launch_jacobi_fused<T, 6>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
+    case 7: return launch_jacobi_fused<T, 7>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
+    case 8: return launch_jacobi_fused<T, 8>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
     default: return GLA_ERR_UNSUPPORTED;
   }
 }
@@ -1868,6 +1885,23 @@ int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void*
                                           (double)w, st, part, 0, nullptr, nullptr, ghost_lines);
   return launch_jacobi_fused_ts<float>(sweeps, A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w,
                                        st, part, 0, nullptr, nullptr, ghost_lines);
+}
+
+int gla_jacobi_fused_parts_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, int64_t row_offset,
+                               int64_t n_attr_rows, void* diag_work, void* b_work, void* Xout, double w, int sweeps, int part,
+                               int ghost_lines, gla_stream_t stream) {
+  if (!A || !vertex_attr || ld < 3 || row_offset < 0 || n_attr_rows < 1 || !diag_work || !b_work || !Xout || sweeps < 2 ||
+      sweeps > 8 || part < 0 || part > 2 || ghost_lines < sweeps || (dtype != GLA_F32 && dtype != GLA_F64))
+    return GLA_ERR_INVALID_ARG;
+  if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
+  if (A->n_rows == 0) return GLA_OK;
+  if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A))) return GLA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GLA_F64)
+    return launch_jacobi_fused_ts<double>(sweeps, A, nullptr, nullptr, (const double*)vertex_attr, (double*)Xout, (double)w, st,
+                                          part, ld, (double*)diag_work, (double*)b_work, ghost_lines, row_offset, n_attr_rows);
+  return launch_jacobi_fused_ts<float>(sweeps, A, nullptr, nullptr, (const float*)vertex_attr, (float*)Xout, (float)w, st, part,
+                                       ld, (float*)diag_work, (float*)b_work, ghost_lines, row_offset, n_attr_rows);
 }
 
 int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,

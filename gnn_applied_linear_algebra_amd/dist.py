@@ -412,18 +412,33 @@ class RowBlockJacobi(RowBlockOps):
                                   torch.zeros(n_ext, dtype=dt, device=dev), torch.zeros(n_ext, dtype=dt, device=dev))
         d_ext, b_ext, cur, nxt = buf
         own = lambda v: v[off:off + nl]                      # noqa: E731
-        # the AoS rows [A_ii, b, x] of this rank go straight into the own part of the extended vectors (one pass)
-        outs = (ctypes.c_void_p * 3)(own(d_ext).data_ptr(), own(b_ext).data_ptr(), own(cur).data_ptr())
-        check(lib().gla_split_columns(code, nl, 3, ptr(va), va.stride(0) if nl > 1 else 3, outs, st))
-        first = True
         passes = list(self._sched(int(n_iters), dt))         # the single-GPU path's launch plan (fewest passes)
+        T, S = self.TS_MAX, e["S"]
+        # First pass straight from the AoS rows (as the single-GPU path does): the interior line blocks of a pass read
+        # nothing but the rank's own rows, so they can take A_ii, b, x from vertex_attr itself (plan row r = tensor row
+        # r - off) and leave the contiguous copies of A_ii and b behind; only the few lines the two edge blocks touch are
+        # copied by hand.  Otherwise (no library communicator, tiny blocks, single sweeps): one split pass into the
+        # extended vectors.
+        aos_first = (self.comm is not None and self.overlap and passes[0] > 1 and n_ext // S > 2 * (T + passes[0])
+                     and va.stride(1) == 1)
+        if aos_first:
+            E = (T + 2 * passes[0]) * S                      # rows the first / last edge block reads
+            for a, b_ in ((0, E), (n_ext - E, n_ext)):
+                a, b_ = max(a, off), min(b_, off + nl)       # ... that are the rank's own
+                if a < b_:
+                    d_ext[a:b_], b_ext[a:b_], cur[a:b_] = va[a - off:b_ - off, 0], va[a - off:b_ - off, 1], va[a - off:b_ - off, 2]
+        else:
+            outs = (ctypes.c_void_p * 3)(own(d_ext).data_ptr(), own(b_ext).data_ptr(), own(cur).data_ptr())
+            check(lib().gla_split_columns(code, nl, 3, ptr(va), va.stride(0) if nl > 1 else 3, outs, st))
+        first = True
         spare = nxt
         for i, ts in enumerate(passes):
             if i == len(passes) - 1:                         # the last pass writes into a fresh buffer the caller keeps
                 nxt = torch.empty(n_ext, dtype=dt, device=dev)
             # ghost lines of x every pass; those of A_ii and b ride along in the first exchange of the call
             vecs = [d_ext, b_ext, cur] if first else [cur]
-            owns = [own(v) for v in vecs]
+            owns = [va[:, 0], va[:, 1], va[:, 2]] if (first and aos_first) else [own(v) for v in vecs]
+            from_aos = first and aos_first
             first = False
             if ts == 1:                                      # one ordinary sweep of the extended block
                 self._fill_ghosts(vecs, self._ghost_exchange(owns))
@@ -432,14 +447,17 @@ class RowBlockJacobi(RowBlockOps):
                 # ghost lines in flight on the communicator's stream while the interior line blocks run on this one; a
                 # second stream waits for the gather, fills the ghost lines and runs the (short) first / last line block
                 # CONCURRENTLY with the interior launch -- the two launches write disjoint lines of nxt
-                T = self.TS_MAX
                 main = torch.cuda.current_stream(dev)
                 side = e.get("side_stream")
                 if side is None:
                     side = e["side_stream"] = torch.cuda.Stream(device=dev)
                 self._ghost_exchange(owns, begin_only=True)
                 side.wait_stream(main)                        # cur / nxt as the previous pass left them
-                check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, T, st))
+                if from_aos:
+                    check(lib().gla_jacobi_fused_parts_aos(h, code, ptr(va), va.stride(0), off, nl, ptr(d_ext), ptr(b_ext),
+                                                           ptr(nxt), w, ts, 1, T, st))
+                else:
+                    check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, T, st))
                 with torch.cuda.stream(side):
                     self._fill_ghosts(vecs, self._ghost_finish())
                     check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 2, T,

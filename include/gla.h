@@ -171,6 +171,14 @@ int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void*
                            int sweeps, int part, int ghost_lines, gla_stream_t stream);
 int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
                      int sweeps, int part, gla_stream_t stream);
+/* The same launch reading A_ii, b and x from the reference's AoS vertex attributes (as gla_jacobi_sweeps_aos' first pass)
+ * when the plan covers MORE rows than the tensor: plan row r is row r - row_offset of vertex_attr [n_attr_rows, >= 3]
+ * (multi-GPU: the plan spans the rank's rows plus ghost lines, the tensor holds the rank's own rows).  Rows outside the tensor
+ * must not be needed by the chosen part (part 1 with ghost_lines covering them); the rows a launched block owns get their
+ * A_ii and b copied to diag_work / b_work at plan-row positions, Xout receives the iterate at plan-row positions. */
+int gla_jacobi_fused_parts_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, int64_t row_offset,
+                               int64_t n_attr_rows, void* diag_work, void* b_work, void* Xout, double w, int sweeps, int part,
+                               int ghost_lines, gla_stream_t stream);
 
 /* Chebyshev, first degree (two MetaLayers fused): R = B - A X; P = R; Xout = X + alpha*R.
  * ChebyGNN.py:49-163. */
