@@ -34,7 +34,7 @@ def default_layout_only():
     also run as `GLA_OPTIONS=dia=0 pytest ...` etc., where they are skipped (the numerical tests all still run)."""
     import os
     opts = os.environ.get("GLA_OPTIONS", "")
-    if any(k in opts for k in ("dia=0", "col16=0", "compress=1", "jacobi_fuse=")):
+    if any(k in opts for k in ("dia=0", "col16=0", "compress=1", "jacobi_fuse=", "jacobi_march=", "jacobi_ts_max")):
         pytest.skip(f"layout-specific expectations; GLA_OPTIONS={opts}")
 
 
