@@ -342,8 +342,16 @@ class AMGHierarchy:
                 x = chebyshev_relax(self.plans[level], b.contiguous(), x.contiguous(), g, self.cheby.deg,
                                     need_gathered=False)[0]
             return x
-        x = self._smooth(level, self.n_pre, b, x)
-        r = self.residual(b, x, level)
+        # pre-smoothing and the residual of its result: one pass over the level's matrix where the plan qualifies
+        # (gla_jacobi_fused_residual; same arithmetic as the two calls, bit for bit)
+        w = float(torch.tensor(self.w, dtype=b.dtype))
+        xr = self.plans[level].jacobi_sweeps_residual(self.diags[level], b.contiguous(), x.contiguous(), w, self.n_pre) \
+            if (b.dim() == 2 and b.shape[1] == 1) else None
+        if xr is not None:
+            x, r = xr
+        else:
+            x = self._smooth(level, self.n_pre, b, x)
+            r = self.residual(b, x, level)
         rc = self.Pt[level].spmm(r)
         xc = self.cycle(rc, torch.zeros_like(rc), level + 1)
         x = x + self.P[level].spmm(xc.contiguous())

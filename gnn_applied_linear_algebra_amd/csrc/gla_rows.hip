@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
 //   * a wave whose 64 rows all carry the full pattern (wave-uniform flag per coefficient set) skips the mask selects; any other
 //     wave takes the masked in-order sum.  Both are the arithmetic of spmv_dia_kernel + EpiJacobi: bit-identical.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TS, bool AOS = false>
+template <typename T, int TS, bool AOS = false, bool RES = false>
 __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, const T* __restrict__ diag,
                                                                   const T* __restrict__ bvec, const T* __restrict__ x,
                                                                   T* __restrict__ xo, T w, int lines, int nstrips,
@@ -1134,14 +1134,15 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
                                                                   T* __restrict__ diag_out = nullptr,
                                                                   T* __restrict__ b_out = nullptr) {
   constexpr int BW = GLA_BLOCK, LW = BW + 2;      // a line in LDS: lane tid at [1 + tid], one pad either side
-  constexpr int NC = TS + 1;                      // coefficient sets in flight (lines jl + 1 .. jl - TS + 1)
+  constexpr int LV = TS + (RES ? 1 : 0);          // levels: TS sweeps; RES: + one level that forms r = b - A x^(k+TS) (-> b_out)
+  constexpr int NC = LV + 1;                      // coefficient sets in flight (lines jl + 1 .. jl - TS + 1)
   constexpr int U = NC;                           // unroll: static set index
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* buf = reinterpret_cast<T*>(smem_raw);        // [TS][2][LW]: buf[t][p] = the latest line of parity p of x^(k+t)
   const int slot = map_tile(tm);
   if (slot < 0) return;
   const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
-  constexpr int halo = TS, bi_eff = BW - 2 * halo;
+  constexpr int halo = LV, bi_eff = BW - 2 * halo;
   const int lb = blk / nstrips, strip = blk - lb * nstrips;
   const int64_t P0 = (int64_t)strip * bi_eff - halo;
   int64_t J0;
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
     c.lv = live;
     return c;
   };
-  auto update = [&](const DiaCoef<T, 5>& c, bool full, T up, T left, T ctr, T right, T down) -> T {
+  auto update = [&](const DiaCoef<T, 5>& c, bool full, T up, T left, T ctr, T right, T down, bool residual) -> T {
     T acc = T(0);
     if (full) {
       acc = acc + c.v[0] * up;
@@ -1193,14 +1194,15 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
         acc = ((m >> d) & 1) ? nxt : acc;
       }
     }
+    if (residual) return c.b - acc;                 // (GNNResidual.py:97-118, as EpiResidual)
     return ctr + (w * (c.b - acc)) / c.dg;
   };
 
-  constexpr int j_first = -(TS - 1);
-  const int j_last = L - 1 + (TS - 1);
-  T h[TS][3];                                      // h[t]: x^(k+t) of this lane on the last three lines level t produced
+  constexpr int j_first = -(LV - 1);
+  const int j_last = L - 1 + (LV - 1);
+  T h[LV][3];                                      // h[t]: x^(k+t) of this lane on the last three lines level t produced
 #pragma unroll
-  for (int t = 0; t < TS; ++t) h[t][0] = h[t][1] = h[t][2] = T(0);
+  for (int t = 0; t < LV; ++t) h[t][0] = h[t][1] = h[t][2] = T(0);
   h[0][1] = x0_at(j_first - 1);
   h[0][2] = x0_at(j_first);
   buf[((j_first + 64) & 1) * LW + 1 + tid] = h[0][2];
@@ -1235,31 +1237,35 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
       }
     }
 #pragma unroll
-    for (int t = 1; t <= TS; ++t) {
+    for (int t = 1; t <= LV; ++t) {
       if (t <= nact) {
         T* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LW;   // level t - 1, line jl - (t - 1)
         const int ci = ((u - (t - 1)) % NC + NC) % NC;
-        const T xn = update(c[ci], cfull[ci], h[t - 1][0], row[0], h[t - 1][1], row[2], h[t - 1][2]);
-        if (t < TS) {
+        const T xn = update(c[ci], cfull[ci], h[t - 1][0], row[0], h[t - 1][1], row[2], h[t - 1][2], RES && t == LV);
+        if (t < LV) {
           h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
           row[2 * LW + 1] = xn;                    // level t, same line (same parity)
-        } else if (c[ci].lv && owner) {
-          xo[(J0 + jl - (TS - 1)) * dv.S + gi] = xn;
+        }
+        if (t == TS) {                             // the iterate after TS sweeps (RES: its level also runs one line either side)
+          const int line = jl - (TS - 1);
+          if (c[ci].lv && owner && (!RES || (line >= 0 && line < L))) xo[(J0 + line) * dv.S + gi] = xn;
+        } else if (RES && t == LV) {               // ... and its residual
+          if (c[ci].lv && owner) b_out[(J0 + jl - (LV - 1)) * dv.S + gi] = xn;
         }
       }
     }
   };
   // ramp-up: step s = jl - j_first < 2 (TS - 1) has levels 1 .. (s + 2) / 2 active (x^(k+t) starts on line -(TS - t))
 #pragma unroll
-  for (int s = 0; s < 2 * (TS - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
+  for (int s = 0; s < 2 * (LV - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
   // steady state: lines 0 .. L - 1 leave the last level, one per step
-  constexpr int u0 = (2 * (TS - 1)) % U;
+  constexpr int u0 = (2 * (LV - 1)) % U;
 #pragma unroll 1
-  for (int jl0 = TS - 1;; jl0 += U) {
+  for (int jl0 = LV - 1;; jl0 += U) {
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       if (jl0 + q > j_last) return;
-      do_step(jl0 + q, (u0 + q) % U, TS);
+      do_step(jl0 + q, (u0 + q) % U, LV);
     }
   }
 }
@@ -1271,7 +1277,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, cons
 // level underneath produces in the same line step: three lines per level in LDS (slot = line mod 3), one barrier per level
 // and line step, three ds_read2 per update.  Same arithmetic as spmv_dia_kernel + EpiJacobi: bit-identical.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TS, bool AOS = false>
+template <typename T, int TS, bool AOS = false, bool RES = false>
 __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, const T* __restrict__ diag,
                                                                   const T* __restrict__ bvec, const T* __restrict__ x,
                                                                   T* __restrict__ xo, T w, int lines, int nstrips,
@@ -1280,13 +1286,14 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
                                                                   T* __restrict__ diag_out = nullptr,
                                                                   T* __restrict__ b_out = nullptr) {
   constexpr int BW = GLA_BLOCK, LW = BW + 2;      // a line in LDS: lane tid at [1 + tid], one pad either side
-  constexpr int NC = TS + 1, U = NC;
+  constexpr int LV = TS + (RES ? 1 : 0);          // levels: TS sweeps; RES: + one level that forms r = b - A x^(k+TS) (-> b_out)
+  constexpr int NC = LV + 1, U = NC;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* buf = reinterpret_cast<T*>(smem_raw);        // [TS][3][LW]: buf[t][s] = line of x^(k+t) with line mod 3 == s
   const int slot = map_tile(tm);
   if (slot < 0) return;
   const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
-  constexpr int halo = TS, bi_eff = BW - 2 * halo;
+  constexpr int halo = LV, bi_eff = BW - 2 * halo;
   const int lb = blk / nstrips, strip = blk - lb * nstrips;
   const int64_t P0 = (int64_t)strip * bi_eff - halo;
   int64_t J0;
@@ -1322,7 +1329,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
     return c;
   };
   // xs: the nine neighbours in diagonal order
-  auto update = [&](const DiaCoef<T, 9>& c, bool full, const T (&xs)[9]) -> T {
+  auto update = [&](const DiaCoef<T, 9>& c, bool full, const T (&xs)[9], bool residual) -> T {
     T acc = T(0);
     if (full) {
 #pragma unroll
@@ -1335,14 +1342,15 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
         acc = ((m >> d) & 1) ? nxt : acc;
       }
     }
+    if (residual) return c.b - acc;                 // (GNNResidual.py:97-118, as EpiResidual)
     return xs[4] + (w * (c.b - acc)) / c.dg;
   };
 
-  constexpr int j_first = -(TS - 1);
-  const int j_last = L - 1 + (TS - 1);
-  T h[TS][3];                                      // h[t]: x^(k+t) of this lane on the last three lines level t produced
+  constexpr int j_first = -(LV - 1);
+  const int j_last = L - 1 + (LV - 1);
+  T h[LV][3];                                      // h[t]: x^(k+t) of this lane on the last three lines level t produced
 #pragma unroll
-  for (int t = 0; t < TS; ++t) h[t][0] = h[t][1] = h[t][2] = T(0);
+  for (int t = 0; t < LV; ++t) h[t][0] = h[t][1] = h[t][2] = T(0);
   h[0][1] = x0_at(j_first - 1);
   h[0][2] = x0_at(j_first);
   buf[((j_first - 1 + 63) % 3) * LW + 1 + tid] = h[0][1];
@@ -1375,7 +1383,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
       }
     }
 #pragma unroll
-    for (int t = 1; t <= TS; ++t) {
+    for (int t = 1; t <= LV; ++t) {
       __syncthreads();
       if (t <= nact) {
         // lines line + 1, line, line - 1 of level t - 1 (line = jl - (t - 1)): rows rotated by t - 1
@@ -1384,25 +1392,29 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
         T* const above = rw[(t + 1) % 3] + (t - 1) * 3 * LW;
         const int ci = ((u - (t - 1)) % NC + NC) % NC;
         const T xs[9] = {above[0], h[t - 1][0], above[2], same[0], h[t - 1][1], same[2], below[0], h[t - 1][2], below[2]};
-        const T xn = update(c[ci], cfull[ci], xs);
-        if (t < TS) {
+        const T xn = update(c[ci], cfull[ci], xs, RES && t == LV);
+        if (t < LV) {
           h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
           same[3 * LW + 1] = xn;                   // level t, same line (same slot)
-        } else if (c[ci].lv && owner) {
-          xo[(J0 + jl - (TS - 1)) * dv.S + gi] = xn;
+        }
+        if (t == TS) {                             // the iterate after TS sweeps (RES: its level also runs one line either side)
+          const int line = jl - (TS - 1);
+          if (c[ci].lv && owner && (!RES || (line >= 0 && line < L))) xo[(J0 + line) * dv.S + gi] = xn;
+        } else if (RES && t == LV) {               // ... and its residual
+          if (c[ci].lv && owner) b_out[(J0 + jl - (LV - 1)) * dv.S + gi] = xn;
         }
       }
     }
   };
 #pragma unroll
-  for (int s = 0; s < 2 * (TS - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
-  constexpr int u0 = (2 * (TS - 1)) % U;
+  for (int s = 0; s < 2 * (LV - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
+  constexpr int u0 = (2 * (LV - 1)) % U;
 #pragma unroll 1
-  for (int jl0 = TS - 1;; jl0 += U) {
+  for (int jl0 = LV - 1;; jl0 += U) {
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       if (jl0 + q > j_last) return;
-      do_step(jl0 + q, (u0 + q) % U, TS);
+      do_step(jl0 + q, (u0 + q) % U, LV);
     }
   }
 }
@@ -1554,6 +1566,62 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     GLA_LAUNCH_CHECK();
   }
   return GLA_OK;
+}
+
+// `TS` sweeps AND the residual of the result in one pass (march kernels with RES = true: one more level that forms
+// r = b - A x^(k+TS); canonical 5-point plans TS = 1 .. 7, canonical 9-point plans TS = 1 .. 5)
+template <typename T, int TS>
+int launch_jacobi_fused_res(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T* ro, T w, hipStream_t st) {
+  const bool canon = TS + 1 <= 8 && jacobi_canon(A);
+  const bool canon9 = TS + 1 <= JACOBI_TS_MAX9 && jacobi_canon9(A);
+  if (!canon && !canon9) return GLA_ERR_UNSUPPORTED;
+  constexpr int LV = TS + 1;
+  Dia2D dv;
+  dv.val = A->dia_val;
+  dv.mask = A->dia_mask;
+  dv.D = A->dia_D; dv.S = A->dia_S; dv.A = A->dia_A; dv.B = A->dia_B;
+  for (int i = 0; i < GLA_DIA_MAX; ++i) { dv.da[i] = i < A->dia_D ? A->dia_a[i] : 0; dv.db[i] = i < A->dia_D ? A->dia_b[i] : 0; }
+  dv.n_rows = A->n_rows; dv.n_cols = A->n_cols;
+  dv.nbi = dv.nbj = dv.nci = dv.nchunks = 0; dv.w_magic = 0; dv.part_off = 0;
+  dv.aos_off = 0; dv.aos_rows = A->n_rows;
+  const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
+  const int bi_eff = GLA_BLOCK - 2 * LV;
+  const int nstrips = (int)((A->dia_S + bi_eff - 1) / bi_eff);
+  int lines = g_tuning.jacobi_lines;
+  if (lines <= 0) lines = gla_pick_block_lines(nlines, nstrips, 256 * 2, 2 * (LV - 1), 2 * LV);
+  if (lines > 1024) lines = 1024;
+  if (lines < 2 * LV) lines = 2 * LV;
+  dv.nbj = (int)((nlines + lines - 1) / lines);
+  TileMap tm;
+  tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
+  tm.n_tiles = dv.nbj * nstrips;
+  set_tile_mapping(tm);
+  const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
+  if (canon) {
+    if constexpr (TS + 1 <= 8)
+      hipLaunchKernelGGL((jacobi_march5_kernel<T, TS, false, true>), grid, block, (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T), st, dv,
+                         diag, b, x, xo, w, lines, nstrips, nlines, tm, 0, tm.n_tiles, 0, (int64_t)1, (T*)nullptr, ro);
+  } else {
+    if constexpr (TS + 1 <= JACOBI_TS_MAX9)
+      hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, false, true>), grid, block, (size_t)LV * 3 * (GLA_BLOCK + 2) * sizeof(T), st, dv,
+                         diag, b, x, xo, w, lines, nstrips, nlines, tm, 0, tm.n_tiles, 0, (int64_t)1, (T*)nullptr, ro);
+  }
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+template <typename T>
+int launch_jacobi_fused_res_ts(int ts, gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T* ro, T w, hipStream_t st) {
+  switch (ts) {
+    case 1: return launch_jacobi_fused_res<T, 1>(A, diag, b, x, xo, ro, w, st);
+    case 2: return launch_jacobi_fused_res<T, 2>(A, diag, b, x, xo, ro, w, st);
+    case 3: return launch_jacobi_fused_res<T, 3>(A, diag, b, x, xo, ro, w, st);
+    case 4: return launch_jacobi_fused_res<T, 4>(A, diag, b, x, xo, ro, w, st);
+    case 5: return launch_jacobi_fused_res<T, 5>(A, diag, b, x, xo, ro, w, st);
+    case 6: return launch_jacobi_fused_res<T, 6>(A, diag, b, x, xo, ro, w, st);
+    case 7: return launch_jacobi_fused_res<T, 7>(A, diag, b, x, xo, ro, w, st);
+    default: return GLA_ERR_UNSUPPORTED;
+  }
 }
 
 // run-time sweeps-per-pass -> template (2 .. 8; 3, 6, 7, 8 exist for the canonical 5-point pattern only)
@@ -1885,6 +1953,24 @@ int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void*
                                           (double)w, st, part, 0, nullptr, nullptr, ghost_lines);
   return launch_jacobi_fused_ts<float>(sweeps, A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w,
                                        st, part, 0, nullptr, nullptr, ghost_lines);
+}
+
+int gla_jacobi_fused_residual(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, void* Rout,
+                              double w, int sweeps, gla_stream_t stream) {
+  if (!A || !diag || !B || !X || !Xout || !Rout || X == Xout || Xout == Rout || X == Rout || sweeps < 1 ||
+      (dtype != GLA_F32 && dtype != GLA_F64))
+    return GLA_ERR_INVALID_ARG;
+  if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
+  if (A->n_rows == 0) return GLA_OK;
+  if (A->n_rows < g_tuning.jacobi_min_rows || g_tuning.jacobi_fuse != 1 ||
+      !(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A)))
+    return GLA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == GLA_F64)
+    return launch_jacobi_fused_res_ts<double>(sweeps, A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout,
+                                              (double*)Rout, (double)w, st);
+  return launch_jacobi_fused_res_ts<float>(sweeps, A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout,
+                                           (float*)Rout, (float)w, st);
 }
 
 int gla_jacobi_fused_parts_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, int64_t row_offset,

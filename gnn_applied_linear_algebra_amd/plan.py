@@ -218,6 +218,40 @@ class CsrPlan:
                                           ptr(Xout), ptr(Xtmp), float(w), int(n_iters), stream_ptr(self.device)))
         return Xout
 
+    @_on_device
+    def jacobi_sweeps_residual(self, diag, B, X0, w, n_iters):
+        """(x after n_iters sweeps, r = B - A x) with the residual formed inside the last temporally blocked pass
+        (gla_jacobi_fused_residual), or None when the plan / count does not qualify (the caller runs jacobi_sweeps and
+        residual).  Single contiguous rhs."""
+        from ._lib import GlaError
+        n_iters = int(n_iters)
+        if self.n_rows != self.n_cols or n_iters < 1 or self.n_rows == 0:
+            return None
+        X0, K, _ = _dense(X0, self.n_cols, "X0")
+        B, Kb, _ = _dense(B, self.n_rows, "B")
+        if K != 1 or Kb != 1 or not (X0.is_contiguous() and B.is_contiguous() and diag.is_contiguous()):
+            return None
+        self._need(X0.dtype)
+        info = self.info
+        cap = 7 if int(info.dia_canon5) == 1 else (5 if int(info.dia_canon5) == 9 else 0)
+        sched = self.jacobi_schedule(n_iters, X0.dtype)
+        last = sched[-1] if sched else 0
+        if cap == 0 or last > cap or (n_iters > 1 and max(sched) < 2):
+            return None
+        x = X0
+        if n_iters > last:                                   # the earlier passes of the schedule as usual
+            x = self.jacobi_sweeps(diag, B, X0, w, n_iters - last)
+        Xout = torch.empty((self.n_rows, 1), dtype=X0.dtype, device=self.device)
+        R = torch.empty_like(Xout)
+        try:
+            check(lib().gla_jacobi_fused_residual(self._h, dtype_code(X0.dtype), ptr(diag), ptr(B), ptr(x), ptr(Xout), ptr(R),
+                                                  float(w), last, stream_ptr(self.device)))
+        except GlaError as err:
+            if err.code == -5:                               # GLA_ERR_UNSUPPORTED (small matrix, options)
+                return None
+            raise
+        return Xout, R
+
     def jacobi_schedule(self, n_iters, dtype=torch.float64):
         """Sweeps per launch, in launch order, that gla_jacobi_sweeps uses for n_iters sweeps on one contiguous rhs:
         (7, 7, 6) for 20 sweeps on a canonical 5-point plan, (5, 5, 5, 5) on other 2-D stencils, (1,) * 20 unfused."""

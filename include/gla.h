@@ -171,6 +171,12 @@ int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void*
                            int sweeps, int part, int ghost_lines, gla_stream_t stream);
 int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
                      int sweeps, int part, gla_stream_t stream);
+/* `sweeps` Jacobi sweeps AND the residual of the result in ONE pass: Xout = x after the sweeps, Rout = B - A Xout (as
+ * gla_jacobi_sweeps followed by gla_residual, bit for bit; what a V-cycle does before it restricts, VCycle.py:196,212).
+ * Canonical 5-point plans: sweeps = 1 .. 7; canonical 9-point plans: 1 .. 5; contiguous vectors, K = 1.  GLA_ERR_UNSUPPORTED
+ * for other plans / counts, below "jacobi_min_rows" rows, or with "jacobi_fuse" != 1: run the two calls then. */
+int gla_jacobi_fused_residual(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, void* Rout,
+                              double w, int sweeps, gla_stream_t stream);
 /* The same launch reading A_ii, b and x from the reference's AoS vertex attributes (as gla_jacobi_sweeps_aos' first pass)
  * when the plan covers MORE rows than the tensor: plan row r is row r - row_offset of vertex_attr [n_attr_rows, >= 3]
  * (multi-GPU: the plan spans the rank's rows plus ghost lines, the tensor holds the rank's own rows).  Rows outside the tensor

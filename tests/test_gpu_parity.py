@@ -1265,6 +1265,46 @@ def test_cheby_fused_pass_bit_identical():
     assert plan.cheby_fused(v[0], v[1], v[2], v[3], v[4], [-0.25, -0.26], [0.0, 0.1]) is False
 
 
+def test_jacobi_fused_residual_bit_identical():
+    """gla_jacobi_fused_residual: n sweeps AND r = b - A x of the result in one pass (what a V-cycle does before it
+    restricts) == gla_jacobi_sweeps followed by gla_residual, bit for bit; 5- and 9-point plans, holes, ragged grids,
+    fp64 / fp32, counts that need earlier passes; plans / counts that do not qualify return None."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+    gen = torch.Generator().manual_seed(33)
+    cases = [("laplacian 300 x 77", *rp.laplacianfun_torch(300, 77), 23100),
+             ("laplacian 40 x 9", *rp.laplacianfun_torch(40, 9), 360),
+             ("fem 9-point 70 x 58", *rp.heateqnfem2dfun([71, 59], [1.0, 4.0]), 70 * 58)]
+    ei, ev = _stencil_matrix(300, 40, [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)], gen, 0.2)
+    cases.append(("5-point with holes", ei, ev, 12000))
+    for name, ei, ev, n in cases:
+        for dtype in (torch.float64, torch.float32):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            cap = 7 if plan.info.dia_canon5 == 1 else 5
+            b = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            x = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            diag = d((torch.rand(n, generator=gen, dtype=torch.float64) + 3.0).to(dtype))
+            for its in (1, 2, 3, 4, 5, 6, 7, 8, 10, 13):
+                try:
+                    check(lib().gla_set_option(b"jacobi_fuse", 0))
+                    want_x = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                    want_r = plan.residual(b, want_x)
+                finally:
+                    check(lib().gla_set_option(b"jacobi_fuse", 1))
+                got = plan.jacobi_sweeps_residual(diag, b, x, 0.7, its)
+                last = plan.jacobi_schedule(its, dtype)[-1]
+                assert (got is None) == (last > cap), (name, dtype, its, last)
+                if got is not None:
+                    assert torch.equal(got[0], want_x) and torch.equal(got[1], want_r), \
+                        (name, dtype, its, float((got[0] - want_x).abs().max()), float((got[1] - want_r).abs().max()))
+    ei, ev = _stencil_matrix(64, 50, [(-1, 0), (0, -2), (0, 0), (0, 2), (1, 0)], gen)        # B = 2: not a canonical pattern
+    plan = gla.CsrPlan(d(ei), 3200)
+    plan.set_values(d(ev))
+    assert plan.jacobi_sweeps_residual(d(torch.ones(3200, dtype=torch.float64)), d(torch.ones(3200, 1, dtype=torch.float64)),
+                                       d(torch.ones(3200, 1, dtype=torch.float64)), 0.7, 3) is None
+
+
 def test_jacobi_fusion_size_threshold():
     """Below option jacobi_min_rows (default 2^19 rows) gla_jacobi_sweeps keeps one sweep per launch (faster there)."""
     default_layout_only()
