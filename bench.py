@@ -23,7 +23,8 @@ same matrix measured in the same run.  A failure of the overlapped exchange is a
 N = 1 side records (never `value`): `one_sweep_per_pass` (the stencil kernel without temporal blocking), `csr_general`
 (the CSR-stream kernel every non-stencil matrix gets),
 `config3_k16` (BASELINE config 3: Chebyshev degree 4 + power method, 16 right-hand sides), `config4_1gpu`
-(8192 x 8192 on one GPU), `optin_packed_stream`.
+(8192 x 8192 on one GPU), `optin_packed_stream`, `dist_route_one_gpu` (the N > 1 route rehearsed on this GPU with a one-rank
+RCCL communicator).
 
 Prints ONE JSON line on rank 0.
 """
@@ -483,9 +484,46 @@ def single_gpu(args, gla, dev):
             del p4
             torch.cuda.empty_cache()
 
+        # the multi-GPU route on this ONE GPU: dist.RowBlockJacobi's temporally blocked forward with a real one-rank RCCL
+        # communicator whose upper and lower neighbour are the rank itself (periodic in the line direction): pack,
+        # ncclAllGather on the library's stream, interior line blocks, ghost fill + edge blocks on a second stream.  Its
+        # ratio to `value` is what weak scaling can reach before inter-GPU latency (tools/bench_dist_selfhalo.py)
+        try:
+            import types
+            from gnn_applied_linear_algebra_amd.dist import LibComm, RowBlockJacobi
+            T_ = RowBlockJacobi.TS_MAX
+            Nn = args.n
+            ei_e, ev_e = gla.UtilsGNN.laplacianfun_torch(Nn, Ny=Nn + 2 * T_, device=dev)
+            plan_e = gla.CsrPlan(ei_e, Nn * (Nn + 2 * T_))
+            plan_e.set_values(ev_e)
+            del ei_e, ev_e
+            drv = RowBlockJacobi.__new__(RowBlockJacobi)
+            comm_ = LibComm()
+            drv.comm, drv.overlap, drv._ghost_pending = comm_, True, None
+            drv.part = types.SimpleNamespace(world=1, rank=0, n_local=Nn * Nn, group=None)
+            drv._sched = plan_e.jacobi_schedule
+            drv.ext = dict(plan=plan_e, S=Nn, n_ext=Nn * (Nn + 2 * T_), off=Nn * T_, up=True, down=True, slab=T_ * Nn,
+                           dtype=torch.float64, dev=dev, up_src=0, down_src=0)
+            va_d = pr.vertex_attr
+            eld, msd = timed_steps(lambda: drv.forward(args.sweeps, va_d, pr.g), 20, 3)
+            td = median(msd) * 1e-3
+            out["dist_route_one_gpu"] = {
+                "what": "dist.RowBlockJacobi forward (the N > 1 route: one ghost-line exchange per pass over a real one-rank "
+                        "RCCL communicator, neighbours = the rank itself), same block size and sweeps as the headline",
+                "value": round(args.sweeps / td, 2), "unit": "sweeps/s", "ms_per_step": round(td * 1e3, 4),
+                "fraction_of_headline_step": round((median(step_ms) * 1e-3) / td, 4)}
+            del drv, plan_e
+            torch.cuda.synchronize()
+            from gnn_applied_linear_algebra_amd._lib import lib as _lib
+            _lib().gla_comm_destroy(comm_._h)
+            comm_._h = None
+            torch.cuda.empty_cache()
+        except Exception as exc:                             # (a side record only: e.g. no RCCL library on the box)
+            out["dist_route_one_gpu"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.n, args.cpu_sweeps)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def multi_gpu(args, gla, dev, world, rank):
@@ -575,8 +613,28 @@ def multi_gpu(args, gla, dev, world, rank):
         print(json.dumps(out), flush=True)
 
 
+_JSON_FD = None
+
+
+def emit(obj):
+    """The ONE JSON line, written to the process's original stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def worker(args):
+    global _JSON_FD
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; before any HIP call
+    # stdout carries the JSON line and nothing else: libraries print there too (RCCL's version banner on the first
+    # communicator, gloo's connection banner), so file descriptor 1 is pointed at stderr for the life of the rank and
+    # the line goes to a duplicate of the original
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
