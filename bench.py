@@ -610,7 +610,7 @@ def multi_gpu(args, gla, dev, world, rank):
                         "parallel_efficiency": round(t1 / t4 / world, 3)})
         out["config4_strong"] = rec
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 _JSON_FD = None

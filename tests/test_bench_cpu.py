@@ -42,3 +42,13 @@ def test_parent_relays_child_failure_as_nonzero_exit():
               "--child-timeout", "90"])
     assert r.returncode != 0
     assert "Traceback" in r.stderr or "Error" in r.stderr
+
+
+def test_rank_processes_write_the_json_line_to_the_saved_stdout():
+    """A rank points fd 1 at stderr for its lifetime (RCCL / gloo print banners on stdout), so the JSON line must go through
+    emit() -- a plain print() in a rank would land on stderr and the driver would see no line at all."""
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def single_gpu("):]
+    assert "print(json.dumps" not in body, "rank code must call emit(), not print()"
+    assert len(re.findall(r"\bemit\(out\)", body)) >= 2            # the N = 1 line and the N > 1 line
