@@ -71,7 +71,7 @@ struct gla_tuning {
   int col16 = 1;            // K = 1 kernels read int16 tile-relative columns when the plan could build them
   int compress = 0;         // 1: gla_csr_set_values also builds the packed stream when the matrix allows it
   int dia = 1;              // stencil matrices (<= 16 diagonals): K = 1 kernels use the diagonal layout
-  int jacobi_fuse = 1;      // gla_jacobi_sweeps on 2-D stencil plans: 0 one sweep per pass, 1 up to four (temporal blocking), 2 up to two
+  int jacobi_fuse = 1;      // gla_jacobi_sweeps on 2-D stencil plans: 0 one sweep per pass, 1 several (temporal blocking; gla_jacobi_sweeps_schedule), 2 up to two
   int jacobi_lines = 0;     // grid lines a workgroup of the fused kernel marches through (0 = one resident round of workgroups)
   int jacobi_ts_max = 8;    // canonical 5-point plans: most sweeps per pass (2 .. 8)
   int jacobi_ts_max9 = 5;   // canonical 9-point plans: most sweeps per pass (2 .. 6)
