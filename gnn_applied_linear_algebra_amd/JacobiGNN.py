@@ -8,7 +8,7 @@ write of x; the [A_ij, c_ij] edge tensor the reference re-materialises every swe
 import torch
 
 from . import meta
-from ._common import aggregate, back, cols, compute_device, float_dtype, plan_for, split_cols, stack_cols, to_dev
+from ._common import aggregate, back, cols, compute_device, float_dtype, plan_for, scalar0, split_cols, stack_cols, to_dev
 
 
 def edge_to_vertex_aggregation(edgeij_pair, edge_attr, n_vertices):
@@ -46,7 +46,7 @@ def _prep(vertex_attr, edgeij_pair, edge_attr, g):
     if va.shape[1] != 3:
         raise ValueError("vertex_attr must be [n, 3] = [A_ii, b, x]")
     plan = plan_for(ei, va.shape[0], edge_attr=ea)
-    w = float(g.reshape(-1)[0])                  # w = g[0] in the tensor's own dtype (JacobiGNN.py:108)
+    w = scalar0(g)                               # w = g[0] in the tensor's own dtype (JacobiGNN.py:108)
     if va.dim() == 2:
         d_col, b, x = split_cols(va)             # one pass over the AoS rows
         return plan, va, ea, d_col.reshape(-1), b, x, w
@@ -80,7 +80,7 @@ class JacobiGNN(torch.nn.Module):
             if va.shape[1] != 3:
                 raise ValueError("vertex_attr must be [n, 3] = [A_ii, b, x]")
             plan = plan_for(ei, va.shape[0], edge_attr=ea)
-            x = plan.jacobi_sweeps_aos(va, float(g.reshape(-1)[0]), int(n_iters))
+            x = plan.jacobi_sweeps_aos(va, scalar0(g), int(n_iters))
             if x is not None:
                 return back(x, vertex_attr)
         plan, va, ea, diag, b, x, w = _prep(vertex_attr, edgeij_pair, edge_attr, g)

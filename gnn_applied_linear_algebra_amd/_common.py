@@ -5,6 +5,27 @@ from . import _lib
 from .plan import plan_for
 
 
+_SCALAR0 = {}
+
+
+def scalar0(g):
+    """float(g.reshape(-1)[0]) -- the relaxation weight w = g[0] the kernels take by value (JacobiGNN.py:108).  For a GPU
+    tensor that read is a device-to-host copy which drains the stream on every call; the value is remembered per tensor
+    (storage, offset, dtype) and version counter, so a solver loop that passes the same unmodified `g` reads it once
+    (any in-place write to `g` bumps its version and is read again)."""
+    if not g.is_cuda:
+        return float(g.reshape(-1)[0])
+    key = (g.device.index, g.untyped_storage().data_ptr(), g.storage_offset(), g.dtype)
+    hit = _SCALAR0.get(key)
+    if hit is not None and hit[0] == g._version:
+        return hit[1]
+    val = float(g.reshape(-1)[0])
+    if len(_SCALAR0) > 64:
+        _SCALAR0.clear()
+    _SCALAR0[key] = (g._version, val)
+    return val
+
+
 def compute_device(*tensors):
     """GPU the call runs on: the device of the first GPU operand, else the current HIP device.
     The reference is CPU-only, so CPU operands are accepted, moved once, and results moved back."""

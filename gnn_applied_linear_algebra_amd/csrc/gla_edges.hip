@@ -460,6 +460,22 @@ __global__ __launch_bounds__(GLA_BLOCK) void edge_dot_wide_kernel(
 // pass over the AoS rows instead of `a` strided copies.  The a (<= 8) column pointers are passed by value.
 struct SplitPtrs { void* p[8]; };
 
+struct CopyBatch {                      // up to 8 strided vector copies in one launch (blockIdx.y = entry)
+  const void* src[8];
+  void* dst[8];
+  int64_t count[8], sstride[8];
+};
+
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void copy_batch_kernel(CopyBatch cb) {
+  const int e = blockIdx.y;
+  const T* __restrict__ src = static_cast<const T*>(cb.src[e]);
+  T* __restrict__ dst = static_cast<T*>(cb.dst[e]);
+  const int64_t n = cb.count[e], ss = cb.sstride[e];
+  for (int64_t i = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * GLA_BLOCK)
+    dst[i] = src[i * ss];
+}
+
 template <typename T>
 __global__ __launch_bounds__(GLA_BLOCK) void split_columns_kernel(const T* __restrict__ src, int64_t n, int a, int64_t ld,
                                                                   SplitPtrs out) {
@@ -742,6 +758,34 @@ int gla_split_columns(int dtype, int64_t n, int a, const void* src, int64_t ld, 
   else
     hipLaunchKernelGGL((split_columns_kernel<float>), dim3(grid), dim3(GLA_BLOCK), 0, (hipStream_t)stream,
                        (const float*)src, n, a, ld, sp);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+int gla_copy_batch(int dtype, int n_copies, const void* const* src_host, void* const* dst_host, const int64_t* count_host,
+                   const int64_t* src_stride_host, gla_stream_t stream) {
+  if (n_copies < 0 || n_copies > 8 || (dtype != GLA_F32 && dtype != GLA_F64) ||
+      (n_copies > 0 && (!src_host || !dst_host || !count_host)))
+    return GLA_ERR_INVALID_ARG;
+  CopyBatch cb;
+  int64_t most = 0;
+  int k = 0;
+  for (int i = 0; i < n_copies; ++i) {
+    if (count_host[i] < 0 || (count_host[i] > 0 && (!src_host[i] || !dst_host[i]))) return GLA_ERR_INVALID_ARG;
+    if (count_host[i] == 0) continue;
+    cb.src[k] = src_host[i]; cb.dst[k] = dst_host[i]; cb.count[k] = count_host[i];
+    cb.sstride[k] = src_stride_host ? src_stride_host[i] : 1;
+    if (cb.sstride[k] < 1) return GLA_ERR_INVALID_ARG;
+    most = count_host[i] > most ? count_host[i] : most;
+    ++k;
+  }
+  if (k == 0) return GLA_OK;
+  for (int i = k; i < 8; ++i) { cb.src[i] = nullptr; cb.dst[i] = nullptr; cb.count[i] = 0; cb.sstride[i] = 1; }
+  const dim3 grid(grid_for(most, GLA_BLOCK * 4, 256 * 8), (unsigned)k);
+  if (dtype == GLA_F64)
+    hipLaunchKernelGGL((copy_batch_kernel<double>), grid, dim3(GLA_BLOCK), 0, (hipStream_t)stream, cb);
+  else
+    hipLaunchKernelGGL((copy_batch_kernel<float>), grid, dim3(GLA_BLOCK), 0, (hipStream_t)stream, cb);
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }

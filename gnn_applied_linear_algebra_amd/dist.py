@@ -21,6 +21,8 @@ tests/test_dist_cpu.py covers it with world_size 2); `RowBlockJacobi` / `RowBloc
 import torch
 import torch.distributed as dist
 
+from ._common import scalar0
+
 class _Done:
     def wait(self):
         return True
@@ -391,13 +393,39 @@ class RowBlockJacobi(RowBlockOps):
             out.append((up, lo))                             # the neighbour above's LAST lines / below's FIRST lines
         return out
 
+    @staticmethod
+    def _copy_batch(pairs):
+        """dst[:] = src for every (src, dst) pair of 1-D tensors (src may be strided) in ONE launch (gla_copy_batch); plain
+        copies for CPU tensors."""
+        pairs = [(s_, d_) for s_, d_ in pairs if d_.numel()]
+        if not pairs:
+            return
+        if not pairs[0][1].is_cuda:
+            for s_, d_ in pairs:
+                d_.copy_(s_)
+            return
+        import ctypes
+        from ._lib import check, dtype_code, lib, stream_ptr
+        for i in range(0, len(pairs), 8):
+            chunk = pairs[i:i + 8]
+            k = len(chunk)
+            for s_, d_ in chunk:
+                assert s_.dim() == 1 and d_.dim() == 1 and d_.is_contiguous() and s_.numel() == d_.numel() and s_.dtype == d_.dtype
+            src = (ctypes.c_void_p * k)(*[s_.data_ptr() for s_, _ in chunk])
+            dst = (ctypes.c_void_p * k)(*[d_.data_ptr() for _, d_ in chunk])
+            cnt = (ctypes.c_int64 * k)(*[d_.numel() for _, d_ in chunk])
+            strd = (ctypes.c_int64 * k)(*[max(1, s_.stride(0)) for s_, _ in chunk])
+            check(lib().gla_copy_batch(dtype_code(chunk[0][1].dtype), k, src, dst, cnt, strd, stream_ptr(chunk[0][1].device)))
+
     def _fill_ghosts(self, ext_vecs, slabs):
         e = self.ext
+        pairs = []
         for vec, (upper, lower) in zip(ext_vecs, slabs):
             if upper is not None:
-                vec[:e["off"]] = upper
+                pairs.append((upper, vec[:e["off"]]))
             if lower is not None:
-                vec[e["off"] + self.part.n_local:] = lower
+                pairs.append((lower, vec[e["off"] + self.part.n_local:]))
+        self._copy_batch(pairs)
 
     def _forward_temporal(self, n_iters, va, w):
         import ctypes
@@ -423,10 +451,12 @@ class RowBlockJacobi(RowBlockOps):
                      and va.stride(1) == 1)
         if aos_first:
             E = (T + 2 * passes[0]) * S                      # rows the first / last edge block reads
+            pairs = []
             for a, b_ in ((0, E), (n_ext - E, n_ext)):
                 a, b_ = max(a, off), min(b_, off + nl)       # ... that are the rank's own
                 if a < b_:
-                    d_ext[a:b_], b_ext[a:b_], cur[a:b_] = va[a - off:b_ - off, 0], va[a - off:b_ - off, 1], va[a - off:b_ - off, 2]
+                    pairs += [(va[a - off:b_ - off, c_], vec[a:b_]) for c_, vec in enumerate((d_ext, b_ext, cur))]
+            self._copy_batch(pairs)
         else:
             outs = (ctypes.c_void_p * 3)(own(d_ext).data_ptr(), own(b_ext).data_ptr(), own(cur).data_ptr())
             check(lib().gla_split_columns(code, nl, 3, ptr(va), va.stride(0) if nl > 1 else 3, outs, st))
@@ -479,10 +509,10 @@ class RowBlockJacobi(RowBlockOps):
         if self.ext is not None and K == 1 and va.dim() == 2 and va.dtype == self.ext["dtype"] and int(n_iters) > 0:
             if va.stride(1) != 1:
                 va = va.contiguous()
-            return self._forward_temporal(int(n_iters), va, float(g.reshape(-1)[0]))
+            return self._forward_temporal(int(n_iters), va, scalar0(g))
         diag = (va[:, 0] if va.dim() == 2 else va[:, 0, 0]).contiguous()
         B = (va[:, 1].reshape(-1, 1) if va.dim() == 2 else va[:, 1, :]).contiguous()
-        w = float(g.reshape(-1)[0])
+        w = scalar0(g)
         cur = p.new_buffer(K, va.dtype, va.device)
         nxt = p.new_buffer(K, va.dtype, va.device)
         cur[:p.n_local] = va[:, 2].reshape(-1, 1) if va.dim() == 2 else va[:, 2, :]

@@ -273,6 +273,12 @@ int gla_mlp_relu3(int dtype, int64_t n, int in_dim, int h1, int h2, const void* 
 int gla_split_columns(int dtype, int64_t n, int a, const void* src, int64_t ld, void* const* cols_host,
                       gla_stream_t stream);
 
+/* Up to 8 vector copies in ONE launch: dst_i[j] = src_i[j * src_stride_i], j < count_i (HOST arrays of device pointers /
+ * counts / element strides; src_stride_host = NULL: all contiguous).  The multi-GPU route's ghost-line fills and the few AoS
+ * lines its edge blocks need: a dozen small hipMemcpyAsync calls (14 us each) become two launches. */
+int gla_copy_batch(int dtype, int n_copies, const void* const* src_host, void* const* dst_host, const int64_t* count_host,
+                   const int64_t* src_stride_host, gla_stream_t stream);
+
 /* Edge products in EDGE order: C[e,k] = A_e * X[col_e,k] -- the `c_ij`/`z_ij` column every EdgeUpdate
  * returns (e.g. JacobiGNN.py:83-88); materialised only when a caller asks for edge_attr. */
 int gla_edge_products(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* C, int64_t ldc,

@@ -1733,3 +1733,23 @@ def test_random_graphs_property():
             chk(lib().gla_set_option(b"compress", 0))
 
     check()
+
+
+def test_relaxation_weight_cache_follows_in_place_updates():
+    """JacobiGNN reads w = g[0] once per (tensor, version): an in-place change of a GPU-resident g is seen by the next call."""
+    ei, ev = rp.laplacianfun_torch(24)
+    n = 576
+    gen = torch.Generator().manual_seed(3)
+    va = torch.rand(n, 3, generator=gen, dtype=torch.float64)
+    va[:, 0] += 3.0
+    ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+    jac = gla.JacobiGNN.JacobiGNN()
+    g = d(torch.tensor([0.7], dtype=torch.float64))
+    for w in (0.7, 0.7, 0.45, 1.1):
+        g.fill_(w)                                            # in place: same storage, new version
+        got = jac(3, d(va), d(ei), d(ea), g)
+        want = rp.jacobi_forward(3, va, ei, ea, torch.tensor([w], dtype=torch.float64))
+        assert torch.equal(got.cpu(), want), w
+    g2 = g[:]                                                 # a view shares storage and version counter
+    g2.mul_(0.5)
+    assert torch.equal(jac(2, d(va), d(ei), d(ea), g).cpu(), rp.jacobi_forward(2, va, ei, ea, torch.tensor([0.55], dtype=torch.float64)))
