@@ -63,9 +63,15 @@ def chebyshev_relax(plan, b, x0, g, deg, out=None, need_gathered=True, b_copy=No
         p, p_next = (p_final, p_other) if (deg - 1) % 2 == 0 else (p_other, p_final)
         plan.cheby_first(b, x0, r, p, x, float(alphas[0]))
         done = 1
-    for it in range(done + 1, deg + 1):
-        plan.cheby_next(p, p_next, r, x, float(alphas[it - 2]), float(alphas[it - 1]), float(betas[it - 1]))
-        gathered, p, p_next = p, p_next, p
+    rest_steps = deg - done
+    if rest_steps > 0:
+        # the remaining steps done + 1 .. deg are enqueued by ONE library call (no host round trip per step)
+        its = range(done + 1, deg + 1)
+        plan.cheby_steps(p, p_next, r, x, [alphas[it - 2] for it in its], [alphas[it - 1] for it in its],
+                         [betas[it - 1] for it in its])
+        if rest_steps % 2 == 1:
+            p, p_next = p_next, p
+        gathered = p_next                                            # the operand the last step gathered
     alpha, beta = alphas[-1], betas[-1]
     g_out = torch.hstack([c, d, alpha] if beta is None else [c, d, alpha, beta]).to(g.device)
     return x, r, p, gathered, g_out

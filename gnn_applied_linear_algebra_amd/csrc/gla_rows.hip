@@ -1981,6 +1981,12 @@ int gla_jacobi_fused_parts_aos(gla_csr_t A, int dtype, const void* vertex_attr, 
     return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
   if (A->n_rows == 0) return GLA_OK;
+  // parts 0 and 2 read every row of the plan: only a tensor that holds them all will do
+  if (part != 1 && (row_offset != 0 || n_attr_rows < A->n_rows)) return GLA_ERR_INVALID_ARG;
+  // part 1 reads the plan rows outside the first / last ghost_lines grid lines: the tensor must hold those
+  if (part == 1 && A->dia_S > 0 &&
+      (row_offset > (int64_t)ghost_lines * A->dia_S || row_offset + n_attr_rows < A->n_rows - (int64_t)ghost_lines * A->dia_S))
+    return GLA_ERR_INVALID_ARG;
   if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A))) return GLA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == GLA_F64)
@@ -2070,6 +2076,23 @@ int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, vo
                         (T)alpha_old, (T)alpha_new, (T)beta};
     return launch_rows<T>(A, K, (const T*)P, ldp, epi, which, (hipStream_t)stream);
   })
+}
+
+int gla_cheby_steps(gla_csr_t A, int dtype, int K, int n_steps, void* P0, int64_t ldp0, void* P1, int64_t ldp1, void* R,
+                    int64_t ldr, void* X, int64_t ldx, const double* alpha_old_host, const double* alpha_new_host,
+                    const double* beta_host, gla_stream_t stream) {
+  if (n_steps < 0 || (n_steps > 0 && (!alpha_old_host || !alpha_new_host || !beta_host))) return GLA_ERR_INVALID_ARG;
+  void* p = P0;
+  void* pn = P1;
+  int64_t lp = ldp0, lpn = ldp1;
+  for (int i = 0; i < n_steps; ++i) {              // one launch per step, enqueued back to back: no host work between them
+    const int rc = gla_cheby_next(A, dtype, K, p, lp, pn, lpn, R, ldr, X, ldx, alpha_old_host[i], alpha_new_host[i],
+                                  beta_host[i], 0, stream);
+    if (rc) return rc;
+    void* t = p; p = pn; pn = t;
+    const int64_t tl = lp; lp = lpn; lpn = tl;
+  }
+  return GLA_OK;
 }
 
 static inline int64_t power_partials(const gla_csr* A) {

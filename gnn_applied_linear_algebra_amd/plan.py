@@ -288,6 +288,25 @@ class CsrPlan:
                                    stream_ptr(self.device)))
 
     @_on_device
+    def cheby_steps(self, P0, P1, R, X, alpha_old, alpha_new, beta):
+        """len(alpha_new) consecutive cheby_next steps enqueued by ONE library call (gla_cheby_steps): step i gathers from
+        P0 (i even) / P1 (i odd) and writes the other; R, X in place."""
+        import ctypes
+        k = len(alpha_new)
+        if k == 0:
+            return
+        P0, K, ldp0 = _dense(P0, self.n_cols, "P0")
+        P1, _, ldp1 = _dense(P1, self.n_rows, "P1")
+        R, _, ldr = _dense(R, self.n_rows, "R")
+        X, _, ldx = _dense(X, self.n_rows, "X")
+        self._need(P0.dtype)
+        assert P1.shape[1] == R.shape[1] == X.shape[1] == K and P1.dtype == R.dtype == X.dtype == P0.dtype
+        assert P0.data_ptr() != P1.data_ptr() and len(alpha_old) == k and len(beta) == k
+        arr = lambda v: (ctypes.c_double * k)(*[float(t) for t in v])      # noqa: E731
+        check(lib().gla_cheby_steps(self._h, dtype_code(P0.dtype), K, k, ptr(P0), ldp0, ptr(P1), ldp1, ptr(R), ldr, ptr(X), ldx,
+                                    arr(alpha_old), arr(alpha_new), arr(beta), stream_ptr(self.device)))
+
+    @_on_device
     def cheby_fused(self, B, X0, Xout, R, P, alphas, betas, Pprev=None, Bcopy=None):
         """Steps 1 .. len(alphas) (2 .. 4) of the Chebyshev relaxation in ONE pass (gla_cheby_fused).  Returns False when
         the plan / operands do not qualify (the caller runs cheby_first / cheby_next step by step), True otherwise."""

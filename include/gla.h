@@ -198,6 +198,13 @@ int gla_cheby_first(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, c
 int gla_cheby_next(gla_csr_t A, int dtype, int K, const void* P, int64_t ldp, void* Pout, int64_t ldpo,
                    void* R, int64_t ldr, void* X, int64_t ldx, double alpha_old, double alpha_new, double beta,
                    int which_tiles, gla_stream_t stream);
+/* n_steps consecutive gla_cheby_next steps enqueued from C (ChebyRelaxGNN's loop, ChebyGNN.py:322-351, without a host
+ * round trip per step: a degree-768 coarse solve on a 512^2 level is launch-bound).  Step i gathers from P0 (i even) or P1
+ * (i odd) and writes the other; R and X are updated in place; scalars of step i: alpha_old_host[i], alpha_new_host[i],
+ * beta_host[i].  After n_steps the newest p is in P0 (n_steps even) or P1 (odd), the previous one in the other. */
+int gla_cheby_steps(gla_csr_t A, int dtype, int K, int n_steps, void* P0, int64_t ldp0, void* P1, int64_t ldp1, void* R,
+                    int64_t ldr, void* X, int64_t ldx, const double* alpha_old_host, const double* alpha_new_host,
+                    const double* beta_host, gla_stream_t stream);
 
 /* The first `deg` (2 .. 4) Chebyshev steps in ONE pass over the data (temporal blocking, as gla_jacobi_sweeps does for
  * Jacobi): Xout, R, P = x, r, p after step `deg` of ChebyRelaxGNN (ChebyGNN.py:287-353) started from (B, X0);
