@@ -492,7 +492,8 @@ def col_scale_rsqrt(X, sumsq, out=None):
 
 def invalidate(*tensors):
     """Drop everything this package cached ON the given tensors: the CSR plan of an `edgeij_pair`, the CSR-ordered copy
-    of an `edge_attr`'s values (the plan re-gathers them on the next call), the GPU copy of a CPU operand.  The caches
+    of an `edge_attr`'s values (the plan re-gathers them on the next call), the GPU copy of a CPU operand, the remembered
+    relaxation weight of a GPU-resident `g`.  The caches
     are keyed on tensor identity plus torch's in-place version counter, which does NOT see writes made through a raw
     pointer, a NumPy view sharing the memory, or `.data`: after such a write call this (or pass a fresh tensor)."""
     for t in tensors:
@@ -511,6 +512,15 @@ def invalidate(*tensors):
             _PLANS_WITH_VALUES.discard(ref)
         elif plan._val_ref is not None and any(plan._val_ref() is t for t in tensors):
             plan._val_key = plan._val_ref = None
+    _SCALAR_CACHES_CLEAR()
+
+
+def _SCALAR_CACHES_CLEAR():
+    """(the remembered relaxation weights g[0] of GPU-resident `g` tensors, _common.scalar0)"""
+    import sys
+    mod = sys.modules.get(__package__ + "._common")
+    if mod is not None:
+        mod._SCALAR0.clear()
 
 
 _PLANS_WITH_VALUES = set()
