@@ -38,9 +38,11 @@ class PowerMethodGNN(torch.nn.Module):
         out_dtype = torch.result_type(va, g)
         gd = to_dev(g, dev).to(out_dtype).reshape(3, -1)
         nrm, n_A = gd[0].expand(K).clone(), gd[1].expand(K).clone()
+        tail_done, fused_tail_ok = False, False
         if self.num_iter > 0:
             try:
                 y, ss, work = plan.power_step(b)                 # iteration 1: b is used as given
+                fused_tail_ok = True
                 for _ in range(self.num_iter - 1):
                     y, ss, work = plan.power_step(y, nrm=torch.sqrt(ss), work=work)
             except _lib.GlaError as e:
@@ -50,19 +52,32 @@ class PowerMethodGNN(torch.nn.Module):
                 for it in range(self.num_iter):                  # unfused path, same arithmetic
                     y = plan.spmm(y if it == 0 else col_scale_rsqrt(y, ss))
                     ss = col_dot(y, y)
-            # Layer 3 of the last iteration: b <- b / n
-            b = col_scale_rsqrt(y, ss, out=res[:, 0, :] if in_place else None)
-            nrm = torch.sqrt(ss).to(out_dtype)
+            nrm_dev = torch.sqrt(ss)
+            nrm = nrm_dev.to(out_dtype)
+            # Layer 3 of the last iteration (b <- b / n), the Rayleigh layers' A b, n_A = sum b (A b), sum b^2 and the
+            # module's [b, b^2] result in ONE pass where the plan has the blocked stencil kernel (gla_power_rayleigh)
+            if in_place and fused_tail_ok:
+                sums = plan.power_rayleigh(y, nrm_dev, res[:, 0, :], res[:, 1, :])
+                if sums is not None:
+                    tail_done = True
+                    b = res[:, 0, :]
+                    n_A = sums[0].to(out_dtype)
+                    lam = n_A / sums[1].to(out_dtype)
+            if not tail_done:
+                b = col_scale_rsqrt(y, ss, out=res[:, 0, :] if in_place else None)
         elif in_place:
             res[:, 0, :] = b
             b = res[:, 0, :]
-        Ab = plan.spmm(b)                             # Rayleigh layer 1: y = b * (A b); n_A = sum y  (:209-266)
-        n_A = col_dot(b, Ab).to(out_dtype)
-        lam = n_A / col_dot(b, b).to(out_dtype)       # Rayleigh layer 2: lambda = n_A / sum b^2      (:268-294)
+        if not tail_done:
+            Ab = plan.spmm(b)                             # Rayleigh layer 1: y = b * (A b); n_A = sum y  (:209-266)
+            n_A = col_dot(b, Ab).to(out_dtype)
+            lam = n_A / col_dot(b, b).to(out_dtype)       # Rayleigh layer 2: lambda = n_A / sum b^2      (:268-294)
         g_out = torch.stack([nrm, n_A, lam], 0)
         g_out = g_out.reshape(3) if g.dim() == 1 else g_out
         ea_out = plan.edge_attr(b) if self.return_edge_attr else None           # [A_ij, A_ij * b_j] in one pass
-        if in_place:
+        if tail_done:
+            pass                                          # [b, b^2] already written by the fused tail
+        elif in_place:
             torch.mul(b, b, out=res[:, 1, :])
         else:
             res = stack_cols([b, b * b], va)

@@ -748,6 +748,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_dia2d_kernel(Dia2D dv, const T
   // ---- products and in-order row sums from LDS, fused vertex update; BJ passes of BI rows, 4 passes in flight
   const int ii = tid / KV;
   TV red = TV(T(0));
+  [[maybe_unused]] TV red2 = TV(T(0));
   constexpr int G = DMAX > 5 ? 2 : (BJ < 4 ? BJ : 4);      // 9+ diagonals: two passes in flight keep the kernel under 128 VGPRs
 #pragma unroll 1
   for (int g = 0; g < BJ; g += G) {
@@ -783,15 +784,24 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_dia2d_kernel(Dia2D dv, const T
       if (m[u] & 0x10000) {
         epi.template applyv<TV>(rr[u], q * VW, acc[u], pre[u]);
         if constexpr (Epi::NRED > 0) red = red + epi.template redv<TV>(acc[u], pre[u]);
+        if constexpr (Epi::NRED > 1) red2 = red2 + epi.template redv2<TV>(acc[u], pre[u]);
       }
     }
   }
   if constexpr (Epi::NRED > 0) {       // lanes with the same rhs vector are KV apart: fixed-order sum over the rows
     const TV tot = block_lane_group_sum<KV>(red, reinterpret_cast<TV*>(smem_raw));
+    const int64_t blk = dv.part_off + (int64_t)jb * dv.nbi + ib;
     if (tid < KV) {
-      const int64_t blk = dv.part_off + (int64_t)jb * dv.nbi + ib;
 #pragma unroll
       for (int i = 0; i < VW; ++i) epi.partials_ptr()[blk * K + q * VW + i] = tot[i];
+    }
+    if constexpr (Epi::NRED > 1) {
+      __syncthreads();
+      const TV tot2 = block_lane_group_sum<KV>(red2, reinterpret_cast<TV*>(smem_raw));
+      if (tid < KV) {
+#pragma unroll
+        for (int i = 0; i < VW; ++i) epi.partials2_ptr()[blk * K + q * VW + i] = tot2[i];
+      }
     }
   }
 }
@@ -967,6 +977,27 @@ int launch_dia2d(gla_csr* A, const T* X, int64_t ldx, const Epi& epi, hipStream_
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }
+
+// The tail of PowerMethodGNN.forward in one pass of the blocked stencil kernel (PowerMethodGNN.py:187-294): b = y / n (the
+// last iteration's layer 3, applied while X is staged exactly as in EpiPower), then the Rayleigh layers' A b, n_A = sum b (A b)
+// and sum b^2 as two block partials, and the module's [b, b^2] result written straight out -- A b itself is never stored.
+template <typename T>
+struct EpiRayleigh : EpiPower<T> {
+  const T* x; int64_t ldx; T* bout; int64_t ldb; T* b2out; int64_t ldb2; T* partials2;
+  static constexpr int NRED = 2;
+  template <typename V> struct PreV { V b; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{this->template gx<V>(ldv<V>(x + r * ldx + k), this->template gx_load<V>(k))};
+  }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V, const PreV<V>& p) const {
+    stv<V>(bout + r * ldb + k, p.b);
+    stv<V>(b2out + r * ldb2 + k, p.b * p.b);
+  }
+  template <typename V> __device__ __forceinline__ V redv(V acc, const PreV<V>& p) const { return p.b * acc; }
+  template <typename V> __device__ __forceinline__ V redv2(V, const PreV<V>& p) const { return p.b * p.b; }
+  __device__ __forceinline__ T* partials2_ptr() const { return partials2; }
+  bool vec_ok(int w) const { return al16(x) && al16(bout) && al16(b2out) && ldx % w == 0 && ldb % w == 0 && ldb2 % w == 0; }
+};
 
 // number of 2-D blocks the blocked stencil kernel may use (upper bound over its block shapes): partials of reducing
 // epilogues need one slot per block
@@ -2132,6 +2163,41 @@ int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, co
                                tile_part + power_partials(A) * K, st);
     }
     return GLA_OK;
+  })
+}
+
+int gla_power_rayleigh(gla_csr_t A, int dtype, int K, const void* Y, int64_t ldy, const void* nrm_in, const void* rnrm_in,
+                       void* Bout, int64_t ldb, void* B2out, int64_t ldb2, void* nA_out, void* bb_out, void* work,
+                       gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;
+  if (!Y || !nrm_in || !rnrm_in || !Bout || !B2out || !nA_out || !bb_out || !work || ldy < K || ldb < K || ldb2 < K ||
+      Y == Bout || Y == B2out || Bout == B2out)
+    return GLA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  GLA_DISPATCH(dtype, {
+    // work: [partials of b (A b) | partials of b^2 | scratch of the column sums], each gla_power_work_bytes / 3 ... the
+    // caller passes 2 x gla_power_work_bytes: first half as gla_power_step uses it, second half for the b^2 partials
+    const int64_t half = power_partials(A) * K + (int64_t)DOT_BLOCKS_MAX * K;      // elements of one gla_power_step work area
+    T* w1 = (T*)work;
+    T* w2 = w1 + half;
+    EpiRayleigh<T> epi{{nullptr, 0, (const T*)nrm_in, (const T*)rnrm_in, w1}, (const T*)Y, ldy, (T*)Bout, ldb, (T*)B2out, ldb2, w2};
+    const int kv = dia2d_kv<T>(A, K, (const T*)Y, ldy, epi, 0);
+    if (!kv) return GLA_ERR_UNSUPPORTED;              // (no blocked stencil kernel for this plan / K: unfused tail)
+    const int bj = g_tuning.spmm_variant == 10 ? 8 : 4;
+    if (bj != 4) return GLA_ERR_UNSUPPORTED;
+    switch (kv) {
+      case 1: rc = launch_dia2d<T, EpiRayleigh<T>, 1, 4>(A, (const T*)Y, ldy, epi, st); break;
+      case 2: rc = launch_dia2d<T, EpiRayleigh<T>, 2, 4>(A, (const T*)Y, ldy, epi, st); break;
+      case 4: rc = launch_dia2d<T, EpiRayleigh<T>, 4, 4>(A, (const T*)Y, ldy, epi, st); break;
+      default: rc = launch_dia2d<T, EpiRayleigh<T>, 8, 4>(A, (const T*)Y, ldy, epi, st); break;
+    }
+    if (rc) return rc;
+    const int64_t rows_used = dia2d_nblocks(A, kv);
+    rc = launch_col_dot<T>(rows_used, K, w1, K, (const T*)nullptr, K, (T*)nA_out, w1 + power_partials(A) * K, st);
+    if (rc) return rc;
+    return launch_col_dot<T>(rows_used, K, w2, K, (const T*)nullptr, K, (T*)bb_out, w2 + power_partials(A) * K, st);
   })
 }
 

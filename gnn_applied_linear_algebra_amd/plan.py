@@ -357,6 +357,29 @@ class CsrPlan:
         return Y, sumsq, work
 
     @_on_device
+    def power_rayleigh(self, Y, nrm, Bout, B2out):
+        """The tail of the power method in one pass (gla_power_rayleigh): Bout = Y ./ nrm, B2out = Bout^2; returns
+        (n_A, sum b^2) [K] each, or None when the plan / K has no fused kernel (the caller runs the unfused tail)."""
+        Y, K, ldy = _dense(Y, self.n_cols, "Y")
+        Bout, Kb, ldb = _dense(Bout, self.n_rows, "Bout")
+        B2out, Kb2, ldb2 = _dense(B2out, self.n_rows, "B2out")
+        if self.n_rows != self.n_cols or Kb != K or Kb2 != K or Bout.dtype != Y.dtype or B2out.dtype != Y.dtype:
+            return None
+        self._need(Y.dtype)
+        code = dtype_code(Y.dtype)
+        assert nrm.numel() == K and nrm.dtype == Y.dtype and nrm.is_cuda and nrm.is_contiguous()
+        work = torch.empty(2 * lib().gla_power_work_bytes(self._h, K, code), dtype=torch.uint8, device=self.device)
+        n_A = torch.empty(K, dtype=Y.dtype, device=self.device)
+        bb = torch.empty(K, dtype=Y.dtype, device=self.device)
+        rnrm = torch.reciprocal(nrm)
+        rc = lib().gla_power_rayleigh(self._h, code, K, ptr(Y), ldy, ptr(nrm), ptr(rnrm), ptr(Bout), ldb, ptr(B2out), ldb2,
+                                      ptr(n_A), ptr(bb), ptr(work), stream_ptr(self.device))
+        if rc == -5:
+            return None
+        check(rc)
+        return n_A, bb
+
+    @_on_device
     def segment_reduce(self, src, reduce="sum"):
         """torch_scatter.scatter(src, row, dim=0, dim_size=n_rows, reduce=...) on the plan's row structure; src is in
         EDGE order, [nnz] or [nnz, K]; returns [n_rows] resp. [n_rows, K]."""

@@ -242,6 +242,15 @@ int64_t gla_power_work_bytes(gla_csr_t A, int K, int dtype);
 int gla_power_step(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, const void* nrm_in,
                    const void* rnrm_in, void* Y, int64_t ldy, void* sumsq_out, void* work, int which_tiles,
                    gla_stream_t stream);
+/* The tail of PowerMethodGNN.forward in ONE pass (PowerMethodGNN.py:187-294): Bout = Y / nrm (layer 3 of the last iteration,
+ * bit-identical to gla_col_scale_rsqrt), B2out = Bout^2, nA_out[k] = sum_i Bout[i,k] (A Bout)[i,k] and bb_out[k] = sum_i
+ * Bout[i,k]^2 -- A Bout itself is never stored (unfused: a scale pass, an SpMM, two dot products and a square: 3.5 ms at
+ * 4096^2 x 16, fused 1.5 ms).  nrm_in / rnrm_in [K] as for gla_power_step; work: 2 x gla_power_work_bytes.  The sums go
+ * through block partials (fixed order, but not gla_col_dot's): they agree with the unfused path to rounding.
+ * 2-D stencil plans with K a multiple of the 16-byte vector; GLA_ERR_UNSUPPORTED otherwise (run the unfused tail). */
+int gla_power_rayleigh(gla_csr_t A, int dtype, int K, const void* Y, int64_t ldy, const void* nrm_in, const void* rnrm_in,
+                       void* Bout, int64_t ldb, void* B2out, int64_t ldb2, void* nA_out, void* bb_out, void* work,
+                       gla_stream_t stream);
 
 /* The aggregation primitive on its own: out[i,k] = reduce over the edges e with row(e) = i of src[e,k], src in EDGE
  * order [nnz, K].  op: 0 sum (edge order, = the reference's sequential scatter-add), 1 max, 2 min, 3 mean; rows

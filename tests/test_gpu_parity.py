@@ -1753,3 +1753,37 @@ def test_relaxation_weight_cache_follows_in_place_updates():
     g2 = g[:]                                                 # a view shares storage and version counter
     g2.mul_(0.5)
     assert torch.equal(jac(2, d(va), d(ei), d(ea), g).cpu(), rp.jacobi_forward(2, va, ei, ea, torch.tensor([0.55], dtype=torch.float64)))
+
+
+def test_power_rayleigh_tail_fused():
+    """gla_power_rayleigh (layer 3 of the last power iteration + both Rayleigh layers + the [b, b^2] result in one pass):
+    b and b^2 bit-identical to the unfused tail (gla_col_scale_rsqrt, square), n_A = sum b (A b) and sum b^2 to rounding
+    (block partials instead of gla_col_dot's order); 5- and 9-point plans, K = 2 ... 16, fp64 / fp32; declined (None)
+    for K = 1 and non-stencil plans."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd.plan import col_dot, col_scale_rsqrt
+    gen = torch.Generator().manual_seed(77)
+    for name, ei, ev, n in (("laplacian 130 x 70", *rp.laplacianfun_torch(130, 70), 9100),
+                            ("fem 9-point 70 x 58", *rp.heateqnfem2dfun([71, 59], [1.0, 4.0]), 70 * 58)):
+        for dtype in (torch.float64, torch.float32):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            for K in (2, 4, 8, 16):
+                if dtype == torch.float32 and K < 4:
+                    continue                                   # (a 16-byte vector is four floats)
+                y = d(torch.rand(n, K, generator=gen, dtype=torch.float64).to(dtype) - 0.3)
+                ss = col_dot(y, y)
+                nrm = torch.sqrt(ss)
+                res = torch.zeros(n, 2, K, dtype=dtype, device=DEV)
+                got = plan.power_rayleigh(y, nrm, res[:, 0, :], res[:, 1, :])
+                if got is None:                                # one 16-byte vector per row: the blocked kernel's LDS window
+                    assert K * y.element_size() == 16, (name, dtype, K)            # of 256 points may not fit
+                    continue
+                b = col_scale_rsqrt(y, ss)
+                assert torch.equal(res[:, 0, :], b) and torch.equal(res[:, 1, :], b * b), (name, dtype, K)
+                tol = 1e-12 if dtype == torch.float64 else 2e-5
+                assert torch.allclose(got[0], col_dot(b, plan.spmm(b)), rtol=tol, atol=0), (name, dtype, K)
+                assert torch.allclose(got[1], col_dot(b, b), rtol=tol, atol=0), (name, dtype, K)
+            y1 = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            r1 = torch.zeros(n, 2, 1, dtype=dtype, device=DEV)
+            assert plan.power_rayleigh(y1, torch.sqrt(col_dot(y1, y1)), r1[:, 0, :], r1[:, 1, :]) is None
