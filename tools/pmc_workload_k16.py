@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc workload: 5 launches each of the K = 16 SpMM / Jacobi / Chebyshev-next kernels at 4096^2."""
+"""Workload for rocprofv3 --pmc passes over BASELINE config 3's kernels: ChebyRelaxGNN(4) (one fused pass,
+cheby_march5_kernel) and PowerMethodGNN(10) (spmm_dia2d_kernel<EpiPower> x 10 + the fused Rayleigh tail) on the
+4096^2 Laplacian with 16 right-hand sides, plus a calibration add of known volume (FETCH_SIZE x 2 on gfx950)."""
 import os
 import sys
 
@@ -8,21 +10,23 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnn_applied_linear_algebra_amd as gla  # noqa: E402
 
-N, K = 4096, 16
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = 16
 dev = torch.device("cuda:0")
 ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=dev)
 n = N * N
-plan = gla.CsrPlan(ei, n)
-plan.set_values(ev)
-del ei
 gen = torch.Generator().manual_seed(1)
-X = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
-B = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
-Y, R, P2, Xo = (torch.empty_like(X) for _ in range(4))
-diag = torch.full((n,), -4.0, dtype=torch.float64, device=dev)
-for _ in range(5):
-    plan.spmm(X, out=Y)
-    plan.jacobi_sweep(diag, B, X, Xo, 0.7)
-    plan.cheby_next(B, P2, R, Xo, -0.25, -0.26, 0.1)
+va = torch.rand(n, 2, K, generator=gen, dtype=torch.float64).to(dev)
+cheb = gla.ChebyGNN.ChebyRelaxGNN(4, return_edge_attr=False)
+powm = gla.PowerMethodGNN.PowerMethodGNN(10, return_edge_attr=False)
+g2 = torch.tensor([-3.4, -4.0], dtype=torch.float64)
+g3 = torch.zeros(3, K, dtype=torch.float64)
+for _ in range(2):
+    out = cheb(va, ei, ev, g2)
+    outp = powm(va, ei, ev, g3)
 torch.cuda.synchronize()
-print("done")
+a = torch.rand(64 * 1024 * 1024, dtype=torch.float64, device=dev)
+c = torch.rand(64 * 1024 * 1024, dtype=torch.float64, device=dev)
+d = a + c
+torch.cuda.synchronize()
+print("done", float(out[0][0, 1, 0]), float(outp[2][2, 0]), float(d[0]))
