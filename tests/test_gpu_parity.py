@@ -1787,3 +1787,18 @@ def test_power_rayleigh_tail_fused():
             y1 = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
             r1 = torch.zeros(n, 2, 1, dtype=dtype, device=DEV)
             assert plan.power_rayleigh(y1, torch.sqrt(col_dot(y1, y1)), r1[:, 0, :], r1[:, 1, :]) is None
+
+
+def test_jacobi_march_randomised():
+    import os
+    """tools/fuzz_jacobi_march.py: 150 random grid shapes / patterns with holes / dtypes / sweep counts / block heights /
+    sweeps-per-pass caps through gla_jacobi_sweeps, the AoS entry point and gla_jacobi_fused_residual, bit for bit."""
+    default_layout_only()
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GLA_OPTIONS", None)
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_jacobi_march.py"), "150", "7"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
