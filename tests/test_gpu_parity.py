@@ -1802,3 +1802,18 @@ def test_jacobi_march_randomised():
     r = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_jacobi_march.py"), "150", "7"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cheby_fused_randomised():
+    """tools/fuzz_cheby_fused.py: 120 random grids / 5-point-type and 9-point patterns / K / degrees / dtypes through
+    chebyshev_relax (fused pass + C-side step loop) against one kernel per step, bit for bit."""
+    import os
+    default_layout_only()
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GLA_OPTIONS", None)
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_cheby_fused.py"), "120", "11"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
