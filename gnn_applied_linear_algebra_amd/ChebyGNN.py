@@ -14,6 +14,25 @@ from ._common import aggregate, back, cols, compute_device, float_dtype, plan_fo
 FUSED_MAX = 4          # gla_cheby_fused takes the first 2 .. 4 steps in one pass over the data
 
 
+def _scalars(g, deg):
+    """The scalar recurrences of the global updates, all steps up front (they do not depend on the vectors), evaluated in
+    g's dtype on the host exactly as the reference's GlobalUpdate modules do."""
+    gh = g.detach().to("cpu")
+    c, d = gh[0], gh[1]
+    alphas, betas = [1 / d], [None]                                  # ChebyGNN.py:137
+    for it in range(2, deg + 1):
+        a_prev = alphas[-1]
+        beta = 0.5 * (c * a_prev) ** 2 if it == 2 else ((c * a_prev) / 2) ** 2      # :262 / :283
+        alphas.append(1 / (d - beta / a_prev))                                      # :263 / :283
+        betas.append(beta)
+    return c, d, alphas, betas
+
+
+def _g_out(c, d, alphas, betas, g):
+    alpha, beta = alphas[-1], betas[-1]
+    return torch.hstack([c, d, alpha] if beta is None else [c, d, alpha, beta]).to(g.device)
+
+
 def chebyshev_relax(plan, b, x0, g, deg, out=None, need_gathered=True, b_copy=None):
     """Core of ChebyRelaxGNN on SoA operands: b, x0 [n, K] (row-major, any leading dimension), g = [c, d] (any
     device).  Runs `deg` steps on `plan` and returns (x, r, p, gathered, g_out) where `gathered` is the vector
@@ -23,15 +42,7 @@ def chebyshev_relax(plan, b, x0, g, deg, out=None, need_gathered=True, b_copy=No
     b_copy: where the module's [b, x, r, p] result wants its copy of b (written by the fused pass, else copied here).
     On 2-D stencil plans with K a multiple of the 16-byte vector the first min(deg, 4) steps run as ONE temporally
     blocked pass (gla_cheby_fused, bit-identical); the rest, and every other case, one fused kernel per step."""
-    gh = g.detach().to("cpu")
-    c, d = gh[0], gh[1]
-    # the scalar recurrences of the global updates, all steps up front (they do not depend on the vectors)
-    alphas, betas = [1 / d], [None]                                  # ChebyGNN.py:137
-    for it in range(2, deg + 1):
-        a_prev = alphas[-1]
-        beta = 0.5 * (c * a_prev) ** 2 if it == 2 else ((c * a_prev) / 2) ** 2      # :262 / :282
-        alphas.append(1 / (d - beta / a_prev))                                      # :263 / :283
-        betas.append(beta)
+    c, d, alphas, betas = _scalars(g, deg)
     if out is None:
         r, p_final, x = torch.empty_like(b), torch.empty_like(b), torch.empty_like(b)
     else:
@@ -72,9 +83,7 @@ def chebyshev_relax(plan, b, x0, g, deg, out=None, need_gathered=True, b_copy=No
         if rest_steps % 2 == 1:
             p, p_next = p_next, p
         gathered = p_next                                            # the operand the last step gathered
-    alpha, beta = alphas[-1], betas[-1]
-    g_out = torch.hstack([c, d, alpha] if beta is None else [c, d, alpha, beta]).to(g.device)
-    return x, r, p, gathered, g_out
+    return x, r, p, gathered, _g_out(c, d, alphas, betas, g)
 
 
 class ChebyRelaxGNN(torch.nn.Module):
@@ -102,6 +111,17 @@ class ChebyRelaxGNN(torch.nn.Module):
                                                        out=(res[:, 1, :], res[:, 2, :], res[:, 3, :]),
                                                        need_gathered=self.return_edge_attr, b_copy=res[:, 0, :])
         else:
+            if va.dim() == 2 and 2 <= self.deg <= FUSED_MAX and va.is_contiguous():
+                # single right-hand side, up to four steps: the fused pass reads b, x as columns of the AoS input and
+                # writes [b, x, r, p] straight into the AoS result (no split / stack passes) where the plan qualifies
+                c_, d_, alphas, betas = _scalars(g, self.deg)
+                res = torch.empty((va.shape[0], 4), dtype=va.dtype, device=va.device)
+                pprev = torch.empty((va.shape[0], 1), dtype=va.dtype, device=va.device) if self.return_edge_attr else None
+                if plan.cheby_fused(va[:, 0:1], va[:, 1:2], res[:, 1:2], res[:, 2:3], res[:, 3:4],
+                                    [float(a) for a in alphas], [0.0] + [float(v) for v in betas[1:]],
+                                    Pprev=pprev, Bcopy=res[:, 0:1]):
+                    ea_out = plan.edge_attr(pprev) if self.return_edge_attr else None
+                    return back(res, vertex_attr), back(ea_out, edge_attr), _g_out(c_, d_, alphas, betas, g)
             b, x0 = split_cols(va) if va.dim() == 2 else (cols(va, 0), cols(va, 1))
             x, r, p, gathered, g_out = chebyshev_relax(plan, b, x0, g, self.deg, need_gathered=self.return_edge_attr)
             res = stack_cols([b, x, r, p], va)

@@ -171,12 +171,11 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_fused_dia2d_kernel(
 // Rows above a step's first valid line carry garbage through the first line steps; it never reaches a stored value
 // (step t is valid from line -(DEG - t) on, and a valid line only reads valid lines of the step below).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KV, int DEG>
+template <typename T, int KV, int DEG, int VW = 16 / (int)sizeof(T)>      // VW = 1: one right-hand side (lanes = points)
 __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
     Cheb2D cv, const T* __restrict__ bvec, int64_t ldb, const T* __restrict__ x0, int64_t ldx0, T* __restrict__ xout,
     int64_t ldxo, T* __restrict__ rout, int64_t ldr, T* __restrict__ pout, int64_t ldp, T* __restrict__ pprev,
     int64_t ldpp, T* __restrict__ bcopy, int64_t ldbc, int lines, int nstrips, int64_t nlines, TileMap tm) {
-  constexpr int VW = 16 / (int)sizeof(T);
   constexpr int BP = GLA_BLOCK / KV;               // grid points of a strip
   constexpr int LWV = (BP + 2) * KV;               // 16-byte vectors of a line in LDS: point ii at [(1 + ii) * KV + q]
   constexpr int NC = DEG + 1, U = NC;
@@ -318,6 +317,28 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
   }
 }
 
+// one right-hand side: the march kernel with scalar lanes (256 points per strip); canonical 5-point plans only
+template <typename T, int DEG>
+int launch_cheby_fused_k1(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout,
+                          int64_t ldxo, T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc,
+                          hipStream_t st) {
+  constexpr int BP = GLA_BLOCK;
+  const int bp_eff = BP - 2 * DEG;
+  const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
+  const int nstrips = (int)((A->dia_S + bp_eff - 1) / bp_eff);
+  const size_t lds = (size_t)DEG * 2 * (BP + 2) * sizeof(T);
+  int lines = g_tuning.jacobi_lines;
+  if (lines <= 0) lines = gla_pick_block_lines(nlines, nstrips, 256 * 2, 2 * (DEG - 1), 2 * DEG);
+  TileMap tm;
+  tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
+  tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
+  set_tile_mapping(tm);
+  hipLaunchKernelGGL((cheby_march5_kernel<T, 1, DEG, 1>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds, st,
+                     cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
 template <typename T, int KV, int DEG>
 int launch_cheby_fused(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout,
                        int64_t ldxo, T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc,
@@ -367,6 +388,22 @@ int cheby_fused_impl(gla_csr* A, int K, int deg, const T* b, int64_t ldb, const 
                      T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc, const double* alpha,
                      const double* beta, hipStream_t st) {
   constexpr int VW = 16 / (int)sizeof(T);
+  if (K == 1) {                                     // single right-hand side (the reference's own ChebyRelaxGNN): scalar lanes
+    if (!(g_tuning.jacobi_march && gla_dia_canon5(A))) return GLA_ERR_UNSUPPORTED;
+    Cheb2D cv1;
+    cv1.val = A->dia_val;
+    cv1.mask = A->dia_mask;
+    cv1.D = A->dia_D; cv1.S = A->dia_S; cv1.B = A->dia_B;
+    for (int i = 0; i < CH_DMAX; ++i) { cv1.da[i] = A->dia_a[i]; cv1.db[i] = A->dia_b[i]; }
+    cv1.n_rows = A->n_rows; cv1.n_cols = A->n_cols;
+    for (int i = 0; i < CH_DEG_MAX; ++i) { cv1.alpha[i] = i < deg ? alpha[i] : 0.0; cv1.beta[i] = i < deg ? beta[i] : 0.0; }
+    switch (deg) {
+      case 2: return launch_cheby_fused_k1<T, 2>(A, cv1, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+      case 3: return launch_cheby_fused_k1<T, 3>(A, cv1, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+      case 4: return launch_cheby_fused_k1<T, 4>(A, cv1, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
+      default: return GLA_ERR_UNSUPPORTED;
+    }
+  }
   const int kv = K / VW;
   const bool ptr_ok = al16(b) && al16(x0) && al16(xout) && al16(r) && al16(p) && (!pprev || al16(pprev)) &&
                       (!bcopy || (al16(bcopy) && ldbc % VW == 0)) &&

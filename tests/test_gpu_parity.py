@@ -1215,8 +1215,9 @@ def test_generic_stencils_blocked_and_fused_kernels():
 def test_cheby_fused_pass_bit_identical():
     """gla_cheby_fused (steps 1 .. deg of ChebyRelaxGNN in ONE pass over the data, deg = 2, 3, 4) against the
     step-by-step kernels gla_cheby_first + gla_cheby_next: x, r, p and the operand of the last step, bit for bit;
-    K = 1, 2, 4, 8 16-byte vectors, fp64 and fp32, ragged grid sizes, a 5-point pattern with holes, a B = 2 stencil;
-    operands with leading dimensions (columns of an AoS tensor).  9-point plans and K = 1 are declined (False)."""
+    K = 1, 2, 4, 8 16-byte vectors and a single right-hand side (canonical 5-point plans), fp64 and fp32, ragged grid
+    sizes, a 5-point pattern with holes, a B = 2 stencil; operands with leading dimensions (columns of an AoS tensor).
+    9-point plans, and K = 1 on non-canonical patterns, are declined (False)."""
     default_layout_only()
     gen = torch.Generator().manual_seed(91)
     cases = [("laplacian 300 x 70", *rp.laplacianfun_torch(300, 70), 21000),
@@ -1226,10 +1227,12 @@ def test_cheby_fused_pass_bit_identical():
     ei, ev = _stencil_matrix(70, 45, [(-1, 0), (0, -2), (0, 0), (0, 2), (1, 0)], gen, 0.0)
     cases.append(("B = 2", ei, ev, 3150))
     for name, ei, ev, n in cases:
-        for dtype, Ks in ((torch.float64, (2, 4, 8, 16)), (torch.float32, (4, 8, 16, 32))):
+        for dtype, Ks in ((torch.float64, (1, 2, 4, 8, 16)), (torch.float32, (1, 4, 8, 16, 32))):
             plan = gla.CsrPlan(d(ei), n)
             plan.set_values(d(ev.to(dtype)))
             for K in Ks:
+                if K == 1 and plan.info.dia_canon5 != 1:
+                    continue                                  # one right-hand side: canonical 5-point plans only (below)
                 g2 = torch.Generator().manual_seed(K)
                 wide_b = d(torch.rand(n, 3, K, generator=g2, dtype=torch.float64).to(dtype))      # b, x0 as AoS columns
                 b, x0 = wide_b[:, 0, :], wide_b[:, 2, :]
@@ -1252,11 +1255,11 @@ def test_cheby_fused_pass_bit_identical():
                                             (pprev, prev, "p_prev")):
                         assert torch.equal(got, want), (name, dtype, K, deg, what, float((got - want).abs().max()))
                     assert bool((res[:, 2, :] == 0).all())                     # the neighbouring AoS column is untouched
-    # declined: one right-hand side (no 16-byte vector of them), and the 9-point operator
-    ei, ev = rp.laplacianfun_torch(40)
-    plan = gla.CsrPlan(d(ei), 1600)
+    # declined: one right-hand side on a plan that is not the canonical 5-point pattern, and the 9-point operator
+    ei, ev = _stencil_matrix(70, 45, [(-1, 0), (0, -2), (0, 0), (0, 2), (1, 0)], gen, 0.0)
+    plan = gla.CsrPlan(d(ei), 3150)
     plan.set_values(d(ev))
-    v = [torch.zeros(1600, 1, dtype=torch.float64, device=DEV) for _ in range(5)]
+    v = [torch.zeros(3150, 1, dtype=torch.float64, device=DEV) for _ in range(5)]
     assert plan.cheby_fused(v[0], v[1], v[2], v[3], v[4], [-0.25, -0.26], [0.0, 0.1]) is False
     ei, ev = rp.heateqnfem2dfun([41, 41], [1.0, 1.0])
     plan = gla.CsrPlan(d(ei), 1600)
