@@ -354,5 +354,5 @@ class AMGHierarchy:
             r = self.residual(b, x, level)
         rc = self.Pt[level].spmm(r)
         xc = self.cycle(rc, torch.zeros_like(rc), level + 1)
-        x = x + self.P[level].spmm(xc.contiguous())
+        x = self.P[level].spmm_add(x.contiguous(), xc.contiguous())       # x + P xc in one pass (gla_spmm_add)
         return self._smooth(level, self.n_post, b, x)

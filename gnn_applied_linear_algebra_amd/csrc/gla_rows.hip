@@ -62,6 +62,20 @@ struct EpiStore {                       // y = A x                       MatVecG
 };
 
 template <typename T>
+struct EpiAddTo {                       // y = z + A x                   the coarse-grid correction x + P xc, VCycle.py:228
+  const T* z; int64_t ldz; T* y; int64_t ldy;
+  template <typename V> struct PreV { V z; };
+  template <typename V> __device__ __forceinline__ PreV<V> loadv(int64_t r, int k) const {
+    return PreV<V>{ldv<V>(z + r * ldz + k)};
+  }
+  template <typename V> __device__ __forceinline__ void applyv(int64_t r, int k, V acc, const PreV<V>& p) const {
+    stv<V>(y + r * ldy + k, p.z + acc);
+  }
+  bool vec_ok(int w) const { return al16(z) && al16(y) && ldz % w == 0 && ldy % w == 0; }
+  GLA_EPI_SCALAR_API
+};
+
+template <typename T>
 struct EpiResidual {                    // r = b - A x                   GNNResidual.py:97-118
   const T* b; int64_t ldb; T* res; int64_t ldr;
   template <typename V> struct PreV { V b; };
@@ -1912,6 +1926,18 @@ int gla_residual(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, cons
   if (!B || !X || !R || ldb < K || ldx < K || ldr < K) return GLA_ERR_INVALID_ARG;
   GLA_DISPATCH(dtype, {
     EpiResidual<T> epi{(const T*)B, ldb, (T*)R, ldr};
+    return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
+  })
+}
+
+int gla_spmm_add(gla_csr_t A, int dtype, int K, const void* Z, int64_t ldz, const void* X, int64_t ldx, void* Y,
+                 int64_t ldy, int which, gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (A->n_rows == 0) return GLA_OK;      // nothing to compute; empty operands may be null
+  if (!Z || !X || !Y || ldz < K || ldx < K || ldy < K) return GLA_ERR_INVALID_ARG;
+  GLA_DISPATCH(dtype, {
+    EpiAddTo<T> epi{(const T*)Z, ldz, (T*)Y, ldy};
     return launch_rows<T>(A, K, (const T*)X, ldx, epi, which, (hipStream_t)stream);
   })
 }

@@ -158,6 +158,19 @@ class CsrPlan:
         return Y
 
     @_on_device
+    def spmm_add(self, Z, X, out=None, which=ALL_TILES):
+        """Z + A X in one pass (gla_spmm_add); out may be Z itself."""
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        Z, Kz, ldz = _dense(Z, self.n_rows, "Z")
+        self._need(X.dtype)
+        Y = torch.empty((self.n_rows, K), dtype=X.dtype, device=self.device) if out is None else out
+        Y, Ky, ldy = _dense(Y, self.n_rows, "Y")
+        assert Kz == K and Ky == K and Z.dtype == X.dtype == Y.dtype
+        check(lib().gla_spmm_add(self._h, dtype_code(X.dtype), K, ptr(Z), ldz, ptr(X), ldx, ptr(Y), ldy, which,
+                                 stream_ptr(self.device)))
+        return Y
+
+    @_on_device
     def residual(self, B, X, out=None, which=ALL_TILES):
         X, K, ldx = _dense(X, self.n_cols, "X")
         B, Kb, ldb = _dense(B, self.n_rows, "B")

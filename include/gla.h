@@ -122,6 +122,11 @@ int gla_csr_classify_tiles(gla_csr_t plan, int64_t col_limit, gla_stream_t strea
 int gla_spmm(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* Y, int64_t ldy,
              int which_tiles, gla_stream_t stream);
 
+/* Y = Z + A X (Y may be Z): the coarse-grid correction x + P xc of a V-cycle (VCycle.py:228) without a separate add pass;
+ * the row sum is formed first and added to Z afterwards, as torch's `x + P @ xc` rounds. */
+int gla_spmm_add(gla_csr_t A, int dtype, int K, const void* Z, int64_t ldz, const void* X, int64_t ldx, void* Y,
+                 int64_t ldy, int which_tiles, gla_stream_t stream);
+
 /* R = B - A X.  GNNResidual.py:43-132 (r_i = b_i - cbar_i, :110). */
 int gla_residual(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, const void* X, int64_t ldx,
                  void* R, int64_t ldr, int which_tiles, gla_stream_t stream);
