@@ -117,6 +117,11 @@ inline bool gla_dia_canon5(const gla_csr* A) {
   return true;
 }
 
+// jacobik.hip: `sweeps` (2 .. GLA_JACOBIK_TS_MAX) Jacobi sweeps of K right-hand sides in one temporally blocked pass
+constexpr int GLA_JACOBIK_TS_MAX = 4;
+int gla_jacobik_pass(gla_csr* A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X, int64_t ldx,
+                     void* Xout, int64_t ldxo, double w, int sweeps, hipStream_t st);
+
 // plan.hip
 int gla_sort_rows_stable(int64_t nnz, int64_t n_rows, const int64_t* row, int32_t* perm_out,
                          uint32_t* keys_sorted, hipStream_t stream);

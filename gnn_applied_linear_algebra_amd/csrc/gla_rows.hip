@@ -2088,6 +2088,32 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
   // Same arithmetic per row: bit-identical.  Option "jacobi_fuse": 0 off, 1 (default), 2 at most two per pass.
   JacobiPlan plan;
   jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && diag && B && X0, n_iters, plan);
+  // K right-hand sides on canonical 5- / 9-point plans: passes of up to GLA_JACOBIK_TS_MAX sweeps (jacobi_marchk_kernel,
+  // gla_jacobik.hip), ceil(n / 4) passes of equal size +- 1; anything it declines keeps one sweep per launch
+  if (K > 1 && n_iters >= 2 && g_tuning.jacobi_fuse == 1 && diag && B && X0 && A->val_dtype == dtype &&
+      A->n_rows * (int64_t)K >= g_tuning.jacobi_min_rows && (gla_dia_canon5(A) || gla_dia_canon9(A))) {
+    const int k = (n_iters + GLA_JACOBIK_TS_MAX - 1) / GLA_JACOBIK_TS_MAX, base = n_iters / k, r = n_iters % k;
+    const int n_single = base < 2 ? k - r : 0;             // (base = 1 only for n_iters = ... never with n_iters >= 2 and k = ceil(n / 4))
+    (void)n_single;
+    const void* src = X0;
+    int64_t lsrc = ldx0;
+    int rc = GLA_OK;
+    bool declined = false;
+    for (int i = 1; i <= k; ++i) {
+      void* dst = ((k - i) % 2 == 0) ? Xout : Xtmp;
+      const int ts = i <= r ? base + 1 : base;
+      if (ts >= 2) {
+        rc = gla_jacobik_pass(A, dtype, K, diag, B, ldb, src, lsrc, dst, ldw, w, ts, (hipStream_t)stream);
+        if (rc == GLA_ERR_UNSUPPORTED && i == 1) { declined = true; break; }
+      } else {
+        rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, src, lsrc, dst, ldw, w, 0, stream);
+      }
+      if (rc) return rc;
+      src = dst;
+      lsrc = ldw;
+    }
+    if (!declined) return GLA_OK;
+  }
   const int n_launch = jacobi_plan_launches(plan);
   const void* src = X0;
   int64_t lds_ = ldx0;

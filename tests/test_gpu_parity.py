@@ -1820,3 +1820,50 @@ def test_cheby_fused_randomised():
     r = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_cheby_fused.py"), "120", "11"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_jacobi_multi_rhs_temporal_blocking_bit_identical():
+    """gla_jacobi_sweeps on K right-hand sides takes up to four (9-point: three) sweeps per pass on canonical stencil plans
+    (jacobi_marchk_kernel): bit-identical to single sweeps for K = 2 ... 16, sweep counts 1 ... 11, 5- / 9-point patterns,
+    holes, ragged grids, fp64 / fp32, operands with leading dimensions; through plan.jacobi_sweeps and JacobiGNN [n, 3, K]."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+    gen = torch.Generator().manual_seed(55)
+    cases = [("laplacian 130 x 70", *rp.laplacianfun_torch(130, 70), 9100),
+             ("laplacian 40 x 9", *rp.laplacianfun_torch(40, 9), 360),
+             ("fem 9-point 70 x 58", *rp.heateqnfem2dfun([71, 59], [1.0, 4.0]), 70 * 58)]
+    ei, ev = _stencil_matrix(150, 40, [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)], gen, 0.2)
+    cases.append(("5-point with holes", ei, ev, 6000))
+    ei, ev = _stencil_matrix(90, 40, [(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)], gen, 0.2)
+    cases.append(("9-point with holes", ei, ev, 3600))
+    for name, ei, ev, n in cases:
+        for dtype, Ks in ((torch.float64, (2, 4, 8, 16)), (torch.float32, (4, 8, 16))):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            for K in Ks:
+                wide = d(torch.rand(n, 3, K, generator=gen, dtype=torch.float64).to(dtype))
+                b, x = wide[:, 1, :], wide[:, 2, :]                    # leading dimension 3 K
+                diag = d((torch.rand(n, generator=gen, dtype=torch.float64) + 3.0).to(dtype))
+                for its in (1, 2, 3, 4, 5, 7, 11):
+                    try:
+                        check(lib().gla_set_option(b"jacobi_fuse", 0))
+                        want = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                    finally:
+                        check(lib().gla_set_option(b"jacobi_fuse", 1))
+                    for lines in (0, 9, 50):
+                        try:
+                            check(lib().gla_set_option(b"jacobi_lines", lines))
+                            got = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                        finally:
+                            check(lib().gla_set_option(b"jacobi_lines", 0))
+                        assert torch.equal(got, want), (name, dtype, K, its, lines, float((got - want).abs().max()))
+    # the module surface: vertex_attr [n, 3, K]
+    ei, ev = rp.laplacianfun_torch(64)
+    va = torch.rand(4096, 3, 8, generator=gen, dtype=torch.float64)
+    va[:, 0, :] = -4.0
+    ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+    g = torch.tensor([0.7], dtype=torch.float64)
+    got = gla.JacobiGNN.JacobiGNN()(6, d(va), d(ei), d(ea), g)
+    for k in range(8):
+        want = rp.jacobi_forward(6, va[:, :, k].contiguous(), ei, ea, g)
+        assert torch.equal(got[:, 0, k].cpu(), want[:, 0]), k
