@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised stress of the temporally blocked Jacobi kernels: random grid shapes (also narrower than a strip, fewer lines
-than a block), 5- / 9-point patterns with random holes and values, fp64 / fp32, random sweep counts, block heights and
-sweeps-per-pass caps -- gla_jacobi_sweeps, the AoS entry point and gla_jacobi_fused_residual against one ordinary sweep at a
+than a block), 5- / 9-point patterns with random holes and values, fp64 / fp32, random sweep counts, block heights,
+sweeps-per-pass caps and 1 ... 16 right-hand sides -- gla_jacobi_sweeps, the AoS entry point and gla_jacobi_fused_residual against one ordinary sweep at a
 time, bit for bit.  Usage: python tools/fuzz_jacobi_march.py [cases=300] [seed=0]"""
 import os, random, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,26 +41,31 @@ for c in range(cases):
     holes = rnd.choice([0.0, 0.0, 0.1, 0.5])
     dtype = rnd.choice([torch.float64, torch.float32])
     its = rnd.randint(1, 24)
+    K = rnd.choice([1, 1, 1, 2, 4, 8, 16])
+    if dtype == torch.float32 and K == 2:
+        K = 4
     var = (rnd.choice([0, 0, 3, 9, 16, 40, 200]), rnd.choice([1, 1, 1, 0]), rnd.randint(2, 8), rnd.randint(2, 6))
     n = Nx * Ny
     ei, ev = stencil(Nx, Ny, pts, holes)
     plan = gla.CsrPlan(ei.to(dev), n)
     plan.set_values(ev.to(dtype).to(dev))
-    b = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype).to(dev)
-    x = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype).to(dev)
+    b = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dtype).to(dev)
+    x = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dtype).to(dev)
     diag = (torch.rand(n, generator=gen, dtype=torch.float64) + 3.0).to(dtype).to(dev)
     try:
         check(lib().gla_set_option(b"jacobi_fuse", 0))
         want = plan.jacobi_sweeps(diag, b, x, 0.7, its)
-        want_r = plan.residual(b, want)
+        want_r = plan.residual(b, want) if K == 1 else None
         check(lib().gla_set_option(b"jacobi_fuse", 1))
         for o, v in zip(opts, var):
             check(lib().gla_set_option(o.encode(), v))
         sched = plan.jacobi_schedule(its, dtype)
         got = plan.jacobi_sweeps(diag, b, x, 0.7, its)
-        va = torch.stack([diag, b.reshape(-1), x.reshape(-1)], 1)
-        got_aos = plan.jacobi_sweeps_aos(va, 0.7, its)
-        xr = plan.jacobi_sweeps_residual(diag, b, x, 0.7, its)
+        got_aos, xr = None, None
+        if K == 1:
+            va = torch.stack([diag, b.reshape(-1), x.reshape(-1)], 1)
+            got_aos = plan.jacobi_sweeps_aos(va, 0.7, its)
+            xr = plan.jacobi_sweeps_residual(diag, b, x, 0.7, its)
     finally:
         for o, v in zip(opts, (0, 1, 8, 5)):
             check(lib().gla_set_option(o.encode(), v))
@@ -68,7 +73,7 @@ for c in range(cases):
         (xr is None or (torch.equal(xr[0], want) and torch.equal(xr[1], want_r)))
     if not ok:
         bad += 1
-        print("MISMATCH", dict(Nx=Nx, Ny=Ny, pts=len(pts), holes=holes, dtype=str(dtype), its=its, var=var, sched=sched,
+        print("MISMATCH", dict(K=K, Nx=Nx, Ny=Ny, pts=len(pts), holes=holes, dtype=str(dtype), its=its, var=var, sched=sched,
                                dia=int(plan.info.dia), canon=int(plan.info.dia_canon5), stride=int(plan.info.dia_stride),
                                sweeps=torch.equal(got, want), aos=None if got_aos is None else torch.equal(got_aos, want),
                                res=None if xr is None else (torch.equal(xr[0], want), torch.equal(xr[1], want_r))))
