@@ -43,7 +43,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_marchk_kernel(JacK jv, const
   typedef T TV __attribute__((ext_vector_type(VW)));
   typedef KCoef<T, D> Coef;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  TV* buf = reinterpret_cast<TV*>(smem_raw);       // [TS][3][LWV]: buf[t][s] = line of x^(k+t) with line mod 3 == s
+  TV* buf = reinterpret_cast<TV*>(smem_raw);       // 9-point: [TS][3][LWV], slot = line mod 3; 5-point: [TS][2][LWV], slot = parity
   const int blk = map_tile(tm);
   if (blk < 0) return;
   constexpr int halo = TS, bp_eff = BP - 2 * halo;
@@ -101,8 +101,12 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_marchk_kernel(JacK jv, const
   for (int t = 0; t < TS; ++t) h[t][0] = h[t][1] = h[t][2] = TV(T(0));
   h[0][1] = x0_at(j_first - 1);
   h[0][2] = x0_at(j_first);
-  buf[((j_first - 1 + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][1];
-  buf[((j_first + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][2];
+  if constexpr (D == 5) {
+    buf[((j_first + 64) & 1) * LWV + (1 + ii) * KV + q] = h[0][2];
+  } else {
+    buf[((j_first - 1 + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][1];
+    buf[((j_first + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][2];
+  }
   TV xpre = x0_at(j_first + 1);
   Coef c[NC];                                      // set of line j_first + s lives in c[s % NC]
   TV cb[NC];                                       // ... and the row's b
@@ -115,39 +119,62 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_marchk_kernel(JacK jv, const
   for (int s = 0; s < NC; ++s) cfull[s] = false;
 
   auto do_step = [&](const int jl, const int u, const int nact) {
-    const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
-    // LDS rows of the lines jl + 1, jl, jl - 1 (level 0): [0] left, [KV] own, [2 KV] right of this lane's point
-    TV* const rw[3] = {buf + s1 * LWV + ii * KV + q, buf + s0 * LWV + ii * KV + q, buf + s2 * LWV + ii * KV + q};
-    h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
-    rw[0][KV] = xpre;                              // level 0, line jl + 1
-    xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
-    c[(u + 1) % NC] = coef_at(jl + 1);
-    cb[(u + 1) % NC] = b_at(jl + 1);
-    cfull[u % NC] = __all(c[u % NC].lv && ((unsigned)c[u % NC].m & FULL) == FULL) != 0;   // (at first use)
-#pragma unroll
-    for (int t = 1; t <= TS; ++t) {
+    if constexpr (D == 5) {
+      // 5-point: a level only needs the i -/+ 1 neighbours of ITS OWN line, which the level below wrote one line step
+      // earlier: two lines per level (slot = line parity) and ONE barrier per line step (as jacobi_march5 / cheby_march5)
       __syncthreads();
-      if (t <= nact) {
-        // lines line + 1, line, line - 1 of level t - 1 (line = jl - (t - 1)): the three rows rotated by t - 1
-        TV* const below = rw[(t - 1) % 3] + (t - 1) * 3 * LWV;
-        TV* const same = rw[t % 3] + (t - 1) * 3 * LWV;
-        TV* const above = rw[(t + 1) % 3] + (t - 1) * 3 * LWV;
-        const int ci = ((u - (t - 1)) % NC + NC) % NC;
-        TV xn;
-        (void)below; (void)above;
-        if constexpr (D == 5) {
-          const TV xs[5] = {h[t - 1][0], same[0], h[t - 1][1], same[2 * KV], h[t - 1][2]};
-          xn = update(c[ci], cb[ci], cfull[ci], xs, h[t - 1][1]);
-        } else {
+      const int pj = (jl + 64) & 1;
+      TV* const row_e = buf + pj * LWV + ii * KV + q;          // lines of the parity of jl: [0] left, [KV] own, [2 KV] right
+      TV* const row_o = buf + (1 - pj) * LWV + ii * KV + q;
+      h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
+      row_o[KV] = xpre;                            // level 0, line jl + 1
+      xpre = x0_at(jl + 2);                        // clamped / dead beyond the block: harmless, never used
+      c[(u + 1) % NC] = coef_at(jl + 1);
+      cb[(u + 1) % NC] = b_at(jl + 1);
+      cfull[u % NC] = __all(c[u % NC].lv && ((unsigned)c[u % NC].m & FULL) == FULL) != 0;   // (at first use)
+#pragma unroll
+      for (int t = 1; t <= TS; ++t) {
+        if (t <= nact) {
+          TV* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LWV;   // level t - 1, line jl - (t - 1)
+          const int ci = ((u - (t - 1)) % NC + NC) % NC;
+          const TV xs[5] = {h[t - 1][0], row[0], h[t - 1][1], row[2 * KV], h[t - 1][2]};
+          const TV xn = update(c[ci], cb[ci], cfull[ci], xs, h[t - 1][1]);
+          if (t < TS) {
+            h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
+            row[2 * LWV + KV] = xn;                // level t, same line (same parity)
+          } else if (c[ci].lv && owner) {
+            stv<TV>(xout + ((J0 + jl - (TS - 1)) * jv.S + gi) * ldxo + q * VW, xn);
+          }
+        }
+      }
+    } else {
+      const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
+      // LDS rows of the lines jl + 1, jl, jl - 1 (level 0): [0] left, [KV] own, [2 KV] right of this lane's point
+      TV* const rw[3] = {buf + s1 * LWV + ii * KV + q, buf + s0 * LWV + ii * KV + q, buf + s2 * LWV + ii * KV + q};
+      h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
+      rw[0][KV] = xpre;                            // level 0, line jl + 1
+      xpre = x0_at(jl + 2);                        // clamped / dead beyond the block: harmless, never used
+      c[(u + 1) % NC] = coef_at(jl + 1);
+      cb[(u + 1) % NC] = b_at(jl + 1);
+      cfull[u % NC] = __all(c[u % NC].lv && ((unsigned)c[u % NC].m & FULL) == FULL) != 0;   // (at first use)
+#pragma unroll
+      for (int t = 1; t <= TS; ++t) {
+        __syncthreads();
+        if (t <= nact) {
+          // lines line + 1, line, line - 1 of level t - 1 (line = jl - (t - 1)): the three rows rotated by t - 1
+          TV* const below = rw[(t - 1) % 3] + (t - 1) * 3 * LWV;
+          TV* const same = rw[t % 3] + (t - 1) * 3 * LWV;
+          TV* const above = rw[(t + 1) % 3] + (t - 1) * 3 * LWV;
+          const int ci = ((u - (t - 1)) % NC + NC) % NC;
           const TV xs[9] = {above[0], h[t - 1][0], above[2 * KV], same[0], h[t - 1][1], same[2 * KV],
                             below[0], h[t - 1][2], below[2 * KV]};
-          xn = update(c[ci], cb[ci], cfull[ci], xs, h[t - 1][1]);
-        }
-        if (t < TS) {
-          h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
-          same[3 * LWV + KV] = xn;                 // level t, same line (same slot)
-        } else if (c[ci].lv && owner) {
-          stv<TV>(xout + ((J0 + jl - (TS - 1)) * jv.S + gi) * ldxo + q * VW, xn);
+          const TV xn = update(c[ci], cb[ci], cfull[ci], xs, h[t - 1][1]);
+          if (t < TS) {
+            h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
+            same[3 * LWV + KV] = xn;               // level t, same line (same slot)
+          } else if (c[ci].lv && owner) {
+            stv<TV>(xout + ((J0 + jl - (TS - 1)) * jv.S + gi) * ldxo + q * VW, xn);
+          }
         }
       }
     }
@@ -179,7 +206,7 @@ int launch_marchk(gla_csr* A, const T* diag, const T* b, int64_t ldb, const T* x
   jv.n_rows = A->n_rows; jv.n_cols = A->n_cols;
   const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
   const int nstrips = (int)((A->dia_S + bp_eff - 1) / bp_eff);
-  const size_t lds = (size_t)TS * 3 * (BP + 2) * KV * 16;
+  const size_t lds = (size_t)TS * (D == 5 ? 2 : 3) * (BP + 2) * KV * 16;
   int lines = g_tuning.jacobi_lines;
   if (lines <= 0) lines = gla_pick_block_lines(nlines, nstrips, 256 * 2, 2 * (TS - 1), 2 * TS);
   if (lines < 2 * TS) lines = 2 * TS;
