@@ -459,6 +459,12 @@ def single_gpu(args, gla, dev):
         el_p, ms_p = timed_steps(lambda: pw(vp, pr.ei, pr.edge_attr, g3), 5, 2)
         Bp = 11 * (base + 16 * n * K) + 6 * 8 * n * K
         tc, tpw = median(ms_c) * 1e-3, median(ms_p) * 1e-3
+        # JacobiGNN on the same 16 right-hand sides (vertex_attr [n, 3, K]): temporally blocked passes of four sweeps
+        vj = torch.stack([torch.full_like(b16, -4.0), b16, x16], 1)
+        _, ms_j = timed_steps(lambda: jac(args.sweeps, vj, pr.ei, pr.edge_attr, pr.g), 3, 1)
+        tj = median(ms_j) * 1e-3 / args.sweeps
+        Bj16 = base + 8 * n + 24 * n * K
+        del vj
         out["config3_k16"] = {
             "what": f"BASELINE config 3 through the module surface, {Nx}^2 Laplacian, K=16 right-hand sides, fp64",
             "note": "ChebyRelaxGNN(4) runs as ONE temporally blocked pass (gla_cheby_fused: b, x in; x, r, p out), so "
@@ -467,7 +473,9 @@ def single_gpu(args, gla, dev):
             "cheby_deg4_ms": round(tc * 1e3, 3), "cheby_GBps": round(Bc / tc / 1e9, 1),
             "cheby_frac": round(Bc / tc / HBM_PEAK, 4), "cheby_algorithmic_bytes": Bc,
             "power_10its_ms": round(tpw * 1e3, 3), "power_GBps": round(Bp / tpw / 1e9, 1),
-            "power_frac": round(Bp / tpw / HBM_PEAK, 4), "power_algorithmic_bytes": Bp}
+            "power_frac": round(Bp / tpw / HBM_PEAK, 4), "power_algorithmic_bytes": Bp,
+            "jacobi_ms_per_sweep": round(tj * 1e3, 4), "jacobi_GBps": round(Bj16 / tj / 1e9, 1),
+            "jacobi_frac": round(Bj16 / tj / HBM_PEAK, 4), "jacobi_algorithmic_bytes_per_sweep": Bj16}
         del vp, b16, x16
         torch.cuda.empty_cache()
 
