@@ -49,12 +49,14 @@ def chebyshev_relax(plan, b, x0, g, deg, out=None, need_gathered=True, b_copy=No
         x, r, p_final = out
     gathered = x0
     done = 0
-    m = min(deg, FUSED_MAX)
-    if m >= 2:
-        # fused pass for steps 1 .. m.  Its p goes to the caller's buffer when it is the final p, otherwise (more steps
-        # follow) to a scratch chosen so that the ping-pong below ends in the caller's buffer.
+    scratch = None
+    for m in range(min(deg, FUSED_MAX), 1, -1):
+        # fused pass for steps 1 .. m (the most the plan's kernel takes: four, or three for K-wide 9-point passes).  Its p
+        # goes to the caller's buffer when it is the final p, otherwise (more steps follow) to a scratch chosen so that the
+        # ping-pong below ends in the caller's buffer.
         rest = deg - m
-        scratch = torch.empty((b.shape[0], b.shape[1]), dtype=b.dtype, device=b.device) if rest > 0 or need_gathered else None
+        if scratch is None and (rest > 0 or need_gathered):
+            scratch = torch.empty((b.shape[0], b.shape[1]), dtype=b.dtype, device=b.device)
         p_m = p_final if rest % 2 == 0 else scratch
         p_prev = None
         if rest == 0 and need_gathered:
@@ -66,6 +68,7 @@ def chebyshev_relax(plan, b, x0, g, deg, out=None, need_gathered=True, b_copy=No
             p = p_m
             p_next = scratch if p_m is p_final else p_final
             gathered = p_prev if rest == 0 else None
+            break
     if b_copy is not None:
         b_copy.copy_(b)
     if done == 0:

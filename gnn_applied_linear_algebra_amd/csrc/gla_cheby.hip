@@ -30,6 +30,8 @@ struct Cheb2D {
 };
 
 template <typename T>
+struct ChCoef9 { T v[12]; int m, lv, pad_[2]; };   // the 9-point pattern's row (values padded to whole 16-byte groups)
+template <typename T>
 struct ChCoef { T v[CH_DMAX]; int m, lv, pad_; };        // one row's diagonal values, mask as loaded (untouched until its first
                                                    // use, so that the load stays in flight across the line step), row exists
 
@@ -317,6 +319,157 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
   }
 }
 
+// The same pass for the canonical 9-point pattern ((a, b) in {-1, 0, 1}^2: the Q1 FEM operator): a row also needs the i -/+ 1
+// neighbours of the operand's line BELOW, which the step underneath produces in the same line step -- three lines per step in
+// LDS (slot = line mod 3), one barrier per step and line step (as jacobi_march9_kernel).
+template <typename T, int KV, int DEG, int VW = 16 / (int)sizeof(T)>
+__global__ __launch_bounds__(GLA_BLOCK) void cheby_march9_kernel(
+    Cheb2D cv, const T* __restrict__ bvec, int64_t ldb, const T* __restrict__ x0, int64_t ldx0, T* __restrict__ xout,
+    int64_t ldxo, T* __restrict__ rout, int64_t ldr, T* __restrict__ pout, int64_t ldp, T* __restrict__ pprev,
+    int64_t ldpp, T* __restrict__ bcopy, int64_t ldbc, int lines, int nstrips, int64_t nlines, TileMap tm) {
+  constexpr int BP = GLA_BLOCK / KV;               // grid points of a strip
+  constexpr int LWV = (BP + 2) * KV;               // 16-byte vectors of a line in LDS: point ii at [(1 + ii) * KV + q]
+  constexpr int NC = DEG + 1, U = NC;
+  typedef T TV __attribute__((ext_vector_type(VW)));
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  TV* buf = reinterpret_cast<TV*>(smem_raw);       // [DEG][3][LWV]: buf[t][s] = line (mod 3 == s) of the operand of step t + 1
+  const int blk = map_tile(tm);
+  if (blk < 0) return;
+  constexpr int halo = DEG, bp_eff = BP - 2 * halo;
+  const int lb = blk / nstrips, strip = blk - lb * nstrips;
+  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bp_eff - halo;
+  const int L = (int)min((int64_t)lines, nlines - J0);
+  const int tid = threadIdx.x, ii = tid / KV, q = tid % KV;
+  const T* __restrict__ val = static_cast<const T*>(cv.val);
+  const int64_t gi = P0 + ii;
+  const bool in_i = gi >= 0 && gi < cv.S;
+  const bool interior = ii >= halo && ii < BP - halo;
+
+  auto live_row = [&](int jl, int64_t& r) -> bool {
+    const int64_t gj = J0 + jl;
+    r = gj * cv.S + gi;
+    return in_i && gj >= 0 && gj < nlines && r < cv.n_rows;
+  };
+  auto x0_at = [&](int jl) -> TV {                 // clamped: values of dead rows are never used
+    int64_t flat = (J0 + jl) * cv.S + gi;
+    flat = min(max(flat, (int64_t)0), cv.n_cols - 1);
+    return ldv<TV>(x0 + flat * ldx0 + q * VW);
+  };
+  auto b_at = [&](int jl) -> TV {
+    int64_t r;
+    const bool live = live_row(jl, r);
+    return ldv<TV>(bvec + (live ? r : 0) * ldb + q * VW);
+  };
+  auto coef_at = [&](int jl) -> ChCoef9<T> {
+    int64_t r;
+    const bool live = live_row(jl, r);
+    const int64_t rc = live ? r : 0;
+    ChCoef9<T> c;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) c.v[d] = val[(int64_t)d * cv.n_rows + rc];
+    c.m = (int)cv.mask[rc];
+    c.lv = live;
+    return c;
+  };
+  auto stencil = [&](const ChCoef9<T>& c, bool full, const TV (&xs)[9]) -> TV {
+    TV acc = TV(T(0));
+    if (full) {
+#pragma unroll
+      for (int d = 0; d < 9; ++d) acc = acc + c.v[d] * xs[d];
+    } else {
+      const int m = c.lv ? c.m : 0;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        const TV nxt = acc + c.v[d] * xs[d];
+        acc = ((m >> d) & 1) ? nxt : acc;
+      }
+    }
+    return acc;
+  };
+
+  constexpr int j_first = -(DEG - 1);
+  const int j_last = L - 1 + (DEG - 1);
+  TV h[DEG][3];                                    // h[t]: the operand of step t + 1 (x for t = 0, p_t after) of this lane on
+#pragma unroll                                     // the last three lines it was produced on
+  for (int t = 0; t < DEG; ++t) h[t][0] = h[t][1] = h[t][2] = TV(T(0));
+  h[0][1] = x0_at(j_first - 1);
+  h[0][2] = x0_at(j_first);
+  buf[((j_first - 1 + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][1];
+  buf[((j_first + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][2];
+  TV xpre = x0_at(j_first + 1), bq = b_at(j_first);
+  ChCoef9<T> c[NC];                                // set of line j_first + s lives in c[s % NC]
+  bool cfull[NC];
+  c[0] = coef_at(j_first);
+#pragma unroll
+  for (int s = 1; s < NC; ++s) c[s] = c[0];
+#pragma unroll
+  for (int s = 0; s < NC; ++s) cfull[s] = false;
+  TV cr[DEG], cx[DEG];                             // r and x step t left for this lane's row one line step ago
+#pragma unroll
+  for (int t = 0; t < DEG; ++t) cr[t] = cx[t] = TV(T(0));
+
+  auto do_step = [&](const int jl, const int u) {
+    const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
+    // LDS rows of the lines jl + 1, jl, jl - 1 (operand of step 1): [0] left, [KV] own, [2 KV] right of this lane's point
+    TV* const rw[3] = {buf + s1 * LWV + ii * KV + q, buf + s0 * LWV + ii * KV + q, buf + s2 * LWV + ii * KV + q};
+    h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
+    rw[0][KV] = xpre;                              // x, line jl + 1
+    const TV bnow = bq;                            // b of line jl (loaded a step ago)
+    xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
+    bq = b_at(jl + 1);
+    c[(u + 1) % NC] = coef_at(jl + 1);
+    cfull[u % NC] = __all(c[u % NC].lv && (c[u % NC].m & 0x1ff) == 0x1ff) != 0;   // (at first use: loaded a step ago)
+    TV in_r = TV(T(0)), in_x = TV(T(0));
+#pragma unroll
+    for (int t = 1; t <= DEG; ++t) {
+      __syncthreads();
+      const int line = jl - (t - 1);
+      // lines line + 1, line, line - 1 of the operand of step t: the three rows rotated by t - 1
+      TV* const below = rw[(t - 1) % 3] + (t - 1) * 3 * LWV;
+      TV* const same = rw[t % 3] + (t - 1) * 3 * LWV;
+      TV* const above = rw[(t + 1) % 3] + (t - 1) * 3 * LWV;
+      const int ci = ((u - (t - 1)) % NC + NC) % NC;
+      const TV use_r = in_r, use_x = in_x;         // what step t - 1 left for THIS row one line step ago
+      if (t < DEG) { in_r = cr[t]; in_x = cx[t]; } // keep step t's previous results for step t + 1 before overwriting them
+      const TV xs[9] = {above[0], h[t - 1][0], above[2 * KV], same[0], h[t - 1][1], same[2 * KV],
+                        below[0], h[t - 1][2], below[2 * KV]};
+      const TV acc = stencil(c[ci], cfull[ci], xs);
+      int64_t r;
+      const bool store_ok = live_row(line, r) && interior && line >= 0 && line < L;
+      TV ri, pn, xn;
+      if (t == 1) {                                // EpiChebyFirst: r = b - A x; p = r; x = x + alpha_1 r
+        if (bcopy && store_ok) stv<TV>(bcopy + r * ldbc + q * VW, bnow);
+        ri = bnow - acc;
+        pn = ri;
+        xn = h[0][1] + (T)cv.alpha[0] * ri;
+      } else {                                     // EpiChebyNext: r -= a_old (A p); p = r + beta p; x += a_new p
+        ri = use_r - (T)cv.alpha[t - 2] * acc;
+        pn = ri + (T)cv.beta[t - 1] * h[t - 1][1];
+        xn = use_x + (T)cv.alpha[t - 1] * pn;
+      }
+      if (t < DEG) {
+        h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = pn;
+        same[3 * LWV + KV] = pn;                   // operand of step t + 1, same line (same slot)
+        cr[t] = ri;
+        cx[t] = xn;
+        if (t == DEG - 1 && pprev && store_ok) stv<TV>(pprev + r * ldpp + q * VW, pn);   // the operand the last step gathers
+      } else if (store_ok) {
+        stv<TV>(xout + r * ldxo + q * VW, xn);
+        stv<TV>(rout + r * ldr + q * VW, ri);
+        stv<TV>(pout + r * ldp + q * VW, pn);
+      }
+    }
+  };
+#pragma unroll 1
+  for (int jl0 = j_first;; jl0 += U) {
+#pragma unroll
+    for (int qq = 0; qq < U; ++qq) {
+      if (jl0 + qq > j_last) return;
+      do_step(jl0 + qq, qq);
+    }
+  }
+}
+
 // one right-hand side: the march kernel with scalar lanes (256 points per strip); canonical 5-point plans only
 template <typename T, int DEG>
 int launch_cheby_fused_k1(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout,
@@ -333,8 +486,13 @@ int launch_cheby_fused_k1(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb,
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
   set_tile_mapping(tm);
-  hipLaunchKernelGGL((cheby_march5_kernel<T, 1, DEG, 1>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds, st,
-                     cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
+  if (gla_dia_canon9(A))
+    hipLaunchKernelGGL((cheby_march9_kernel<T, 1, DEG, 1>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK),
+                       (size_t)DEG * 3 * (BP + 2) * sizeof(T), st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp,
+                       bcopy, ldbc, lines, nstrips, nlines, tm);
+  else
+    hipLaunchKernelGGL((cheby_march5_kernel<T, 1, DEG, 1>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds, st,
+                       cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
   GLA_LAUNCH_CHECK();
   return GLA_OK;
 }
@@ -349,12 +507,16 @@ int launch_cheby_fused(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, co
   const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
   const int nstrips = (int)((A->dia_S + bp_eff - 1) / bp_eff);
   const bool canon = g_tuning.jacobi_march && gla_dia_canon5(A);
-  const size_t lds = canon ? (size_t)DEG * 2 * (BP + 2) * KV * 16 : (size_t)DEG * 3 * BP * KV * 16;
+  const bool canon9 = g_tuning.jacobi_march && gla_dia_canon9(A);
+  if (A->dia_D > CH_DMAX && !canon9) return GLA_ERR_UNSUPPORTED;
+  if (canon9 && DEG > 3) return GLA_ERR_UNSUPPORTED;              // (9-point, four steps, K-wide: > 256 VGPRs; the caller fuses three)
+  const size_t lds = canon ? (size_t)DEG * 2 * (BP + 2) * KV * 16
+                           : (canon9 ? (size_t)DEG * 3 * (BP + 2) * KV * 16 : (size_t)DEG * 3 * BP * KV * 16);
   // block height: all workgroups resident at once (LDS: 12 KB per fused step and workgroup; registers: 3 waves per SIMD;
   // the march kernel: two workgroups per CU, as for the Jacobi march)
   int lines = g_tuning.jacobi_lines;
   if (lines <= 0) {
-    const int64_t per_cu = canon ? 2 : std::min<int64_t>(3, (160 * 1024) / (int64_t)lds);
+    const int64_t per_cu = (canon || canon9) ? 2 : std::min<int64_t>(3, (160 * 1024) / (int64_t)lds);
     lines = gla_pick_block_lines(nlines, nstrips, 256 * (per_cu > 0 ? per_cu : 1), 2 * (DEG - 1), 2 * DEG);
   }
   TileMap tm;
@@ -364,7 +526,11 @@ int launch_cheby_fused(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, co
   if (canon)
     hipLaunchKernelGGL((cheby_march5_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
                        st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
-  else
+  else if (canon9) {
+    if constexpr (DEG <= 3)
+      hipLaunchKernelGGL((cheby_march9_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
+                         st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
+  } else
     hipLaunchKernelGGL((cheby_fused_dia2d_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
                        st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
   GLA_LAUNCH_CHECK();
@@ -389,12 +555,12 @@ int cheby_fused_impl(gla_csr* A, int K, int deg, const T* b, int64_t ldb, const 
                      const double* beta, hipStream_t st) {
   constexpr int VW = 16 / (int)sizeof(T);
   if (K == 1) {                                     // single right-hand side (the reference's own ChebyRelaxGNN): scalar lanes
-    if (!(g_tuning.jacobi_march && gla_dia_canon5(A))) return GLA_ERR_UNSUPPORTED;
+    if (!(g_tuning.jacobi_march && (gla_dia_canon5(A) || gla_dia_canon9(A)))) return GLA_ERR_UNSUPPORTED;
     Cheb2D cv1;
     cv1.val = A->dia_val;
     cv1.mask = A->dia_mask;
     cv1.D = A->dia_D; cv1.S = A->dia_S; cv1.B = A->dia_B;
-    for (int i = 0; i < CH_DMAX; ++i) { cv1.da[i] = A->dia_a[i]; cv1.db[i] = A->dia_b[i]; }
+    for (int i = 0; i < CH_DMAX; ++i) { cv1.da[i] = A->dia_a[i]; cv1.db[i] = A->dia_b[i]; }      // (unused by the march kernels)
     cv1.n_rows = A->n_rows; cv1.n_cols = A->n_cols;
     for (int i = 0; i < CH_DEG_MAX; ++i) { cv1.alpha[i] = i < deg ? alpha[i] : 0.0; cv1.beta[i] = i < deg ? beta[i] : 0.0; }
     switch (deg) {
@@ -440,7 +606,7 @@ int gla_cheby_fused(gla_csr_t A, int dtype, int K, int deg, const void* B, int64
   if (deg < 2 || deg > CH_DEG_MAX) return GLA_ERR_UNSUPPORTED;
   // 2-D stencil plans whose entries never leave their grid line, one line either side, at most five diagonals
   if (!(g_tuning.dia && g_tuning.jacobi_fuse && A->dia_state == 1 && A->dia_val && A->dia_S > 0 && A->dia_nowrap &&
-        A->dia_A == 1 && A->dia_B >= 1 && A->dia_B <= 2 && A->dia_D <= CH_DMAX && A->dia_row_lo == 0 &&
+        A->dia_A == 1 && A->dia_B >= 1 && A->dia_B <= 2 && (A->dia_D <= CH_DMAX || gla_dia_canon9(A)) && A->dia_row_lo == 0 &&
         A->dia_row_hi == A->n_rows && A->n_rows == A->n_cols && A->n_rows * (int64_t)K >= g_tuning.jacobi_min_rows))
     return GLA_ERR_UNSUPPORTED;
   if (A->n_rows == 0) return GLA_OK;

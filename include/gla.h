@@ -220,8 +220,8 @@ int gla_cheby_steps(gla_csr_t A, int dtype, int K, int n_steps, void* P0, int64_
  * the last step gathers (the z_ij of the returned edge attributes); Bcopy (may be NULL) a copy of B (the module returns
  * [b, x, r, p] and b passes through a register anyway).  Same per-row arithmetic as gla_cheby_first +
  * gla_cheby_next: bit-identical.  2-D stencil plans with at most five diagonals, K a multiple of the 16-byte vector
- * (1, 2, 4 or 8 vectors), 16-byte aligned operands; K = 1 (the reference's own single-vector call) on canonical 5-point
- * plans; otherwise GLA_ERR_UNSUPPORTED (run the steps one by one). */
+ * (1, 2, 4 or 8 vectors), 16-byte aligned operands; the canonical 9-point plan with deg <= 3 (K-wide); K = 1 (the reference's
+ * own single-vector call) on canonical 5- / 9-point plans, deg <= 4; otherwise GLA_ERR_UNSUPPORTED (fewer steps, or one by one). */
 int gla_cheby_fused(gla_csr_t A, int dtype, int K, int deg, const void* B, int64_t ldb, const void* X0, int64_t ldx0,
                     void* Xout, int64_t ldxo, void* R, int64_t ldr, void* P, int64_t ldp, void* Pprev, int64_t ldpp,
                     void* Bcopy, int64_t ldbc, const double* alpha_host, const double* beta_host, gla_stream_t stream);

@@ -1217,7 +1217,8 @@ def test_cheby_fused_pass_bit_identical():
     step-by-step kernels gla_cheby_first + gla_cheby_next: x, r, p and the operand of the last step, bit for bit;
     K = 1, 2, 4, 8 16-byte vectors and a single right-hand side (canonical 5-point plans), fp64 and fp32, ragged grid
     sizes, a 5-point pattern with holes, a B = 2 stencil; operands with leading dimensions (columns of an AoS tensor).
-    9-point plans, and K = 1 on non-canonical patterns, are declined (False)."""
+    The canonical 9-point operator takes up to three steps K-wide and four for one right-hand side (cheby_march9_kernel);
+    K = 1 on non-canonical patterns is declined (False)."""
     default_layout_only()
     gen = torch.Generator().manual_seed(91)
     cases = [("laplacian 300 x 70", *rp.laplacianfun_torch(300, 70), 21000),
@@ -1261,11 +1262,29 @@ def test_cheby_fused_pass_bit_identical():
     plan.set_values(d(ev))
     v = [torch.zeros(3150, 1, dtype=torch.float64, device=DEV) for _ in range(5)]
     assert plan.cheby_fused(v[0], v[1], v[2], v[3], v[4], [-0.25, -0.26], [0.0, 0.1]) is False
-    ei, ev = rp.heateqnfem2dfun([41, 41], [1.0, 1.0])
-    plan = gla.CsrPlan(d(ei), 1600)
-    plan.set_values(d(ev))
-    v = [torch.zeros(1600, 2, dtype=torch.float64, device=DEV) for _ in range(5)]
-    assert plan.cheby_fused(v[0], v[1], v[2], v[3], v[4], [-0.25, -0.26], [0.0, 0.1]) is False
+    # the canonical 9-point (Q1 FEM) operator: cheby_march9_kernel, up to three steps K-wide, up to four for one right-hand side
+    ei, ev = rp.heateqnfem2dfun([71, 59], [1.0, 4.0])
+    n = 70 * 58
+    for dtype, Ks in ((torch.float64, (1, 2, 16)), (torch.float32, (1, 4, 16))):
+        plan = gla.CsrPlan(d(ei), n)
+        plan.set_values(d(ev.to(dtype)))
+        assert plan.info.dia_canon5 == 9
+        for K in Ks:
+            g2 = torch.Generator().manual_seed(100 + K)
+            b = d(torch.rand(n, K, generator=g2, dtype=torch.float64).to(dtype))
+            x0 = d(torch.rand(n, K, generator=g2, dtype=torch.float64).to(dtype))
+            for deg in (2, 3, 4):
+                alphas, betas = [0.25, 0.26, 0.27, 0.255][:deg], [0.0, 0.1, 0.12, 0.09][:deg]
+                r_w, p_a, x_w, p_b = (torch.empty(n, K, dtype=dtype, device=DEV) for _ in range(4))
+                plan.cheby_first(b, x0, r_w, p_a, x_w, alphas[0])
+                for k in range(2, deg + 1):
+                    plan.cheby_next(p_a, p_b, r_w, x_w, alphas[k - 2], alphas[k - 1], betas[k - 1])
+                    p_a, p_b = p_b, p_a
+                xo, ro, po = (torch.empty(n, K, dtype=dtype, device=DEV) for _ in range(3))
+                ok = plan.cheby_fused(b, x0, xo, ro, po, alphas, betas)
+                assert ok == (deg <= 3 or K == 1), (dtype, K, deg, ok)
+                if ok:
+                    assert torch.equal(xo, x_w) and torch.equal(ro, r_w) and torch.equal(po, p_a), (dtype, K, deg)
 
 
 def test_jacobi_fused_residual_bit_identical():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B: ChebyRelaxGNN(deg) on K right-hand sides, one kernel per step (option jacobi_fuse=0) vs the temporally blocked
-pass gla_cheby_fused (default), through the module surface.  Usage: python tools/ab_cheby_fused.py [N=4096] [K=16] [deg=4]"""
+pass gla_cheby_fused (default), through the module surface.  Usage: python tools/ab_cheby_fused.py [N=4096] [K=16] [deg=4] [fem]"""
 import os
 import sys
 
@@ -10,11 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gnn_applied_linear_algebra_amd as gla          # noqa: E402
 from gnn_applied_linear_algebra_amd._lib import lib, check   # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-deg = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+fem = "fem" in sys.argv
+argv = [a for a in sys.argv if a != "fem"]
+N = int(argv[1]) if len(argv) > 1 else 4096
+K = int(argv[2]) if len(argv) > 2 else 16
+deg = int(argv[3]) if len(argv) > 3 else 4
 dev = torch.device("cuda:0")
-ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=dev)
+ei, ev = (gla.UtilsGNN.heateqnfem2dfun([N + 1, N + 1], [1.0, 1.0], device=dev) if fem else gla.UtilsGNN.laplacianfun_torch(N, device=dev))
 n, nnz = N * N, ei.shape[1]
 gen = torch.Generator().manual_seed(24601)
 va = torch.stack([torch.rand(n, K, generator=gen, dtype=torch.float64), torch.rand(n, K, generator=gen, dtype=torch.float64)], 1).to(dev)
@@ -35,7 +37,7 @@ for rnd in range(6):
             res.setdefault(name, []).append(e0.elapsed_time(e1))
         outs[name] = out
 check(lib().gla_set_option(b"jacobi_fuse", 1))
-print(f"ChebyRelaxGNN(deg={deg}).forward, {N}^2 Laplacian, K={K}, fp64; SURVEY bytes {B_alg / 1e9:.1f} GB")
+print(f"ChebyRelaxGNN(deg={deg}).forward, {N}^2 {'FEM 9-point' if fem else 'Laplacian'}, K={K}, fp64; SURVEY bytes {B_alg / 1e9:.1f} GB")
 for name, ts in res.items():
     ts.sort()
     med = ts[len(ts) // 2]
