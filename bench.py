@@ -94,6 +94,10 @@ def child_specs(args, argv):
         env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
                "GLA_BENCH_CHILD": "1"}
+        if "OMP_NUM_THREADS" not in os.environ:
+            # as torch.distributed.run does for several ranks per node: N ranks with a full set of intra-op CPU threads each
+            # oversubscribe the host, and the setup-time host ops of the row-block drivers crawl (100 s instead of 2)
+            env["OMP_NUM_THREADS"] = str(max(1, min(8, (os.cpu_count() or 8) // (2 * args.gpus))))
         specs.append({"cmd": [sys.executable, os.path.abspath(__file__)] + list(argv), "env": env})
     return specs
 
@@ -540,6 +544,11 @@ def multi_gpu(args, gla, dev, world, rank):
     from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi
     ranks_seen = dist.get_world_size()
     on_dev = args.backend == "nccl"
+    t_start = time.time()
+
+    def log(msg):                                            # progress on stderr (rank 0): a long run is not a hung run
+        if rank == 0:
+            print(f"bench.py [{time.time() - t_start:7.1f} s] {msg}", file=sys.stderr, flush=True)
 
     def barrier():
         dist.barrier()
@@ -554,9 +563,12 @@ def multi_gpu(args, gla, dev, world, rank):
         Ny = lines * world
         n_local = Nx * lines
         pr = Problem(gla, Nx, Ny, rank * n_local, (rank + 1) * n_local, dev, 24601 + rank)
+        log(f"{Ny} x {Nx} grid, {lines} lines per rank: local problem built")
         drv = RowBlockJacobi(pr.ei, pr.edge_attr, n_global=Nx * Ny, row_lo=rank * n_local, row_hi=(rank + 1) * n_local,
                              overlap=not args.no_overlap, host_loop=args.host_loop)
+        log(f"row-block driver ready ({drv.mode})")
         elapsed, step_ms = timed_steps(lambda: drv.forward(args.sweeps, pr.vertex_attr, pr.g), steps, warmup, barrier)
+        log(f"{steps} steps timed: {1e3 * elapsed / steps:.3f} ms per step")
         return max_over_ranks(elapsed), pr, drv
 
     Nx = args.n
@@ -610,6 +622,7 @@ def multi_gpu(args, gla, dev, world, rank):
             p1 = Problem(gla, G, G, 0, G * G, dev, 24601)
             _, ms1 = timed_steps(lambda: jac(args.sweeps, p1.vertex_attr, p1.ei, p1.edge_attr, p1.g), 3, 1)
             t1 = median(ms1) * 1e-3 / args.sweeps
+            log(f"{G} x {G} on rank 0 alone: {t1 * 1e6:.1f} us per sweep")
             del p1
             torch.cuda.empty_cache()
         barrier()
@@ -661,6 +674,8 @@ def worker(args):
         if dist.get_world_size() != world:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, WORLD_SIZE says {world}")
 
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // (2 * world))))
     import gnn_applied_linear_algebra_amd as gla
     check, L = gla._lib.check, gla._lib.lib()
     if args.compress:

@@ -93,7 +93,10 @@ def _publish_rows(ei, ev, row_lo, row_hi, wanted_by_rank, group):
     mine = [w[(w >= row_lo) & (w < row_hi)] for q, w in enumerate(wanted_by_rank) if q != rank]
     pub_ids = torch.unique(torch.cat(mine)) if mine else torch.zeros(0, dtype=torch.int64)
     if pub_ids.numel():
-        m = torch.isin(ei[0], pub_ids.to(dev))
+        # (a lookup table over this rank's rows: torch.isin sorts the whole edge list, seconds at 10^8 edges)
+        flag = torch.zeros(row_hi - row_lo, dtype=torch.bool, device=dev)
+        flag[(pub_ids - row_lo).to(dev)] = True
+        m = flag[ei[0] - row_lo]
         pub = (ei[:, m].cpu(), ev.reshape(-1)[m].cpu())
     else:
         pub = (torch.zeros((2, 0), dtype=torch.int64), torch.zeros(0, dtype=ev.dtype))
@@ -104,7 +107,8 @@ def _publish_rows(ei, ev, row_lo, row_hi, wanted_by_rank, group):
     for q, (pi, pv) in enumerate(pool):
         if q == rank or pi.shape[1] == 0:
             continue
-        m = torch.isin(pi[0], want)
+        pos = torch.searchsorted(want, pi[0]).clamp_(max=max(int(want.numel()) - 1, 0))     # `want` is sorted
+        m = want[pos] == pi[0] if want.numel() else torch.zeros(pi.shape[1], dtype=torch.bool)
         got_i.append(pi[:, m])
         got_v.append(pv[m])
     if not got_i:
