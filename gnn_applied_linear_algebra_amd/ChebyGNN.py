@@ -49,26 +49,69 @@ def chebyshev_relax(plan, b, x0, g, deg, out=None, need_gathered=True, b_copy=No
         x, r, p_final = out
     gathered = x0
     done = 0
-    scratch = None
+    canon = int(plan.info.dia_canon5) in (1, 9)       # the march kernels: continuation passes exist (gla_cheby_fused_next)
+    new = lambda: torch.empty((b.shape[0], b.shape[1]), dtype=b.dtype, device=b.device)   # noqa: E731
     for m in range(min(deg, FUSED_MAX), 1, -1):
-        # fused pass for steps 1 .. m (the most the plan's kernel takes: four, or three for K-wide 9-point passes).  Its p
-        # goes to the caller's buffer when it is the final p, otherwise (more steps follow) to a scratch chosen so that the
-        # ping-pong below ends in the caller's buffer.
+        # Fused pass for steps 1 .. m (the most the plan's kernel takes: four, or three for K-wide 9-point passes), then --
+        # on canonical plans -- continuation passes of the same kind for the steps that follow and at most one single step
+        # at the end (other plans: single steps only).  The buffers are laid out up front so that the last writer of x, r
+        # and p is the caller's buffer.
         rest = deg - m
-        if scratch is None and (rest > 0 or need_gathered):
-            scratch = torch.empty((b.shape[0], b.shape[1]), dtype=b.dtype, device=b.device)
-        p_m = p_final if rest % 2 == 0 else scratch
-        p_prev = None
-        if rest == 0 and need_gathered:
-            p_prev = scratch
-        if plan.cheby_fused(b, x0, x, r, p_m, [float(a) for a in alphas[:m]], [0.0] + [float(v) for v in betas[1:m]],
-                            Pprev=p_prev, Bcopy=b_copy):
-            done = m
-            b_copy = None
-            p = p_m
-            p_next = scratch if p_m is p_final else p_final
-            gathered = p_prev if rest == 0 else None
-            break
+        sizes, single = [], rest                        # continuation pass sizes, single steps after the fused passes
+        if canon and rest >= 2:
+            n_pass = -(-rest // m)
+            base, extra = divmod(rest, n_pass)
+            if base >= 2:
+                sizes, single = [base + 1] * extra + [base] * (n_pass - extra), 0
+            else:
+                sizes, single = [2] * (rest // 2), rest % 2
+        n_cont = len(sizes)
+        # x, r: the passes alternate between the caller's buffers and temporaries, ending in the caller's
+        xr = [(x, r), (new(), new())] if n_cont else [(x, r)]
+        # p: fused pass j writes p_seq[j], alternating between p_final and a scratch; the last one writes p_final when an even
+        # number of single steps follows (they ping-pong), else the scratch
+        s1 = new() if (n_cont or single) else None
+        other = lambda t: s1 if t is p_final else p_final   # noqa: E731
+        p_seq = [p_final if single % 2 == 0 else s1]
+        for _ in range(n_cont):
+            p_seq.insert(0, other(p_seq[0]))
+        # the operand the very last step gathers (z_ij of the returned edge attributes): reported by the last fused pass when
+        # no single step follows
+        s2 = new() if (need_gathered and single == 0) else None
+        cur = xr[n_cont % 2]
+        if not plan.cheby_fused(b, x0, cur[0], cur[1], p_seq[0], [float(a) for a in alphas[:m]],
+                                [0.0] + [float(v) for v in betas[1:m]], Pprev=s2 if n_cont == 0 else None, Bcopy=b_copy):
+            continue
+        b_copy = None
+        done = m
+        for j, sz in enumerate(sizes):
+            nxt = xr[(n_cont - 1 - j) % 2]
+            ok = plan.cheby_fused_next(cur[1], cur[0], p_seq[j], nxt[0], nxt[1], p_seq[j + 1], float(alphas[done - 1]),
+                                       [float(a) for a in alphas[done:done + sz]], [float(v) for v in betas[done:done + sz]],
+                                       Pprev=s2 if j == n_cont - 1 else None)
+            if not ok:
+                # (the march kernels are switched off by option: only the first pass had a kernel.)  Finish step by step from
+                # where the iterates are, then move them into the caller's buffers
+                n_left = deg - done
+                its = range(done + 1, deg + 1)
+                pa, pb = p_seq[j], p_seq[j + 1]
+                plan.cheby_steps(pa, pb, cur[1], cur[0], [alphas[it - 2] for it in its], [alphas[it - 1] for it in its],
+                                 [betas[it - 1] for it in its])
+                p_fin, p_prev = (pa, pb) if n_left % 2 == 0 else (pb, pa)
+                gathered = p_prev.clone() if need_gathered else None
+                if cur[0] is not x:
+                    x.copy_(cur[0])
+                    r.copy_(cur[1])
+                if p_fin is not p_final:
+                    p_final.copy_(p_fin)
+                return x, r, p_final, gathered, _g_out(c, d, alphas, betas, g)
+            done += sz
+            cur = nxt
+        assert cur[0] is x and cur[1] is r
+        p = p_seq[-1]
+        p_next = other(p) if single else None
+        gathered = s2
+        break
     if b_copy is not None:
         b_copy.copy_(b)
     if done == 0:

@@ -56,6 +56,7 @@ SIGNATURES = {
     "gla_jacobi_fused": (_I, [_P, _I, _P, _P, _P, _P, _D, _I, _I, _P]),
     "gla_jacobi_fused_parts": (_I, [_P, _I, _P, _P, _P, _P, _D, _I, _I, _I, _P]),
     "gla_power_rayleigh": (_I, [_P, _I, _I, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "gla_cheby_fused_next": (_I, [_P, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _D, _P, _P, _P]),
     "gla_cheby_steps": (_I, [_P, _I, _I, _I, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P]),
     "gla_copy_batch": (_I, [_I, _I, _P, _P, _P, _P, _P]),
     "gla_jacobi_fused_residual": (_I, [_P, _I, _P, _P, _P, _P, _P, _D, _I, _P]),

@@ -27,6 +27,11 @@ struct Cheb2D {
   int32_t da[CH_DMAX], db[CH_DMAX];
   int64_t n_rows, n_cols;
   double alpha[CH_DEG_MAX], beta[CH_DEG_MAX];      // alpha[k - 1] = alpha_k, beta[k - 1] = beta_k (beta_1 unused)
+  // continuation pass (march kernels only): the pass starts from (r, x, p) of an earlier step instead of (b, x0) -- its
+  // first step is an EpiChebyNext step too: `bvec` holds r, `x0` the operand p, `bcopy` (an INPUT then) x, alpha_prev the
+  // alpha of the step before, alpha[0] / beta[0] those of the pass's first step
+  int32_t cont;
+  double alpha_prev;
 };
 
 template <typename T>
@@ -250,7 +255,14 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
   h[0][1] = x0_at(j_first - 1);
   h[0][2] = x0_at(j_first);
   buf[((j_first + 64) & 1) * LWV + (1 + ii) * KV + q] = h[0][2];
+  auto xin_at = [&](int jl) -> TV {                // continuation pass: x of the row (line J0 + jl), an input
+    int64_t r;
+    const bool live = live_row(jl, r);
+    return ldv<TV>(bcopy + (live ? r : 0) * ldbc + q * VW);
+  };
   TV xpre = x0_at(j_first + 1), bq = b_at(j_first);
+  TV xinq = TV(T(0));
+  if (cv.cont) xinq = xin_at(j_first);
   ChCoef<T> c[NC];                                 // set of line j_first + s lives in c[s % NC]
   bool cfull[NC];
   c[0] = coef_at(j_first);
@@ -270,6 +282,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
     h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
     row_o[KV] = xpre;                              // x, line jl + 1
     const TV bnow = bq;                            // b of line jl (loaded a step ago)
+    const TV xinnow = xinq;
+    if (cv.cont) xinq = xin_at(jl + 1);
     xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
     bq = b_at(jl + 1);
     c[(u + 1) % NC] = coef_at(jl + 1);
@@ -287,10 +301,16 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
       const bool store_ok = live_row(line, r) && interior && line >= 0 && line < L;
       TV ri, pn, xn;
       if (t == 1) {                                // EpiChebyFirst: r = b - A x; p = r; x = x + alpha_1 r
-        if (bcopy && store_ok) stv<TV>(bcopy + r * ldbc + q * VW, bnow);
-        ri = bnow - acc;
-        pn = ri;
-        xn = h[0][1] + (T)cv.alpha[0] * ri;
+        if (!cv.cont) {
+          if (bcopy && store_ok) stv<TV>(bcopy + r * ldbc + q * VW, bnow);
+          ri = bnow - acc;
+          pn = ri;
+          xn = h[0][1] + (T)cv.alpha[0] * ri;
+        } else {                                   // continuation: the pass's first step is a "next" step on loaded r, x
+          ri = bnow - (T)cv.alpha_prev * acc;
+          pn = ri + (T)cv.beta[0] * h[0][1];
+          xn = xinnow + (T)cv.alpha[0] * pn;
+        }
       } else {                                     // EpiChebyNext: r -= a_old (A p); p = r + beta p; x += a_new p
         ri = use_r - (T)cv.alpha[t - 2] * acc;
         pn = ri + (T)cv.beta[t - 1] * h[t - 1][1];
@@ -396,7 +416,14 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march9_kernel(
   h[0][2] = x0_at(j_first);
   buf[((j_first - 1 + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][1];
   buf[((j_first + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][2];
+  auto xin_at = [&](int jl) -> TV {                // continuation pass: x of the row (line J0 + jl), an input
+    int64_t r;
+    const bool live = live_row(jl, r);
+    return ldv<TV>(bcopy + (live ? r : 0) * ldbc + q * VW);
+  };
   TV xpre = x0_at(j_first + 1), bq = b_at(j_first);
+  TV xinq = TV(T(0));
+  if (cv.cont) xinq = xin_at(j_first);
   ChCoef9<T> c[NC];                                // set of line j_first + s lives in c[s % NC]
   bool cfull[NC];
   c[0] = coef_at(j_first);
@@ -415,6 +442,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march9_kernel(
     h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
     rw[0][KV] = xpre;                              // x, line jl + 1
     const TV bnow = bq;                            // b of line jl (loaded a step ago)
+    const TV xinnow = xinq;
+    if (cv.cont) xinq = xin_at(jl + 1);
     xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
     bq = b_at(jl + 1);
     c[(u + 1) % NC] = coef_at(jl + 1);
@@ -438,10 +467,16 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march9_kernel(
       const bool store_ok = live_row(line, r) && interior && line >= 0 && line < L;
       TV ri, pn, xn;
       if (t == 1) {                                // EpiChebyFirst: r = b - A x; p = r; x = x + alpha_1 r
-        if (bcopy && store_ok) stv<TV>(bcopy + r * ldbc + q * VW, bnow);
-        ri = bnow - acc;
-        pn = ri;
-        xn = h[0][1] + (T)cv.alpha[0] * ri;
+        if (!cv.cont) {
+          if (bcopy && store_ok) stv<TV>(bcopy + r * ldbc + q * VW, bnow);
+          ri = bnow - acc;
+          pn = ri;
+          xn = h[0][1] + (T)cv.alpha[0] * ri;
+        } else {                                   // continuation: the pass's first step is a "next" step on loaded r, x
+          ri = bnow - (T)cv.alpha_prev * acc;
+          pn = ri + (T)cv.beta[0] * h[0][1];
+          xn = xinnow + (T)cv.alpha[0] * pn;
+        }
       } else {                                     // EpiChebyNext: r -= a_old (A p); p = r + beta p; x += a_new p
         ri = use_r - (T)cv.alpha[t - 2] * acc;
         pn = ri + (T)cv.beta[t - 1] * h[t - 1][1];
@@ -552,7 +587,8 @@ int dispatch_deg(int deg, gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb,
 template <typename T>
 int cheby_fused_impl(gla_csr* A, int K, int deg, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout, int64_t ldxo,
                      T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc, const double* alpha,
-                     const double* beta, hipStream_t st) {
+                     const double* beta, hipStream_t st, int cont = 0, double alpha_prev = 0.0) {
+  if (cont && !(g_tuning.jacobi_march && (gla_dia_canon5(A) || gla_dia_canon9(A)))) return GLA_ERR_UNSUPPORTED;
   constexpr int VW = 16 / (int)sizeof(T);
   if (K == 1) {                                     // single right-hand side (the reference's own ChebyRelaxGNN): scalar lanes
     if (!(g_tuning.jacobi_march && (gla_dia_canon5(A) || gla_dia_canon9(A)))) return GLA_ERR_UNSUPPORTED;
@@ -563,6 +599,7 @@ int cheby_fused_impl(gla_csr* A, int K, int deg, const T* b, int64_t ldb, const 
     for (int i = 0; i < CH_DMAX; ++i) { cv1.da[i] = A->dia_a[i]; cv1.db[i] = A->dia_b[i]; }      // (unused by the march kernels)
     cv1.n_rows = A->n_rows; cv1.n_cols = A->n_cols;
     for (int i = 0; i < CH_DEG_MAX; ++i) { cv1.alpha[i] = i < deg ? alpha[i] : 0.0; cv1.beta[i] = i < deg ? beta[i] : 0.0; }
+    cv1.cont = cont; cv1.alpha_prev = alpha_prev;
     switch (deg) {
       case 2: return launch_cheby_fused_k1<T, 2>(A, cv1, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
       case 3: return launch_cheby_fused_k1<T, 3>(A, cv1, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
@@ -583,6 +620,7 @@ int cheby_fused_impl(gla_csr* A, int K, int deg, const T* b, int64_t ldb, const 
   for (int i = 0; i < CH_DMAX; ++i) { cv.da[i] = i < A->dia_D ? A->dia_a[i] : 0; cv.db[i] = i < A->dia_D ? A->dia_b[i] : 0; }
   cv.n_rows = A->n_rows; cv.n_cols = A->n_cols;
   for (int i = 0; i < CH_DEG_MAX; ++i) { cv.alpha[i] = i < deg ? alpha[i] : 0.0; cv.beta[i] = i < deg ? beta[i] : 0.0; }
+  cv.cont = cont; cv.alpha_prev = alpha_prev;
   switch (kv) {
     case 1: return dispatch_deg<T, 1>(deg, A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
     case 2: return dispatch_deg<T, 2>(deg, A, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, st);
@@ -617,6 +655,30 @@ int gla_cheby_fused(gla_csr_t A, int dtype, int K, int deg, const void* B, int64
   return cheby_fused_impl<float>(A, K, deg, (const float*)B, ldb, (const float*)X0, ldx0, (float*)Xout, ldxo, (float*)R,
                                  ldr, (float*)P, ldp, (float*)Pprev, ldpp, (float*)Bcopy, ldbc, alpha_host, beta_host,
                                  (hipStream_t)stream);
+}
+
+int gla_cheby_fused_next(gla_csr_t A, int dtype, int K, int deg, const void* Rin, int64_t ldri, const void* Xin, int64_t ldxi,
+                         const void* Pin, int64_t ldpi, void* Xout, int64_t ldxo, void* R, int64_t ldr, void* P, int64_t ldp,
+                         void* Pprev, int64_t ldpp, double alpha_prev, const double* alpha_host, const double* beta_host,
+                         gla_stream_t stream) {
+  int rc = check_plan(A, dtype, K);
+  if (rc) return rc;
+  if (!Rin || !Xin || !Pin || !Xout || !R || !P || Xin == Xout || Rin == R || Pin == P || !alpha_host || !beta_host ||
+      ldri < K || ldxi < K || ldpi < K || ldxo < K || ldr < K || ldp < K || (Pprev && ldpp < K))
+    return GLA_ERR_INVALID_ARG;
+  if (deg < 2 || deg > CH_DEG_MAX) return GLA_ERR_UNSUPPORTED;
+  if (!(g_tuning.dia && g_tuning.jacobi_fuse && A->dia_state == 1 && A->dia_val && A->dia_S > 0 && A->dia_nowrap &&
+        A->dia_row_lo == 0 && A->dia_row_hi == A->n_rows && A->n_rows == A->n_cols &&
+        A->n_rows * (int64_t)K >= g_tuning.jacobi_min_rows))
+    return GLA_ERR_UNSUPPORTED;
+  if (A->n_rows == 0) return GLA_OK;
+  if (dtype == GLA_F64)
+    return cheby_fused_impl<double>(A, K, deg, (const double*)Rin, ldri, (const double*)Pin, ldpi, (double*)Xout, ldxo,
+                                    (double*)R, ldr, (double*)P, ldp, (double*)Pprev, ldpp, (double*)const_cast<void*>(Xin), ldxi,
+                                    alpha_host, beta_host, (hipStream_t)stream, 1, alpha_prev);
+  return cheby_fused_impl<float>(A, K, deg, (const float*)Rin, ldri, (const float*)Pin, ldpi, (float*)Xout, ldxo, (float*)R, ldr,
+                                 (float*)P, ldp, (float*)Pprev, ldpp, (float*)const_cast<void*>(Xin), ldxi, alpha_host, beta_host,
+                                 (hipStream_t)stream, 1, alpha_prev);
 }
 
 }  // extern "C"

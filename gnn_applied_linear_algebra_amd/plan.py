@@ -349,6 +349,34 @@ class CsrPlan:
         return True
 
     @_on_device
+    def cheby_fused_next(self, Rin, Xin, Pin, Xout, R, P, alpha_prev, alphas, betas, Pprev=None):
+        """Steps k + 1 .. k + len(alphas) of the Chebyshev relaxation in ONE pass, from (r, x, p) after step k
+        (gla_cheby_fused_next; out of place).  False when the plan / operands do not qualify."""
+        Pin, K, ldpi = _dense(Pin, self.n_cols, "Pin")
+        Rin, _, ldri = _dense(Rin, self.n_rows, "Rin")
+        Xin, _, ldxi = _dense(Xin, self.n_rows, "Xin")
+        Xout, _, ldxo = _dense(Xout, self.n_rows, "Xout")
+        R, _, ldr = _dense(R, self.n_rows, "R")
+        P, _, ldp = _dense(P, self.n_rows, "P")
+        self._need(Pin.dtype)
+        assert Rin.shape[1] == Xin.shape[1] == Xout.shape[1] == R.shape[1] == P.shape[1] == K
+        assert len({t.dtype for t in (Rin, Xin, Pin, Xout, R, P)}) == 1
+        assert Xin.data_ptr() != Xout.data_ptr() and Rin.data_ptr() != R.data_ptr() and Pin.data_ptr() != P.data_ptr()
+        ldpp = 0
+        if Pprev is not None:
+            Pprev, _, ldpp = _dense(Pprev, self.n_rows, "Pprev")
+        deg = len(alphas)
+        a = (ctypes.c_double * deg)(*[float(v) for v in alphas])
+        bt = (ctypes.c_double * deg)(*[float(v) for v in betas])
+        rc = lib().gla_cheby_fused_next(self._h, dtype_code(Pin.dtype), K, deg, ptr(Rin), ldri, ptr(Xin), ldxi, ptr(Pin), ldpi,
+                                        ptr(Xout), ldxo, ptr(R), ldr, ptr(P), ldp, ptr(Pprev), ldpp, float(alpha_prev), a, bt,
+                                        stream_ptr(self.device))
+        if rc == -5:
+            return False
+        check(rc)
+        return True
+
+    @_on_device
     def power_step(self, X, nrm=None, out=None, which=ALL_TILES, work=None, sumsq=None):
         """Fused power-method step: Y = A (X ./ nrm), sumsq[k] = sum_i Y[i,k]^2 (PowerMethodGNN.py:86-207).
         Returns (Y, sumsq, work); raises GlaError(-5) when the plan / K has no fused kernel."""

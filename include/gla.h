@@ -225,6 +225,14 @@ int gla_cheby_steps(gla_csr_t A, int dtype, int K, int n_steps, void* P0, int64_
 int gla_cheby_fused(gla_csr_t A, int dtype, int K, int deg, const void* B, int64_t ldb, const void* X0, int64_t ldx0,
                     void* Xout, int64_t ldxo, void* R, int64_t ldr, void* P, int64_t ldp, void* Pprev, int64_t ldpp,
                     void* Bcopy, int64_t ldbc, const double* alpha_host, const double* beta_host, gla_stream_t stream);
+/* The continuation of gla_cheby_fused: steps k + 1 .. k + deg (2 <= deg <= 4; three K-wide on 9-point plans) in ONE pass,
+ * started from (Rin, Xin, Pin) = r, x, p after step k.  alpha_prev = alpha_k; alpha_host[i], beta_host[i] = alpha, beta of
+ * step k + 1 + i.  Out of place (Xout, R, P differ from the inputs: the workgroups' strips overlap); Pprev as in
+ * gla_cheby_fused.  Canonical 5- / 9-point plans only (the march kernels); GLA_ERR_UNSUPPORTED otherwise. */
+int gla_cheby_fused_next(gla_csr_t A, int dtype, int K, int deg, const void* Rin, int64_t ldri, const void* Xin, int64_t ldxi,
+                         const void* Pin, int64_t ldpi, void* Xout, int64_t ldxo, void* R, int64_t ldr, void* P, int64_t ldp,
+                         void* Pprev, int64_t ldpp, double alpha_prev, const double* alpha_host, const double* beta_host,
+                         gla_stream_t stream);
 
 /* Column sums of X .* Y over `n` rows -> out[K] (device, same dtype).  PowerMethodGNN.py:50-61
  * (torch.sum(vertex_attr[:,1]) with y = b*b :124 or y = b*cbar :233).  `work` needs gla_dot_work_bytes(n,K). */
