@@ -2089,12 +2089,11 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
   JacobiPlan plan;
   jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && diag && B && X0, n_iters, plan);
   // K right-hand sides on canonical 5- / 9-point plans: passes of up to GLA_JACOBIK_TS_MAX sweeps (jacobi_marchk_kernel,
-  // gla_jacobik.hip), ceil(n / 4) passes of equal size +- 1; anything it declines keeps one sweep per launch
+  // gla_jacobik.hip), ceil(n / 4) (9-point: n / 3) passes of equal size +- 1; anything it declines keeps one sweep per launch
   if (K > 1 && n_iters >= 2 && g_tuning.jacobi_fuse == 1 && diag && B && X0 && A->val_dtype == dtype &&
       A->n_rows * (int64_t)K >= g_tuning.jacobi_min_rows && (gla_dia_canon5(A) || gla_dia_canon9(A))) {
-    const int k = (n_iters + GLA_JACOBIK_TS_MAX - 1) / GLA_JACOBIK_TS_MAX, base = n_iters / k, r = n_iters % k;
-    const int n_single = base < 2 ? k - r : 0;             // (base = 1 only for n_iters = ... never with n_iters >= 2 and k = ceil(n / 4))
-    (void)n_single;
+    const int tmax = gla_dia_canon5(A) ? GLA_JACOBIK_TS_MAX : GLA_JACOBIK_TS_MAX - 1;      // (9-point: three sweeps per pass)
+    const int k = (n_iters + tmax - 1) / tmax, base = n_iters / k, r = n_iters % k;       // base >= 2 for n_iters >= 2
     const void* src = X0;
     int64_t lsrc = ldx0;
     int rc = GLA_OK;
