@@ -1886,3 +1886,33 @@ def test_jacobi_multi_rhs_temporal_blocking_bit_identical():
     for k in range(8):
         want = rp.jacobi_forward(6, va[:, :, k].contiguous(), ei, ea, g)
         assert torch.equal(got[:, 0, k].cpu(), want[:, 0]), k
+
+
+def test_bench_line_contract():
+    """`python bench.py` (short: 2 steps, no side records, no CPU baseline, a 1024^2 grid) prints exactly ONE line on stdout
+    and it is the contract's JSON object: metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+    scaling / vs_baseline / dtype / data / config.workload and a roofline object with bound, achieved, peak, unit, frac,
+    traffic -- on the temporally blocked schedule."""
+    import json
+    import os
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GLA_OPTIONS", None)
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-side",
+                        "--no-cpu-baseline", "--grid", "1024"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d_ = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d_, key
+    assert d_["n_gpus"] == 1 and d_["steps"] == 2 and d_["warmup"] == 1 and d_["unit"] == "sweeps/s" and d_["dtype"] == "f64"
+    assert d_["vs_baseline"] is None and d_["higher_is_better"] is True and "workload" in d_["config"]
+    roof = d_["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["schedule"] == [7, 7, 6] and roof["kernel"].startswith("jacobi_march5_kernel")
+    assert d_["value"] > 0 and abs(d_["value"] - 20 * 2 / (d_["ms_per_step"] * 2e-3)) / d_["value"] < 1e-3
