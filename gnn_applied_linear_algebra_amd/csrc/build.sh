@@ -8,7 +8,8 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-result"
 OUT=../libgla_hip.so
 pids=()
-for f in gla_rows gla_edges gla_plan gla_sparse gla_mlp gla_dist gla_cheby gla_jacobik; do
+SRCS="gla_rows gla_march5 gla_edges gla_plan gla_sparse gla_mlp gla_dist gla_cheby gla_jacobik"
+for f in $SRCS; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gla_internal.h -nt $f.o ] || [ gla_device.h -nt $f.o ] || [ ../../include/gla.h -nt $f.o ]; then
     rm -f $f.o                                   # a failed compile must not leave a stale object behind
     $HIPCC $FLAGS -c $f.hip -o $f.o &
@@ -16,5 +17,6 @@ for f in gla_rows gla_edges gla_plan gla_sparse gla_mlp gla_dist gla_cheby gla_j
   fi
 done
 for p in "${pids[@]}"; do wait $p; done          # (set -e: a failed translation unit stops the build)
-$HIPCC --offload-arch=gfx950 -shared -fPIC gla_rows.o gla_edges.o gla_plan.o gla_sparse.o gla_mlp.o gla_dist.o gla_cheby.o gla_jacobik.o -ldl -o $OUT
+OBJS=""; for f in $SRCS; do OBJS="$OBJS $f.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $OUT
 echo "built $(realpath $OUT)"

@@ -117,6 +117,23 @@ inline bool gla_dia_canon5(const gla_csr* A) {
   return true;
 }
 
+// march5.hip: `ts` Jacobi sweeps (res: + the residual of the result) of a canonical 5-point plan in one temporally blocked pass
+struct gla_march5_args {
+  gla_csr* A;
+  int dtype, ts;
+  bool res;                    // one more level forms r = b - A x^(k+ts) -> b_out
+  const void *diag, *b, *x;    // ldva > 0: x is the AoS vertex attribute tensor [A_ii, b, x] (diag, b unused)
+  void* xo;
+  double w;
+  hipStream_t st;
+  int part;                    // 0 all line blocks, 1 interior, 2 first + last (multi-GPU split)
+  int64_t ldva;
+  void *diag_out, *b_out;      // AoS pass: contiguous copies of A_ii and b; res: the residual
+  int ghost;                   // ghost lines either end (parts 1 / 2)
+  int64_t aos_off, aos_rows;
+};
+int gla_march5_pass(const gla_march5_args& a);
+
 // jacobik.hip: `sweeps` (2 .. GLA_JACOBIK_TS_MAX) Jacobi sweeps of K right-hand sides in one temporally blocked pass
 constexpr int GLA_JACOBIK_TS_MAX = 4;
 int gla_jacobik_pass(gla_csr* A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X, int64_t ldx,

@@ -1,0 +1,437 @@
+// libgla_hip.so -- the temporally blocked Jacobi pass for canonical 5-point plans (gfx950 / MI355X): the headline kernel.
+//
+// JacobiGNN.forward (JacobiGNN.py:138-148) returns only the last iterate, so TS sweeps are taken in ONE pass over the matrix:
+// a workgroup's 256 lanes cover a strip of 256 grid points and march down the grid lines; every line step loads one line of
+// x and of the rows' coefficients (coalesced 2 KiB segments, one step ahead of their use) and advances every level
+// t = 1 .. TS by one line (level t works on line jl - (t - 1)), the last level going to HBM.  The j -/+ 1 neighbours and the
+// centre are the lane's OWN values of the last three line steps (registers h[t][0..2]); LDS carries the i -/+ 1 neighbours
+// (one padded line per level and line parity; a level reads what the level below wrote a step EARLIER: one barrier per line
+// step); the line loop is unrolled over the TS + 1 coefficient sets so that sets and LDS slots have static names.
+//
+// Round 3 (tools/micro/march5_exp.hip holds the experiments, profiles/r03/ the numbers):
+//   * Strips are aligned with the grid: the first strip starts AT the first point of a line and the last one ends AT the last
+//     point, so no lane lies outside the grid (S >= 256).  A row whose diagonal mask is exactly "every neighbour that exists"
+//     takes the unmasked sum: its missing neighbours are read as +0 (LDS pads, lines beyond the grid), their coefficients are
+//     stored zeros, and acc + (0 x 0) == acc bit for bit (acc starts at +0; a sum is -0 only if both operands are).  Before,
+//     the wave holding a line's first / last point ran the masked sum: the edge strips were 25 % slower than the others and
+//     set the kernel time.
+//   * The division by A_ii (JacobiGNN.py:119) goes through RN(1 / A_ii) -- one IEEE division per row and PASS -- and one
+//     Markstein correction per level: q0 = RN(num * rc), rem = num - q0 * d (exact in an FMA), q = RN(q0 + rem * rc) = RN(num / d)
+//     whenever d's significand is not all ones and nothing leaves the normal range.  That condition is checked OFF the
+//     dependent chain (divisor in [2^-500, 2^500] when the set is first used, numerator in (2^-450, 2^450) per level); a line
+//     step in which any lane fails is redone with the generic levels (masked in-order sum, IEEE division) before the barrier --
+//     levels only assign h[t][2], their LDS line and their output row, so a step is idempotent.  An IEEE fp64 division costs
+//     ~25 ns of SIMD time per wave (tools/micro/f64lat.hip), 7 of them per line step were a third of the VALU time.
+//   * The SIMD arbiter serves the OLDER wave first: of the two workgroups a CU holds, the one dispatched second progressed
+//     ~15 % slower and set the kernel time.  The two halves of an XCD's workgroups now alternate s_setprio every line step in
+//     antiphase.
+//   * The i -/+ 1 neighbours of level t + 2 are read from LDS before level t computes.
+// Per row the arithmetic is that of spmv_dia_kernel + EpiJacobi (in-order masked sum over the diagonals, then
+// x + (w * (b - sum)) / A_ii, product and sum rounded separately): bit-identical to TS single sweeps.
+//
+// MODE 1 (first pass of gla_jacobi_sweeps_aos): A_ii, b and x^(k) are columns 0, 1, 2 of the reference's row-major vertex
+// attribute tensor (JacobiGNN.py:104-106); the lane that owns a row leaves contiguous copies of its A_ii and b in diag_out /
+// b_out for the later passes.  MODE 2 (gla_jacobi_fused_residual): one more level forms r = b - A x^(k+TS) (-> b_out).
+#include "gla_device.h"
+
+#include <utility>
+
+namespace {
+
+template <int N> using IC = std::integral_constant<int, N>;
+template <int N> __device__ __forceinline__ constexpr int ic_val(IC<N>) { return N; }
+__device__ __forceinline__ constexpr int ic_val(int v) { return v; }
+
+struct M5View {
+  const void* val;            // [5][n_rows] diagonal-major: (-1,0) (0,-1) (0,0) (0,1) (1,0)
+  const uint16_t* mask;       // [n_rows]
+  int64_t S, n_rows, nlines;  // grid line length, rows (= columns), grid lines (the last one may be ragged)
+  int32_t edge, nlb;          // multi-GPU interior / boundary split: height of the first / last line block (0: uniform), line blocks
+  int64_t aos_off, aos_rows;  // MODE 1: plan row r is row r - aos_off of an AoS tensor of aos_rows rows
+};
+
+// line block lb: lines [J0, J0 + L) of the grid
+__device__ __forceinline__ void m5_block(int lb, int lines, int edge, int nlb, int64_t nlines, int64_t& J0, int& L) {
+  if (edge == 0) { J0 = (int64_t)lb * lines; L = (int)min((int64_t)lines, nlines - J0); }
+  else if (lb == 0) { J0 = 0; L = edge; }
+  else if (lb == nlb - 1) { J0 = nlines - edge; L = edge; }
+  else { J0 = edge + (int64_t)(lb - 1) * lines; L = (int)min((int64_t)lines, nlines - edge - J0); }
+}
+
+template <typename T> struct M5Lim;
+template <> struct M5Lim<double> {
+  static constexpr double dlo = 0x1p-500, dhi = 0x1p500, nlo = 0x1p-450, nhi = 0x1p450;
+  static __device__ __forceinline__ bool all_ones(double v) {
+    return (__builtin_bit_cast(unsigned long long, v) & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+  }
+};
+template <> struct M5Lim<float> {
+  static constexpr float dlo = 0x1p-60f, dhi = 0x1p60f, nlo = 0x1p-50f, nhi = 0x1p50f;
+  static __device__ __forceinline__ bool all_ones(float v) { return (__builtin_bit_cast(unsigned, v) & 0x7FFFFFu) == 0x7FFFFFu; }
+};
+
+template <typename T>
+struct M5Coef {               // one row's matrix data
+  T v[5], b, dg;
+  int m;                      // diagonal mask exactly as loaded; read once, at the set's first use (a line step after the load:
+};                            // no arithmetic on it earlier, the load must stay in flight)
+
+constexpr int M5_PLAIN = 0, M5_AOS = 1, M5_RES = 2;
+
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX>
+__global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, const T* __restrict__ diag,
+                                                                     const T* __restrict__ bvec, const T* __restrict__ x,
+                                                                     T* __restrict__ xo, T w, int lines, int nstrips, TileMap tm,
+                                                                     int tile_base0, int tile_split, int tile_base1, int64_t ldva,
+                                                                     T* __restrict__ diag_out, T* __restrict__ b_out) {
+  constexpr bool AOS = MODE == M5_AOS, RES = MODE == M5_RES;
+  constexpr int BW = GLA_BLOCK, LW = BW + 2;      // a line in LDS: lane tid at [1 + tid], one pad either side (stays +0)
+  constexpr int LV = TS + (RES ? 1 : 0);          // levels: TS sweeps; RES: + one level that forms r = b - A x^(k+TS)
+  constexpr int NC = LV + 1, U = NC;              // coefficient sets in flight (lines jl + 1 .. jl - LV + 1); unroll: static set index
+  typedef M5Lim<T> Lim;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* buf = reinterpret_cast<T*>(smem_raw);        // [LV][2][LW]: buf[t][p] = the latest line of parity p of x^(k+t)
+  const int slot = map_tile(tm);
+  if (slot < 0) return;
+  const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
+  // the arbiter favours the older wave: the two halves of an XCD's workgroups alternate priority in antiphase (see header)
+  const int late = ((blockIdx.x / GLA_XCDS) >> 5) & 1;
+  constexpr int halo = LV, bi_eff = BW - 2 * halo;
+  const int lb = blk / nstrips, strip = blk - lb * nstrips;
+  // strip s: interior strips own the middle bi_eff points; the first starts at point 0, the last ends at point S - 1
+  const int64_t P0 = max((int64_t)0, min((int64_t)strip * bi_eff, dv.S - BW));
+  const int64_t own_lo = strip == 0 ? 0 : (int64_t)strip * bi_eff + halo;
+  const int64_t own_hi = strip == nstrips - 1 ? dv.S : (int64_t)strip * bi_eff + BW - halo;
+  int64_t J0;
+  int L;
+  m5_block(lb, lines, dv.edge, dv.nlb, dv.nlines, J0, L);
+  const int tid = threadIdx.x;
+  const T* __restrict__ val = static_cast<const T*>(dv.val);
+  const int64_t gi = P0 + tid;
+  const bool in_i = gi < dv.S;                     // (false only on grids narrower than a strip)
+  const bool owner = gi >= own_lo && gi < own_hi;
+  const int em_i = 31 & ~(gi == 0 ? 2 : 0) & ~(gi == dv.S - 1 ? 8 : 0);
+  const int64_t nfull = dv.n_rows / dv.S;          // whole grid lines
+  const bool in_tail = gi < dv.n_rows - nfull * dv.S;          // this lane's point exists on the ragged last line
+  // block-relative lines [jlo, jhi) are whole grid lines
+  const int jlo = (int)max((int64_t)-64, -J0), jhi = (int)min((int64_t)L + 64, nfull - J0);
+  const bool wave_in = __all(in_i) != 0;
+
+  for (int i = tid; i < LV * 2 * LW; i += BW) buf[i] = T(0);   // (the pads stay +0: what lies beyond a line's ends)
+  __syncthreads();
+
+  auto row_clamped = [&](int jl) -> int64_t { return min(max((J0 + jl) * dv.S + gi, (int64_t)0), dv.n_rows - 1); };
+  auto live_at = [&](int jl) -> bool {             // the row (line J0 + jl, this lane's point) exists (generic path, level 0)
+    return in_i && J0 + jl >= 0 && (J0 + jl) * dv.S + gi < dv.n_rows;
+  };
+  auto x0_load = [&](int jl) -> T {                // x^(k) at the clamped row; NOT touched until the next step
+    const int64_t rc = row_clamped(jl);
+    if constexpr (AOS) return x[min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1) * ldva + 2];
+    else return x[rc];
+  };
+  auto coef_at = [&](int jl) -> M5Coef<T> {
+    const int64_t rc = row_clamped(jl);
+    M5Coef<T> c;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
+    if constexpr (AOS) {
+      const int64_t ra = min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1);
+      c.dg = x[ra * ldva];
+      c.b = x[ra * ldva + 1];
+    } else { c.b = bvec[rc]; c.dg = diag[rc]; }
+    c.m = (int)dv.mask[rc];
+    return c;
+  };
+
+  constexpr int j_first = -(LV - 1);
+  const int j_last = L - 1 + (LV - 1);
+  T h[LV][3];                                      // h[t]: x^(k+t) of this lane on the last three lines level t produced
+#pragma unroll
+  for (int t = 0; t < LV; ++t) h[t][0] = h[t][1] = h[t][2] = T(0);
+  {
+    const T a = x0_load(j_first - 1), b0 = x0_load(j_first);
+    h[0][1] = live_at(j_first - 1) ? a : T(0);
+    h[0][2] = live_at(j_first) ? b0 : T(0);
+  }
+  buf[((j_first + 64) & 1) * LW + 1 + tid] = h[0][2];
+  T xpre = x0_load(j_first + 1);
+  M5Coef<T> c[NC];                                 // set of line j_first + s lives in c[s % NC]
+  T crc[NC];                                       // RN(1 / A_ii) of the set's rows (1 where the fast division is off anyway)
+  bool cfast[NC];                                  // wave-uniform: a whole grid line, every row with the expected mask and a safe divisor
+  c[0] = coef_at(j_first);
+#pragma unroll
+  for (int s = 1; s < NC; ++s) c[s] = c[0];
+#pragma unroll
+  for (int s = 0; s < NC; ++s) { crc[s] = T(1); cfast[s] = false; }
+
+  // one line step: x^(k) line jl + 1 arrives, levels 1 .. nact advance by one line (level t: line jl - (t - 1)).
+  // u = (jl - j_first) mod NC names the coefficient sets (folds to constants after unrolling); the LDS slot of a line is its
+  // parity: two lane addresses per step, the rest are immediate offsets.
+  // u and nact are either plain ints that fold once the loops below are unrolled, or integral_constant arguments
+  // (STATIC_IDX): every index into c[], crc[], cfast[] must be static -- a dynamically indexed set array lives in scratch
+  // memory -- and which of the two forms the register allocator handles without spilling depends on the instance (M5Cfg)
+  auto do_step = [&](const int jl, auto u_c, auto nact_c) {
+    const int u = ic_val(u_c), nact = ic_val(nact_c);
+    __syncthreads();
+    const int pj = (jl + 64) & 1;
+    if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    T* const row_e = buf + pj * LW + tid;          // lines of the parity of jl:     [0] left, [1] own, [2] right
+    T* const row_o = buf + (1 - pj) * LW + tid;    // lines of the other parity
+    auto lds_row = [&](int t) -> T* { return ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LW; };   // level t - 1, line of level t
+    T nl[LV], nr[LV];
+#pragma unroll
+    for (int t = 1; t <= LV && t <= HD; ++t)
+      if (t <= nact) { nl[t - 1] = lds_row(t)[0]; nr[t - 1] = lds_row(t)[2]; }
+#pragma unroll
+    for (int t = 0; t < LV; ++t) { h[t][0] = h[t][1]; h[t][1] = h[t][2]; }      // (levels only assign h[t][2]: a step is idempotent)
+    const bool whole_next = wave_in && jl + 1 >= jlo && jl + 1 < jhi;            // wave-uniform: line jl + 1 exists for every lane
+    h[0][2] = whole_next || live_at(jl + 1) ? xpre : T(0);
+    row_o[1] = h[0][2];                            // level 0, line jl + 1
+    xpre = x0_load(jl + 2);
+    c[(u + 1) % NC] = coef_at(jl + 1);
+    {                                              // first use of the set of line jl (loaded a step ago)
+      const M5Coef<T>& cu = c[u % NC];
+      const int64_t gj = J0 + jl;
+      // the mask a row at this position has when every neighbour that exists is coupled
+      const bool has_down = gj + 1 < nfull || (gj + 1 == nfull && in_tail);
+      const int em = em_i & ~(gj == 0 ? 1 : 0) & ~(has_down ? 0 : 16);
+      bool dok = true;
+      if constexpr (RCP) {
+        const T ad = __builtin_fabs(cu.dg);
+        dok = ad >= Lim::dlo && ad <= Lim::dhi && !Lim::all_ones(cu.dg);
+        crc[u % NC] = T(1) / (dok ? cu.dg : T(1));
+      }
+      cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all((cu.m & 0x1f) == em && dok) != 0;
+      if constexpr (AOS) {                         // the row's owner leaves contiguous copies of A_ii and b
+        if (jl >= 0 && jl < L && owner && live_at(jl)) {
+          const int64_t r = gj * dv.S + gi;
+          diag_out[r] = cu.dg;
+          b_out[r] = cu.b;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bool fast = true;
+#pragma unroll
+    for (int t = 1; t <= LV; ++t)
+      if (t <= nact) fast = fast && cfast[((u - (t - 1)) % NC + NC) % NC];
+    bool bad = false;                              // per lane: a numerator the Markstein step is not proven for
+    if (fast) {
+#pragma unroll
+      for (int t = 1; t <= LV; ++t) {
+        if (t <= nact) {
+          T* const row = lds_row(t);
+          const int ci = ((u - (t - 1)) % NC + NC) % NC;
+          if constexpr (HD > 0 && HD < LV) {
+            if (t + HD <= LV && t + HD <= nact) { nl[t + HD - 1] = lds_row(t + HD)[0]; nr[t + HD - 1] = lds_row(t + HD)[2]; }
+          }
+          T left, right;
+          if constexpr (HD > 0) { left = nl[t - 1]; right = nr[t - 1]; }
+          else { left = row[0]; right = row[2]; }
+          const M5Coef<T>& cc = c[ci];
+          T acc = T(0);
+          acc = acc + cc.v[0] * h[t - 1][0];
+          acc = acc + cc.v[1] * left;
+          acc = acc + cc.v[2] * h[t - 1][1];
+          acc = acc + cc.v[3] * right;
+          acc = acc + cc.v[4] * h[t - 1][2];
+          const int line = jl - (t - 1);
+          if (RES && t == LV) {                    // r = b - A x^(k+TS)   (GNNResidual.py:97-118, as EpiResidual)
+            if (owner) b_out[(J0 + line) * dv.S + gi] = cc.b - acc;
+          } else {
+            const T num = w * (cc.b - acc);
+            T xn;
+            if constexpr (RCP) {
+              const T an = __builtin_fabs(num);
+              bad = bad || !(an > Lim::nlo && an < Lim::nhi);
+              const T q0 = num * crc[ci];
+              const T rem = fma_t(-q0, cc.dg, num);
+              xn = h[t - 1][1] + fma_t(rem, crc[ci], q0);
+            } else {
+              xn = h[t - 1][1] + num / cc.dg;
+            }
+            if (t < LV) { h[t][2] = xn; row[2 * LW + 1] = xn; }     // level t, same line (same parity)
+            if (t == TS) { if (owner && (!RES || (line >= 0 && line < L))) xo[(J0 + line) * dv.S + gi] = xn; }
+          }
+          __builtin_amdgcn_sched_barrier(0);       // levels stay in program order: the scheduler's own interleaving of seven
+        }                                          // levels costs more registers than the two waves per SIMD leave
+      }
+    }
+    if (!fast || __any(bad)) {                     // generic levels: masked in-order sum, IEEE division, +0 outside the matrix
+      asm volatile("" ::: "memory");               // (keeps this path's LDS reads from being merged with the fast path's above the branch)
+#pragma unroll
+      for (int t = 1; t <= LV; ++t) {
+        if (t <= nact) {
+          T* const row = lds_row(t);
+          const int ci = ((u - (t - 1)) % NC + NC) % NC;
+          const int line = jl - (t - 1);
+          const M5Coef<T>& cc = c[ci];
+          const bool lv = live_at(line);
+          const T xs[5] = {h[t - 1][0], row[0], h[t - 1][1], row[2], h[t - 1][2]};
+          const int m = lv ? (int)dv.mask[row_clamped(line)] : 0;      // (not kept per set: this path is rare)
+          T acc = T(0);
+#pragma unroll
+          for (int d = 0; d < 5; ++d) {
+            const T nxt = acc + cc.v[d] * xs[d];
+            acc = ((m >> d) & 1) ? nxt : acc;
+          }
+          if (RES && t == LV) {
+            if (lv && owner) b_out[(J0 + line) * dv.S + gi] = cc.b - acc;
+          } else {
+            T xn = h[t - 1][1] + (w * (cc.b - acc)) / cc.dg;
+            xn = lv ? xn : T(0);
+            if (t < LV) { h[t][2] = xn; row[2 * LW + 1] = xn; }
+            if (t == TS) { if (lv && owner && (!RES || (line >= 0 && line < L))) xo[(J0 + line) * dv.S + gi] = xn; }
+          }
+        }
+      }
+    }
+  };
+  constexpr int u0 = (2 * (LV - 1)) % U;
+  if constexpr (STATIC_IDX) {
+    // ramp-up: step s = jl - j_first < 2 (LV - 1) has levels 1 .. (s + 2) / 2 active (x^(k+t) starts on line -(LV - t))
+    auto ramp = [&](auto self, auto s_c) {
+      constexpr int sidx = decltype(s_c)::value;
+      if constexpr (sidx < 2 * (LV - 1)) {
+        do_step(j_first + sidx, IC<sidx % U>{}, IC<(sidx + 2) / 2>{});
+        self(self, IC<sidx + 1>{});
+      }
+    };
+    ramp(ramp, IC<0>{});
+    // steady state: lines 0 .. L - 1 leave the last level, one per step
+    auto round = [&](auto self, auto q_c, const int jl0) -> bool {          // U steps; false: the block is done
+      constexpr int q = decltype(q_c)::value;
+      if constexpr (q < U) {
+        if (jl0 + q > j_last) return false;
+        do_step(jl0 + q, IC<(u0 + q) % U>{}, IC<LV>{});
+        return self(self, IC<q + 1>{}, jl0);
+      } else {
+        return true;
+      }
+    };
+#pragma unroll 1
+    for (int jl0 = LV - 1; round(round, IC<0>{}, jl0); jl0 += U) {}
+  } else {
+#pragma unroll
+    for (int s = 0; s < 2 * (LV - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
+#pragma unroll 1
+    for (int jl0 = LV - 1;; jl0 += U) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        if (jl0 + q > j_last) return;
+        do_step(jl0 + q, (u0 + q) % U, LV);
+      }
+    }
+  }
+}
+
+// Markstein division and LDS prefetch depth per level count: what fits two waves per SIMD (256 registers; the build log of
+// csrc/build.sh shows the allocation of every instance)
+template <typename T, int LV, int MODE> struct M5Cfg {
+  static constexpr bool rcp = sizeof(T) == 4 || LV <= 7;
+  static constexpr int hd = sizeof(T) == 4 ? 2 : (LV >= 8 || (MODE == M5_AOS && LV == 6) ? 0 : 2);
+  static constexpr bool static_idx = sizeof(T) == 4 || LV >= 8;
+};
+#define M5_KERNEL(T, TS, MODE, LV) jacobi_march5_kernel<T, TS, MODE, M5Cfg<T, LV, MODE>::rcp, M5Cfg<T, LV, MODE>::hd, M5Cfg<T, LV, MODE>::static_idx>
+
+template <typename T, int TS, int MODE>
+int m5_blocks_per_cu() {
+  static int cached = 0;
+  if (!cached) {
+    constexpr int LV = TS + (MODE == M5_RES ? 1 : 0);
+    int nb = 0;
+    const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, M5_KERNEL(T, TS, MODE, LV), GLA_BLOCK, lds) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = 2;
+    }
+    cached = nb;
+  }
+  return cached;
+}
+
+template <typename T, int TS, int MODE>
+int m5_launch(const gla_march5_args& a) {
+  gla_csr* A = a.A;
+  constexpr int LV = TS + (MODE == M5_RES ? 1 : 0);
+  M5View dv;
+  dv.val = A->dia_val;
+  dv.mask = A->dia_mask;
+  dv.S = A->dia_S; dv.n_rows = A->n_rows;
+  dv.nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
+  dv.aos_off = a.aos_off;
+  dv.aos_rows = a.aos_rows >= 0 ? a.aos_rows : A->n_rows;
+  const int64_t nlines = dv.nlines;
+  const int bi_eff = GLA_BLOCK - 2 * LV;
+  const int nstrips = (int)((A->dia_S + bi_eff - 1) / bi_eff);
+  const int part = a.part, ghost = a.ghost;
+  // Interior / boundary split (part 1 / 2, the multi-GPU route): the first and the last `ghost` grid lines of x arrive while
+  // the interior blocks run, so no interior block may read them: the first and the last line block are ghost + LV lines
+  // high (an interior block reads x from LV lines above its first line), everything between is split as for part 0.
+  // Grids too short for that (fewer than 2 edge blocks + 1 line) count as boundary as a whole.
+  const int edge = part != 0 && nlines > 2 * (int64_t)(ghost + LV) ? ghost + LV : 0;
+  const int64_t inner_lines = nlines - 2 * edge;
+  int lines = g_tuning.jacobi_lines;
+  if (lines <= 0) {
+    // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (LV - 1) coefficient
+    // lines) for which all workgroups are resident at once.  Measured (tools/ab_jacobi_march.py): two workgroups per CU beat
+    // three or four even where the registers allow more -- fewer, longer streams; one per CU cannot hide a line step
+    int per_cu = m5_blocks_per_cu<T, TS, MODE>();
+    if (per_cu > 2) per_cu = 2;
+    lines = gla_pick_block_lines(inner_lines, nstrips, 256 * per_cu, 2 * (LV - 1), 2 * LV);
+    if (lines > 1024) lines = 1024;
+  }
+  if (lines < 2 * LV) lines = 2 * LV;
+  const int nlb_all = (int)((inner_lines + lines - 1) / lines) + (edge ? 2 : 0);
+  dv.edge = edge;
+  dv.nlb = nlb_all;
+  int base0 = 0, split = nlb_all * nstrips, base1 = 0, count = nlb_all * nstrips;
+  if (part == 1) {                                  // line blocks 1 .. nlb - 2
+    if (!edge) return GLA_OK;
+    base0 = nstrips; count = split = (nlb_all - 2) * nstrips;
+  } else if (part == 2) {                           // the first and the last line block (all of them on short grids)
+    if (edge) { base0 = 0; split = nstrips; base1 = (nlb_all - 1) * nstrips; count = 2 * nstrips; }
+  }
+  TileMap tm;
+  tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
+  tm.n_tiles = count;
+  set_tile_mapping(tm);
+  const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
+  const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
+  hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV)), grid, block, lds, a.st, dv,
+                     (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1,
+                     a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+template <typename T, int MODE>
+int m5_dispatch_ts(const gla_march5_args& a) {
+  switch (a.ts) {
+    case 1: if constexpr (MODE == M5_RES) return m5_launch<T, 1, MODE>(a); else return GLA_ERR_UNSUPPORTED;
+    case 2: return m5_launch<T, 2, MODE>(a);
+    case 3: return m5_launch<T, 3, MODE>(a);
+    case 4: return m5_launch<T, 4, MODE>(a);
+    case 5: return m5_launch<T, 5, MODE>(a);
+    case 6: return m5_launch<T, 6, MODE>(a);
+    case 7: return m5_launch<T, 7, MODE>(a);
+    case 8: if constexpr (MODE != M5_RES) return m5_launch<T, 8, MODE>(a); else return GLA_ERR_UNSUPPORTED;
+    default: return GLA_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace
+
+// `ts` sweeps (2 .. 8; with res: 1 .. 7 sweeps + the residual) of the canonical 5-point plan A in one pass.  The caller
+// (gla_rows.hip) has checked the plan (jacobi_fused_ok + gla_dia_canon5) and the operands.
+int gla_march5_pass(const gla_march5_args& a) {
+  if (!a.A || !gla_dia_canon5(a.A) || a.part < 0 || a.part > 2) return GLA_ERR_UNSUPPORTED;
+  const int lv = a.ts + (a.res ? 1 : 0);
+  if (a.ghost < lv && a.part != 0) return GLA_ERR_INVALID_ARG;
+  if (a.res) {
+    if (a.ldva > 0 || a.part != 0) return GLA_ERR_UNSUPPORTED;
+    return a.dtype == GLA_F64 ? m5_dispatch_ts<double, M5_RES>(a) : m5_dispatch_ts<float, M5_RES>(a);
+  }
+  if (a.ldva > 0) return a.dtype == GLA_F64 ? m5_dispatch_ts<double, M5_AOS>(a) : m5_dispatch_ts<float, M5_AOS>(a);
+  return a.dtype == GLA_F64 ? m5_dispatch_ts<double, M5_PLAIN>(a) : m5_dispatch_ts<float, M5_PLAIN>(a);
+}

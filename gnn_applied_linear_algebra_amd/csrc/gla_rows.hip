@@ -1158,162 +1158,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same pass for the canonical 5-point pattern (diagonals (-1,0) (0,-1) (0,0) (0,1) (1,0) in that order, B = 1), built
-// around what bounded the generic kernel above: instruction issue (~335 VALU instructions per line step, of which a third
-// masks, a tenth register rotation and a tenth LDS addressing; rocprof + ISA count).  Here
-//   * the j -/+ 1 neighbours and the centre are the lane's OWN values of the last three line steps -> registers (h[t][0..2]);
-//     LDS only carries the i -/+ 1 neighbours: one padded line per level and line parity, one write + two reads per update,
-//     and since a level reads what the level below wrote a step EARLIER, ONE barrier per line step;
-//   * the line loop is unrolled over the TS + 1 coefficient sets (and the line parity), so sets and LDS slots have static names:
-//     no register rotation, no address arithmetic;
-//   * a wave whose 64 rows all carry the full pattern (wave-uniform flag per coefficient set) skips the mask selects; any other
-//     wave takes the masked in-order sum.  Both are the arithmetic of spmv_dia_kernel + EpiJacobi: bit-identical.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int TS, bool AOS = false, bool RES = false>
-__global__ __launch_bounds__(GLA_BLOCK) void jacobi_march5_kernel(Dia2D dv, const T* __restrict__ diag,
-                                                                  const T* __restrict__ bvec, const T* __restrict__ x,
-                                                                  T* __restrict__ xo, T w, int lines, int nstrips,
-                                                                  int64_t nlines, TileMap tm, int tile_base0, int tile_split,
-                                                                  int tile_base1, int64_t ldva = 1,
-                                                                  T* __restrict__ diag_out = nullptr,
-                                                                  T* __restrict__ b_out = nullptr) {
-  constexpr int BW = GLA_BLOCK, LW = BW + 2;      // a line in LDS: lane tid at [1 + tid], one pad either side
-  constexpr int LV = TS + (RES ? 1 : 0);          // levels: TS sweeps; RES: + one level that forms r = b - A x^(k+TS) (-> b_out)
-  constexpr int NC = LV + 1;                      // coefficient sets in flight (lines jl + 1 .. jl - TS + 1)
-  constexpr int U = NC;                           // unroll: static set index
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* buf = reinterpret_cast<T*>(smem_raw);        // [TS][2][LW]: buf[t][p] = the latest line of parity p of x^(k+t)
-  const int slot = map_tile(tm);
-  if (slot < 0) return;
-  const int blk = slot < tile_split ? tile_base0 + slot : tile_base1 + (slot - tile_split);
-  constexpr int halo = LV, bi_eff = BW - 2 * halo;
-  const int lb = blk / nstrips, strip = blk - lb * nstrips;
-  const int64_t P0 = (int64_t)strip * bi_eff - halo;
-  int64_t J0;
-  int L;
-  march_block(lb, lines, dv.nbi, dv.nbj, nlines, J0, L);
-  const int tid = threadIdx.x;
-  const T* __restrict__ val = static_cast<const T*>(dv.val);
-  const int64_t gi = P0 + tid;
-  const bool in_i = gi >= 0 && gi < dv.S;
-  const bool owner = tid >= halo && tid < BW - halo;
-
-  auto x0_at = [&](int jl) -> T {
-    int64_t flat = (J0 + jl) * dv.S + gi;
-    flat = min(max(flat, (int64_t)0), dv.n_cols - 1);
-    if constexpr (AOS) return x[min(max(flat - dv.aos_off, (int64_t)0), dv.aos_rows - 1) * ldva + 2];
-    else return x[flat];
-  };
-  auto coef_at = [&](int jl) -> DiaCoef<T, 5> {
-    const int64_t gj = J0 + jl, r = gj * dv.S + gi;
-    const bool live = in_i && gj >= 0 && gj < nlines && r < dv.n_rows;
-    const int64_t rc = live ? r : 0;
-    DiaCoef<T, 5> c;
-#pragma unroll
-    for (int d = 0; d < 5; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
-    if constexpr (AOS) {
-      const int64_t ra = min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1);
-      c.dg = x[ra * ldva];
-      c.b = x[ra * ldva + 1];
-    }
-    else { c.b = bvec[rc]; c.dg = diag[rc]; }
-    c.m = (int)dv.mask[rc];
-    c.lv = live;
-    return c;
-  };
-  auto update = [&](const DiaCoef<T, 5>& c, bool full, T up, T left, T ctr, T right, T down, bool residual) -> T {
-    T acc = T(0);
-    if (full) {
-      acc = acc + c.v[0] * up;
-      acc = acc + c.v[1] * left;
-      acc = acc + c.v[2] * ctr;
-      acc = acc + c.v[3] * right;
-      acc = acc + c.v[4] * down;
-    } else {
-      const T xs[5] = {up, left, ctr, right, down};
-      const int m = c.lv ? c.m : 0;
-#pragma unroll
-      for (int d = 0; d < 5; ++d) {
-        const T nxt = acc + c.v[d] * xs[d];
-        acc = ((m >> d) & 1) ? nxt : acc;
-      }
-    }
-    if (residual) return c.b - acc;                 // (GNNResidual.py:97-118, as EpiResidual)
-    return ctr + (w * (c.b - acc)) / c.dg;
-  };
-
-  constexpr int j_first = -(LV - 1);
-  const int j_last = L - 1 + (LV - 1);
-  T h[LV][3];                                      // h[t]: x^(k+t) of this lane on the last three lines level t produced
-#pragma unroll
-  for (int t = 0; t < LV; ++t) h[t][0] = h[t][1] = h[t][2] = T(0);
-  h[0][1] = x0_at(j_first - 1);
-  h[0][2] = x0_at(j_first);
-  buf[((j_first + 64) & 1) * LW + 1 + tid] = h[0][2];
-  T xpre = x0_at(j_first + 1);
-  DiaCoef<T, 5> c[NC];                             // set of line j_first + s lives in c[s % NC]
-  bool cfull[NC];
-  c[0] = coef_at(j_first);
-#pragma unroll
-  for (int s = 1; s < NC; ++s) c[s] = c[0];
-#pragma unroll
-  for (int s = 0; s < NC; ++s) cfull[s] = false;
-
-  // one line step: x^(k) line jl + 1 arrives, levels 1 .. nact advance by one line (level t: line jl - (t - 1)).
-  // u = (jl - j_first) mod NC names the coefficient sets (folds to constants after unrolling); the LDS slot of a line is its
-  // parity: two lane addresses per step, the rest are immediate offsets.
-  auto do_step = [&](const int jl, const int u, const int nact) {
-    __syncthreads();
-    const int pj = (jl + 64) & 1;
-    T* const row_e = buf + pj * LW + tid;          // lines of the parity of jl:     [0] left, [1] own, [2] right
-    T* const row_o = buf + (1 - pj) * LW + tid;    // lines of the other parity
-    h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
-    row_o[1] = xpre;                               // level 0, line jl + 1
-    xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
-    c[(u + 1) % NC] = coef_at(jl + 1);
-    cfull[u % NC] = __all(c[u % NC].lv && (c[u % NC].m & 0x1f) == 0x1f) != 0;   // (at first use: loaded a step ago)
-    if constexpr (AOS) {
-      const DiaCoef<T, 5>& c0 = c[u % NC];
-      if (jl >= 0 && jl < L && c0.lv && owner) {
-        const int64_t r = (J0 + jl) * dv.S + gi;
-        diag_out[r] = c0.dg;
-        b_out[r] = c0.b;
-      }
-    }
-#pragma unroll
-    for (int t = 1; t <= LV; ++t) {
-      if (t <= nact) {
-        T* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LW;   // level t - 1, line jl - (t - 1)
-        const int ci = ((u - (t - 1)) % NC + NC) % NC;
-        const T xn = update(c[ci], cfull[ci], h[t - 1][0], row[0], h[t - 1][1], row[2], h[t - 1][2], RES && t == LV);
-        if (t < LV) {
-          h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
-          row[2 * LW + 1] = xn;                    // level t, same line (same parity)
-        }
-        if (t == TS) {                             // the iterate after TS sweeps (RES: its level also runs one line either side)
-          const int line = jl - (TS - 1);
-          if (c[ci].lv && owner && (!RES || (line >= 0 && line < L))) xo[(J0 + line) * dv.S + gi] = xn;
-        } else if (RES && t == LV) {               // ... and its residual
-          if (c[ci].lv && owner) b_out[(J0 + jl - (LV - 1)) * dv.S + gi] = xn;
-        }
-      }
-    }
-  };
-  // ramp-up: step s = jl - j_first < 2 (TS - 1) has levels 1 .. (s + 2) / 2 active (x^(k+t) starts on line -(TS - t))
-#pragma unroll
-  for (int s = 0; s < 2 * (LV - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
-  // steady state: lines 0 .. L - 1 leave the last level, one per step
-  constexpr int u0 = (2 * (LV - 1)) % U;
-#pragma unroll 1
-  for (int jl0 = LV - 1;; jl0 += U) {
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      if (jl0 + q > j_last) return;
-      do_step(jl0 + q, (u0 + q) % U, LV);
-    }
-  }
-}
+// (the march for the canonical 5-point pattern, jacobi_march5_kernel, lives in gla_march5.hip: gla_march5_pass)
 
 // ------------------------------------------------------------------------------------------------
 // The march for the canonical 9-point pattern (diagonals (-1,-1) (-1,0) (-1,1) (0,-1) (0,0) (0,1) (1,-1) (1,0) (1,1): the Q1
@@ -1477,22 +1322,6 @@ inline bool jacobi_canon(const gla_csr* A) { return g_tuning.jacobi_march && gla
 inline bool jacobi_canon9(const gla_csr* A) { return g_tuning.jacobi_march && gla_dia_canon9(A); }
 constexpr int JACOBI_TS_MAX9 = 6;
 
-// workgroups of the march kernel a CU holds at once (registers decide: 5 at TS = 2 ... 2 at TS = 8 in fp64)
-template <typename T, int TS, bool AOS>
-int jacobi_march_blocks_per_cu() {
-  static int cached = 0;
-  if (!cached) {
-    int nb = 0;
-    const size_t lds5 = (size_t)TS * 2 * (GLA_BLOCK + 2) * sizeof(T);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, jacobi_march5_kernel<T, TS, AOS>, GLA_BLOCK, lds5) != hipSuccess || nb < 1) {
-      (void)hipGetLastError();
-      nb = 2;
-    }
-    cached = nb;
-  }
-  return cached;
-}
-
 template <typename T, int TS, bool AOS>
 int jacobi_march9_blocks_per_cu() {
   static int cached = 0;
@@ -1515,6 +1344,14 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   constexpr bool generic_ts = TS == 2 || TS == 4 || TS == 5;      // what jacobi_fused_dia2d_kernel is instantiated for
   const bool canon = jacobi_canon(A);
   const bool canon9 = TS <= JACOBI_TS_MAX9 && jacobi_canon9(A);
+  if (canon) {                                      // register-history march for the canonical 5-point pattern (gla_march5.hip)
+    gla_march5_args a;
+    a.A = A; a.dtype = sizeof(T) == 8 ? GLA_F64 : GLA_F32; a.ts = TS; a.res = false;
+    a.diag = diag; a.b = b; a.x = x; a.xo = xo; a.w = (double)w; a.st = st; a.part = part;
+    a.ldva = ldva; a.diag_out = diag_out; a.b_out = b_out; a.ghost = ghost; a.aos_off = aos_off; a.aos_rows = aos_rows;
+    if (part < 0 || part > 2 || ghost < TS) return GLA_ERR_INVALID_ARG;
+    return gla_march5_pass(a);
+  }
   if (!canon && !canon9 && !generic_ts) return GLA_ERR_UNSUPPORTED;
   if (part < 0 || part > 2 || ghost < TS) return GLA_ERR_INVALID_ARG;
   Dia2D dv;
@@ -1540,12 +1377,7 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (TS - 1) coefficient
     // lines) for which all workgroups are resident at once -- 256 CUs x the workgroups per CU the register budget allows
     int64_t per_cu;
-    if (canon) {
-      // measured (tools/ab_jacobi_march.py): two workgroups per CU beat three or four even where the registers allow more
-      // (TS = 5: 252 vs 315 us) -- fewer, longer streams, less overlap between blocks; one per CU cannot hide a line step
-      per_cu = ldva > 0 ? jacobi_march_blocks_per_cu<T, TS, true>() : jacobi_march_blocks_per_cu<T, TS, false>();
-      if (per_cu > 2) per_cu = 2;
-    } else if (canon9) {
+    if (canon9) {
       per_cu = ldva > 0 ? jacobi_march9_blocks_per_cu<T, TS, true>() : jacobi_march9_blocks_per_cu<T, TS, false>();
       if (per_cu > 2) per_cu = 2;
     }
@@ -1553,7 +1385,7 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     lines = gla_pick_block_lines(inner_lines, nstrips, 256 * per_cu, 2 * (TS - 1), 2 * TS);
     if (lines > 1024) lines = 1024;
   }
-  if (lines < 2 * TS && (canon || canon9)) lines = 2 * TS;
+  if (lines < 2 * TS && canon9) lines = 2 * TS;
   const int nlb_all = (int)((inner_lines + lines - 1) / lines) + (edge ? 2 : 0);
   dv.nbi = edge;
   dv.nbj = nlb_all;
@@ -1569,17 +1401,6 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   tm.n_tiles = count;
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
-  if (canon) {                                      // register-history march for the canonical 5-point pattern
-    const size_t lds5 = (size_t)TS * 2 * (GLA_BLOCK + 2) * sizeof(T);
-    if (ldva > 0)
-      hipLaunchKernelGGL((jacobi_march5_kernel<T, TS, true>), grid, block, lds5, st, dv, diag, b, x, xo, w, lines, nstrips,
-                         nlines, tm, base0, split, base1, ldva, diag_out, b_out);
-    else
-      hipLaunchKernelGGL((jacobi_march5_kernel<T, TS>), grid, block, lds5, st, dv, diag, b, x, xo, w, lines, nstrips, nlines,
-                         tm, base0, split, base1);
-    GLA_LAUNCH_CHECK();
-    return GLA_OK;
-  }
   if constexpr (TS <= JACOBI_TS_MAX9) {
     if (canon9) {                                   // the same march for the canonical 9-point pattern
       const size_t lds9 = (size_t)TS * 3 * (GLA_BLOCK + 2) * sizeof(T);
@@ -1619,6 +1440,13 @@ template <typename T, int TS>
 int launch_jacobi_fused_res(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T* ro, T w, hipStream_t st) {
   const bool canon = TS + 1 <= 8 && jacobi_canon(A);
   const bool canon9 = TS + 1 <= JACOBI_TS_MAX9 && jacobi_canon9(A);
+  if (canon) {                                      // gla_march5.hip
+    gla_march5_args a;
+    a.A = A; a.dtype = sizeof(T) == 8 ? GLA_F64 : GLA_F32; a.ts = TS; a.res = true;
+    a.diag = diag; a.b = b; a.x = x; a.xo = xo; a.w = (double)w; a.st = st; a.part = 0;
+    a.ldva = 0; a.diag_out = nullptr; a.b_out = ro; a.ghost = TS + 1; a.aos_off = 0; a.aos_rows = -1;
+    return gla_march5_pass(a);
+  }
   if (!canon && !canon9) return GLA_ERR_UNSUPPORTED;
   constexpr int LV = TS + 1;
   Dia2D dv;
@@ -1642,11 +1470,7 @@ int launch_jacobi_fused_res(gla_csr* A, const T* diag, const T* b, const T* x, T
   tm.n_tiles = dv.nbj * nstrips;
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
-  if (canon) {
-    if constexpr (TS + 1 <= 8)
-      hipLaunchKernelGGL((jacobi_march5_kernel<T, TS, false, true>), grid, block, (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T), st, dv,
-                         diag, b, x, xo, w, lines, nstrips, nlines, tm, 0, tm.n_tiles, 0, (int64_t)1, (T*)nullptr, ro);
-  } else {
+  {
     if constexpr (TS + 1 <= JACOBI_TS_MAX9)
       hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, false, true>), grid, block, (size_t)LV * 3 * (GLA_BLOCK + 2) * sizeof(T), st, dv,
                          diag, b, x, xo, w, lines, nstrips, nlines, tm, 0, tm.n_tiles, 0, (int64_t)1, (T*)nullptr, ro);
