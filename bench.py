@@ -59,6 +59,10 @@ def parse_args(argv=None):
                          "is cut into N row blocks; reports scaling=strong")
     ap.add_argument("--strong-grid", type=int, default=8192, help="grid of the config4_strong side record (N > 1)")
     ap.add_argument("--no-side", action="store_true", help="skip every side record (csr_general, config3_k16, ...)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE over tools/pmc_workload.py) that "
+                         "measure roofline.traffic in this run; the figure of profiles/traffic_jacobi.json is then quoted, marked")
+    ap.add_argument("--pmc-timeout", type=float, default=150.0, help="seconds per rocprofv3 counter pass")
     ap.add_argument("--no-optin", action="store_true", help="skip the side measurement of the opt-in packed stream")
     ap.add_argument("--no-dia", action="store_true",
                     help="keep the CSR kernels (compact index streams) instead of the diagonal layout for stencils")
@@ -206,6 +210,80 @@ def cpu_baseline(n_grid, sweeps):
             "ms_per_sweep": round(1e3 * dt / sweeps, 1)}
 
 
+def measure_traffic(n_grid, timeout_s):
+    """HBM bytes per launch of the dominant Jacobi kernel from the PMC counters, measured NOW on this box: two child runs of
+    `rocprofv3 --pmc <counter> -- python3 tools/pmc_workload.py N` (FETCH_SIZE, WRITE_SIZE: separate passes, KiB units,
+    FETCH_SIZE x 2 on gfx950 -- MI355X_MICROARCH.md, HBM section; the factor is checked against the workload's calibration
+    kernel of known volume).  Returns a dict, or {"error": ...}.  The children are started as ordinary subprocesses of this
+    (GPU-initialised) process -- nothing is exec'ed in place -- and stopped by PID on a time-out."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="gla_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), str(n_grid)]
+            pr_ = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            try:
+                rc = pr_.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                pr_.kill()
+                pr_.wait()
+                return {"error": f"rocprofv3 --pmc {ctr} pass timed out after {timeout_s:.0f} s"}
+            if rc != 0:
+                return {"error": f"rocprofv3 --pmc {ctr} pass exited with {rc}"}
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
+            cover, per = {}, {}
+            for r in rows:
+                name = r["Kernel_Name"]
+                m = re.search(r"jacobi_march5_kernel<\w+,\s*(\d+)", name) or re.search(r"jacobi_fused_dia2d_kernel<\w+,\s*\d+,\s*(\d+)", name)
+                key = None
+                if m:
+                    key = ("jacobi", int(m.group(1)))
+                elif "EpiJacobi" in name:
+                    key = ("jacobi", 1)
+                elif "CUDAFunctor_add" in name:
+                    key = ("calib", 0)
+                if key:
+                    per.setdefault(key, []).append(float(r["Counter_Value"]))
+                    if key[0] == "jacobi":
+                        cover[key] = cover.get(key, 0) + key[1]
+            if not cover or ("calib", 0) not in per:
+                return {"error": f"no Jacobi / calibration kernel rows in the {ctr} pass"}
+            dom = max(cover, key=lambda k: (cover[k], k[1]))
+            vals[ctr] = (dom[1], sum(per[dom]) / len(per[dom]), sum(per[("calib", 0)]) / len(per[("calib", 0)]), len(per[dom]))
+        spl_f, fetch_kib, calib_f, nl = vals["FETCH_SIZE"]
+        spl_w, write_kib, calib_w, _ = vals["WRITE_SIZE"]
+        if spl_f != spl_w:
+            return {"error": "the two passes disagree on the dominant kernel"}
+        fetch_factor = 2 * 512 * 1024 / calib_f          # the calibration kernel reads 2 x 512 MiB, writes 512 MiB
+        write_factor = 512 * 1024 / calib_w
+        if not (1.8 < fetch_factor < 2.2 and 0.9 < write_factor < 1.1):
+            return {"error": f"calibration kernel off: fetch x{fetch_factor:.3f}, write x{write_factor:.3f}"}
+        rd, wr = fetch_kib * 1024 * 2.0, write_kib * 1024
+        return {"sweeps_per_launch": spl_f, "launches_averaged": nl, "hbm_read_bytes_per_launch": int(rd),
+                "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
+                "calibration_fetch_factor_measured": round(fetch_factor, 4),
+                "calibration_write_factor_measured": round(write_factor, 4)}
+    except Exception as exc:                                 # (a measurement aid: never the reason a bench run fails)
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def median(xs):
     xs = sorted(xs)
     m = len(xs) // 2
@@ -296,60 +374,81 @@ def single_gpu(args, gla, dev):
     launches = len(sched)
     spl = max(set(sched), key=lambda ts: (ts * sched.count(ts), ts))      # sweeps per launch of the dominant kernel
     per_call = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in sweep_events]      # seconds per jacobi_sweeps call
-    # the events bracket a whole call (its launches are enqueued by one library call); a launch's share of it is taken
-    # proportional to its sweeps.  Passes of fewer sweeps take nearly as long as the dominant ones (a pass is bound by
-    # one trip of the matrix through HBM), so this is a conservative figure for the dominant kernel; the rocprof kernel
-    # stats under profiles/ give each kernel's own average
-    per_launch = [t * spl / args.sweeps for t in per_call]
-    t_launch = sum(per_launch) / len(per_launch)
+    # (a) inside the timed steps the events bracket a whole library call (its launches are enqueued by one call); a launch's
+    #     share is taken proportional to its sweeps: `in_step_bracket_us`
+    t_bracket = sum(t * spl / args.sweeps for t in per_call) / len(per_call)
+    # (b) the dominant kernel ALONE: one launch of `spl` sweeps (gla_jacobi_fused / gla_jacobi_sweep), HIP events on the launch
+    #     stream around every single launch, 3 warm-up + 15 timed -- this is the duration `roofline` is built on
+    from gnn_applied_linear_algebra_amd._lib import ptr, dtype_code, stream_ptr
+    diag1, xo_buf = pr.diag.reshape(-1).contiguous(), torch.empty_like(pr.x0)
+    alone = []
+    for it in range(18):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if spl > 1:
+            check(L.gla_jacobi_fused(plan._h, dtype_code(torch.float64), ptr(diag1), ptr(pr.b), ptr(pr.x0), ptr(xo_buf), 0.7, spl,
+                                     0, stream_ptr(dev)))
+        else:
+            plan.jacobi_sweep(diag1, pr.b, pr.x0, xo_buf, 0.7)
+        e1.record()
+        torch.cuda.synchronize()
+        if it >= 3:
+            alone.append(e0.elapsed_time(e1) * 1e-3)
+    t_launch, t_launch_med = sum(alone) / len(alone), median(alone)
     info = plan.info
     B_launch = pr.B * spl                                    # per-sweep bytes x the sweeps of one launch
     fused = spl > 1
     march = fused and bool(info.dia_canon5) and plan.jacobi_schedule(3) == (3,)      # (3 per pass: march kernel only)
     kname = ((f"jacobi_march{5 if int(info.dia_canon5) == 1 else 9}_kernel<double,{spl}>" if march else
               f"jacobi_fused_dia2d_kernel<double,{5 if int(info.dia) <= 5 else 9},{spl}>") if fused else
-             "spmv_stream_vec2_kernel<double,EpiJacobi>")
-    roof = {"bound": "hbm", "achieved": round(B_launch / t_launch / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(B_launch / t_launch / HBM_PEAK, 4), "traffic": None,
-            "kernel": kname, "sweeps_per_launch": spl, "launches_per_step": launches, "schedule": list(sched),
-            "algorithmic_bytes_per_launch": B_launch, "algorithmic_bytes_per_sweep": pr.B,
-            "avg_launch_us": round(t_launch * 1e6, 2), "median_launch_us": round(median(per_launch) * 1e6, 2)}
-    if fused:
-        roof["note"] = (f"{spl} sweeps per pass over the data (temporal blocking: the intermediate iterates stay on chip, "
-                        "matrix, b and A_ii are read once per pass), so SURVEY's per-sweep byte model x the sweeps of a "
-                        "launch exceeds what HBM has to deliver and frac > 1 is expected; `traffic` and "
-                        "`hbm_utilisation_by_traffic` are the bytes really moved")
+             ("spmv_dia_kernel<double,EpiJacobi>" if int(info.dia) > 0 and not bool(info.packed) else
+              "spmv_stream_vec2_kernel<double,EpiJacobi>"))
+    # bytes one launch has to move with this plan's layout (one pass over the matrix whatever the sweeps it carries)
+    if int(info.dia) > 0 and not bool(info.packed):
+        layout_name, Bl = f"dia{int(info.dia)}" + (f", {spl} sweeps per pass" if fused else ""), (8 * int(info.dia) + 2 + 32) * pr.n_local
+    elif args.compress and bool(info.packed):
+        layout_name, Bl = "packed stream", 3 * pr.nnz + 2 * (pr.n_local + int(info.n_tiles)) + 32 * pr.n_local
+        kname = "spmv_packed_kernel<double,EpiJacobi>"
+    elif bool(info.col16):
+        layout_name, Bl = "csr, int16 tile-relative columns", 10 * pr.nnz + 2 * (pr.n_local + int(info.n_tiles)) + 32 * pr.n_local
+    else:
+        layout_name, Bl = "csr int32", pr.B
+    # roofline.traffic: HBM bytes per launch by the PMC counters -- measured in THIS run when rocprofv3 is there (two child
+    # passes over tools/pmc_workload.py), else the tracked figure of an earlier run of the same kernel and layout, marked so
+    traffic, traffic_source, pmc = None, None, None
+    default_layout_ = not (args.compress or args.no_col16 or args.no_dia)
+    if default_layout_ and not args.no_pmc and not args.no_side:
+        pmc = measure_traffic(args.n, args.pmc_timeout)
+        if "error" not in pmc and pmc["sweeps_per_launch"] == spl:
+            traffic = pmc["hbm_bytes_per_launch"]
+            traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes over "
+                              "tools/pmc_workload.py, FETCH_SIZE x 2 per the gfx950 note, calibration kernel checked)")
     tp = os.path.join(ROOT, "profiles", "traffic_jacobi.json")
-    if os.path.exists(tp):                                   # PMC passes of the same kernel + layout (tools/pmc_*.py)
+    if traffic is None and os.path.exists(tp):
         tj = json.load(open(tp))
         if tj.get("n") == args.n and int(tj.get("dia", 0)) == int(info.dia) and not bool(info.packed) \
                 and int(tj.get("sweeps_per_launch", 1)) == spl and (fused or int(tj.get("col16", 0)) == int(info.col16)):
-            roof["traffic"] = tj.get("hbm_bytes_per_launch")
-            roof["traffic_source"] = "profiles/traffic_jacobi.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes " \
-                                     "of this kernel and layout; not re-measured by this run)"
-            roof["hbm_utilisation_by_traffic"] = round(roof["traffic"] / t_launch / HBM_PEAK, 4)
-    if fused:
-        Bl = (8 * int(info.dia) + 2 + 32) * pr.n_local        # one pass: values, mask, b, A_ii, x in, x out
-        roof.update({"layout": f"dia{int(info.dia)}, {spl} sweeps per pass", "layout_bytes_per_launch": Bl,
-                     "layout_achieved": round(Bl / t_launch / 1e9, 1), "layout_frac": round(Bl / t_launch / HBM_PEAK, 4)})
-    elif int(info.dia) > 0 and not bool(info.packed):
-        # stencil matrices, one sweep per pass: values diagonal-major, NO index stream (a 2-byte row mask instead).
-        # `achieved` / `frac` keep SURVEY 8(d)'s CSR byte model as prescribed; `layout_*` is what the kernel really
-        # has to move: 8 D bytes of values + 2 per row + the vectors
-        Bl = (8 * int(info.dia) + 2 + 32) * pr.n_local
-        roof.update({"kernel": "spmv_dia_kernel<double,EpiJacobi>", "layout": f"dia{int(info.dia)}",
-                     "layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
-                     "layout_frac": round(Bl / t_launch / HBM_PEAK, 4)})
-    elif bool(info.col16) and not bool(info.packed):
-        # 2-byte tile-relative columns: 10 B per nonzero, 2-byte tile-relative row offsets
-        Bl = 10 * pr.nnz + 2 * (pr.n_local + int(info.n_tiles)) + 32 * pr.n_local
-        roof.update({"layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
-                     "layout_frac": round(Bl / t_launch / HBM_PEAK, 4)})
-    if args.compress and bool(info.packed):
-        Bl = 3 * pr.nnz + 2 * (pr.n_local + int(info.n_tiles)) + 32 * pr.n_local
-        roof.update({"kernel": "spmv_packed_kernel<double,EpiJacobi>", "traffic": None,
-                     "layout_bytes_per_launch": Bl, "layout_achieved": round(Bl / t_launch / 1e9, 1),
-                     "layout_frac": round(Bl / t_launch / HBM_PEAK, 4)})
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/traffic_jacobi.json: PMC passes of an EARLIER run of this kernel and layout, not re-measured now"
+    moved = traffic if traffic is not None else Bl
+    roof = {"bound": "hbm", "achieved": round(moved / t_launch / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(moved / t_launch / HBM_PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "bytes_moved_per_launch": moved,
+            "bytes_moved_is": "PMC traffic" if traffic is not None else f"layout bytes of one pass ({layout_name})",
+            "unit_of_a_launch": "one pass over the matrix" + (f" carrying {spl} sweeps (temporal blocking)" if fused else " = one sweep"),
+            "kernel": kname, "sweeps_per_launch": spl, "launches_per_step": launches, "schedule": list(sched),
+            "avg_launch_us": round(t_launch * 1e6, 2), "median_launch_us": round(t_launch_med * 1e6, 2),
+            "launch_timing": "HIP events on the launch stream around single launches of this kernel alone, 15 after 3 warm-up",
+            "in_step_bracket_us": round(t_bracket * 1e6, 2),
+            "layout": layout_name, "layout_bytes_per_launch": Bl, "layout_frac": round(Bl / t_launch / HBM_PEAK, 4),
+            # SURVEY 8(d)'s CSR byte model: per pass (the unit a launch processes) and per sweep x the sweeps of a launch.  The
+            # latter exceeds what HBM delivers once several sweeps share a pass: a ratio, not a rate
+            "algorithmic_bytes_per_sweep": pr.B, "pass_model_frac": round(pr.B / t_launch / HBM_PEAK, 4),
+            "algorithmic_bytes_per_launch": B_launch, "model_ratio": round(B_launch / t_launch / HBM_PEAK, 4)}
+    if pmc is not None:
+        roof["pmc"] = pmc
+    if traffic is not None:
+        roof["traffic_over_layout"] = round(traffic / Bl, 4)
 
     out = {
         "metric": "Jacobi-GNN sweeps/sec (2D Laplacian, fp64)", "value": round(total_sweeps / elapsed, 2),
@@ -359,7 +458,8 @@ def single_gpu(args, gla, dev):
         "config": {"workload": f"JacobiGNN.forward, {args.sweeps} sweeps/step, 5-pt Laplacian, "
                                f"{Nx}x{Nx} vertices per GPU (global grid {Nx}x{Nx}), fp64, w=0.7",
                    "N": Nx, "rows_per_gpu": pr.n_local, "nnz_per_gpu": pr.nnz, "sweeps_per_step": args.sweeps,
-                   "achieved_GBps_per_gpu_whole_step": round(pr.B * total_sweeps / elapsed / 1e9, 1)},
+                   "bytes_moved_GBps_whole_step": round(moved * launches * args.steps / elapsed / 1e9, 1),
+                   "model_equivalent_GBps_whole_step": round(pr.B * total_sweeps / elapsed / 1e9, 1)},
         "roofline": roof,
     }
     default_layout = not (args.compress or args.no_col16 or args.no_dia)
@@ -407,9 +507,9 @@ def single_gpu(args, gla, dev):
             out["one_sweep_per_pass"] = {
                 "what": "same step with option jacobi_fuse=0: spmv_dia_kernel<double,EpiJacobi>, one launch per sweep",
                 "value": round(total_sweeps / el, 2), "unit": "sweeps/s", "launch_us": round(tl * 1e6, 2),
-                "achieved": round(pr.B / tl / 1e9, 1), "frac": round(pr.B / tl / HBM_PEAK, 4),
-                "layout_bytes_per_launch": Bl, "layout_frac": round(Bl / tl / HBM_PEAK, 4),
-                "bit_identical_to_default": same}
+                "achieved": round(Bl / tl / 1e9, 1), "frac": round(Bl / tl / HBM_PEAK, 4),
+                "bytes_moved_is": "layout bytes of one pass (74 B per row)", "layout_bytes_per_launch": Bl,
+                "pass_model_frac": round(pr.B / tl / HBM_PEAK, 4), "bit_identical_to_default": same}
         finally:
             check(L.gla_set_option(b"jacobi_fuse", 1))
 
@@ -435,8 +535,9 @@ def single_gpu(args, gla, dev):
                 "what": "same step with option dia=0: spmv_stream_vec2_kernel (CSR-adaptive stream tiles, int16 "
                         "tile-relative columns), the kernel non-stencil matrices run on",
                 "value": round(total_sweeps / el, 2), "unit": "sweeps/s", "launch_us": round(tl * 1e6, 2),
-                "achieved": round(pr.B / tl / 1e9, 1), "frac": round(pr.B / tl / HBM_PEAK, 4),
-                "layout_bytes_per_launch": Bl, "layout_frac": round(Bl / tl / HBM_PEAK, 4),
+                "achieved": round(Bl / tl / 1e9, 1), "frac": round(Bl / tl / HBM_PEAK, 4),
+                "bytes_moved_is": "layout bytes of one pass (10 B per nonzero + 2 B per row + the vectors)",
+                "layout_bytes_per_launch": Bl, "pass_model_frac": round(pr.B / tl / HBM_PEAK, 4),
                 "bit_identical_to_default": same}
             del plan_c, ei_c
         finally:
@@ -456,30 +557,36 @@ def single_gpu(args, gla, dev):
         cheb = gla.ChebyGNN.ChebyRelaxGNN(4, return_edge_attr=False)
         el_c, ms_c = timed_steps(lambda: cheb(va, pr.ei, ev, gc), 5, 2)
         Bc = (base + 40 * n * K) + 3 * (base + 48 * n * K)
+        mat = (8 * int(info.dia) + 2) * n if int(info.dia) > 0 else 10 * nnz + 2 * n      # the matrix as this plan stores it
+        Mc = mat + 48 * n * K                                 # the fused pass: b, x in; x, r, p and the module's copy of b out
         del va
         pw = gla.PowerMethodGNN.PowerMethodGNN(10, return_edge_attr=False)
         vp = torch.stack([b16, torch.zeros_like(b16)], 1)
         g3 = torch.zeros(3, K, dtype=torch.float64)
         el_p, ms_p = timed_steps(lambda: pw(vp, pr.ei, pr.edge_attr, g3), 5, 2)
         Bp = 11 * (base + 16 * n * K) + 6 * 8 * n * K
+        Mp = 11 * (mat + 16 * n * K) + 6 * 8 * n * K          # one pass of the matrix + y in / out per iteration, the tail's vectors
         tc, tpw = median(ms_c) * 1e-3, median(ms_p) * 1e-3
         # JacobiGNN on the same 16 right-hand sides (vertex_attr [n, 3, K]): temporally blocked passes of four sweeps
         vj = torch.stack([torch.full_like(b16, -4.0), b16, x16], 1)
         _, ms_j = timed_steps(lambda: jac(args.sweeps, vj, pr.ei, pr.edge_attr, pr.g), 3, 1)
         tj = median(ms_j) * 1e-3 / args.sweeps
         Bj16 = base + 8 * n + 24 * n * K
+        passes16 = max(1, -(-args.sweeps // 4)) if bool(info.dia_canon5) else args.sweeps        # (gla_jacobi_sweeps, K > 1: passes of <= 4)
+        Mj16 = (mat + 8 * n + 24 * n * K) * passes16 / args.sweeps                              # bytes moved per sweep
         del vj
         out["config3_k16"] = {
             "what": f"BASELINE config 3 through the module surface, {Nx}^2 Laplacian, K=16 right-hand sides, fp64",
-            "note": "ChebyRelaxGNN(4) runs as ONE temporally blocked pass (gla_cheby_fused: b, x in; x, r, p out), so "
-                    "SURVEY's per-step byte model reads above the HBM peak (the pass moves b, x in and x, r, p out once: 11.4 GB); the power method needs a global norm "
-                    "between its iterations and stays one fused kernel per iteration",
-            "cheby_deg4_ms": round(tc * 1e3, 3), "cheby_GBps": round(Bc / tc / 1e9, 1),
-            "cheby_frac": round(Bc / tc / HBM_PEAK, 4), "cheby_algorithmic_bytes": Bc,
-            "power_10its_ms": round(tpw * 1e3, 3), "power_GBps": round(Bp / tpw / 1e9, 1),
-            "power_frac": round(Bp / tpw / HBM_PEAK, 4), "power_algorithmic_bytes": Bp,
-            "jacobi_ms_per_sweep": round(tj * 1e3, 4), "jacobi_GBps": round(Bj16 / tj / 1e9, 1),
-            "jacobi_frac": round(Bj16 / tj / HBM_PEAK, 4), "jacobi_algorithmic_bytes_per_sweep": Bj16}
+            "note": "*_frac = bytes the kernels have to move with this plan's layout (matrix once per pass + the K-wide vectors in / "
+                    "out) / time / 8 TB/s; *_model_ratio = SURVEY 8(d)'s per-step byte model / time / 8 TB/s, above 1 where "
+                    "several steps share a pass (ChebyRelaxGNN(4): ONE temporally blocked pass, gla_cheby_fused)",
+            "cheby_deg4_ms": round(tc * 1e3, 3), "cheby_bytes_moved": Mc, "cheby_GBps": round(Mc / tc / 1e9, 1),
+            "cheby_frac": round(Mc / tc / HBM_PEAK, 4), "cheby_model_ratio": round(Bc / tc / HBM_PEAK, 4),
+            "power_10its_ms": round(tpw * 1e3, 3), "power_bytes_moved": Mp, "power_GBps": round(Mp / tpw / 1e9, 1),
+            "power_frac": round(Mp / tpw / HBM_PEAK, 4), "power_model_ratio": round(Bp / tpw / HBM_PEAK, 4),
+            "jacobi_ms_per_sweep": round(tj * 1e3, 4), "jacobi_bytes_moved_per_sweep": int(Mj16),
+            "jacobi_GBps": round(Mj16 / tj / 1e9, 1), "jacobi_frac": round(Mj16 / tj / HBM_PEAK, 4),
+            "jacobi_model_ratio": round(Bj16 / tj / HBM_PEAK, 4)}
         del vp, b16, x16
         torch.cuda.empty_cache()
 
@@ -490,9 +597,12 @@ def single_gpu(args, gla, dev):
             p4 = Problem(gla, 8192, 8192, 0, 8192 * 8192, dev, 24601)
             el4, ms4 = timed_steps(lambda: jac(args.sweeps, p4.vertex_attr, p4.ei, p4.edge_attr, p4.g), 3, 1)
             t4 = median(ms4) * 1e-3 / args.sweeps
+            m4 = (8 * 5 + 2 + 32) * p4.n_local * launches / args.sweeps           # bytes moved per sweep: one pass per launch
             out["config4_1gpu"] = {"what": "JacobiGNN.forward, 20 sweeps, 8192^2 Laplacian fp64 on one GPU",
                                    "value": round(1.0 / t4, 2), "unit": "sweeps/s", "us_per_sweep": round(t4 * 1e6, 1),
-                                   "achieved": round(p4.B / t4 / 1e9, 1), "frac": round(p4.B / t4 / HBM_PEAK, 4)}
+                                   "achieved": round(m4 / t4 / 1e9, 1), "frac": round(m4 / t4 / HBM_PEAK, 4),
+                                   "bytes_moved_is": f"layout bytes: {launches} passes of 74 B per row per {args.sweeps} sweeps",
+                                   "model_ratio": round(p4.B / t4 / HBM_PEAK, 4)}
             del p4
             torch.cuda.empty_cache()
 
@@ -578,10 +688,16 @@ def multi_gpu(args, gla, dev, world, rank):
     elapsed, pr, drv = run_block(Nx, lines, args.steps, args.warmup)
     total_sweeps = args.steps * args.sweeps
     t_sweep = elapsed / total_sweeps
-    roof = {"bound": "hbm", "achieved": round(pr.B / t_sweep / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(pr.B / t_sweep / HBM_PEAK, 4), "traffic": None,
-            "kernel": "per-rank sweep incl. halo exchange (interior + boundary launch)",
-            "algorithmic_bytes_per_launch": pr.B, "avg_launch_us": round(t_sweep * 1e6, 2)}
+    # bytes a rank moves per step: one pass over its block (74 B per row: values, mask, b, A_ii, x in, x out) per launch
+    sched_fn = getattr(drv, "_sched", None)
+    passes = len(sched_fn(args.sweeps)) if sched_fn is not None and drv.mode.startswith("temporally blocked") else args.sweeps
+    moved_sweep = (8 * 5 + 2 + 32) * pr.n_local * passes / args.sweeps
+    roof = {"bound": "hbm", "achieved": round(moved_sweep / t_sweep / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(moved_sweep / t_sweep / HBM_PEAK, 4), "traffic": None,
+            "bytes_moved_is": f"layout bytes per rank: {passes} passes of 74 B per row per {args.sweeps} sweeps",
+            "kernel": "per-rank step incl. halo exchange (interior + boundary launches), per sweep",
+            "passes_per_step": passes, "algorithmic_bytes_per_sweep": pr.B,
+            "model_ratio": round(pr.B / t_sweep / HBM_PEAK, 4), "avg_launch_us": round(t_sweep * 1e6 * args.sweeps / passes, 2)}
     out = {
         "metric": "Jacobi-GNN sweeps/sec (2D Laplacian, fp64)",
         "value": round((1 if args.strong else world) * total_sweeps / elapsed, 2), "unit": "sweeps/s",
@@ -593,8 +709,8 @@ def multi_gpu(args, gla, dev, world, rank):
                                f"halo all-gather ({drv.mode})",
                    "N": Nx, "rows_per_gpu": pr.n_local, "nnz_per_gpu": pr.nnz, "sweeps_per_step": args.sweeps,
                    "backend": args.backend, "exchange": drv.mode,
-                   "aggregate_GBps": round(world * pr.B * total_sweeps / elapsed / 1e9, 1),
-                   "achieved_GBps_per_gpu_whole_step": round(pr.B * total_sweeps / elapsed / 1e9, 1)},
+                   "aggregate_bytes_moved_GBps": round(world * moved_sweep * total_sweeps / elapsed / 1e9, 1),
+                   "aggregate_model_equivalent_GBps": round(world * pr.B * total_sweeps / elapsed / 1e9, 1)},
         "roofline": roof,
     }
     del pr, drv
@@ -612,8 +728,13 @@ def multi_gpu(args, gla, dev, world, rank):
                        f"{G // world} grid lines per GPU, halo all-gather per sweep ({d4.mode})",
                "scaling": "strong", "n_gpus": world, "ranks_seen": ranks_seen, "value": round(1.0 / t4, 2),
                "unit": "sweeps/s", "us_per_sweep": round(t4 * 1e6, 2),
-               "GBps_per_gpu": round(p4.B / t4 / 1e9, 1), "frac_per_gpu": round(p4.B / t4 / HBM_PEAK, 4),
-               "aggregate_GBps": round(B4_global / t4 / 1e9, 1)}
+               "model_equivalent_GBps_per_gpu": round(p4.B / t4 / 1e9, 1), "model_ratio_per_gpu": round(p4.B / t4 / HBM_PEAK, 4),
+               "aggregate_model_equivalent_GBps": round(B4_global / t4 / 1e9, 1)}
+        sf4 = getattr(d4, "_sched", None)
+        ps4 = len(sf4(args.sweeps)) if sf4 is not None and d4.mode.startswith("temporally blocked") else args.sweeps
+        m4 = (8 * 5 + 2 + 32) * p4.n_local * ps4 / args.sweeps
+        rec.update({"bytes_moved_GBps_per_gpu": round(m4 / t4 / 1e9, 1), "frac_per_gpu": round(m4 / t4 / HBM_PEAK, 4),
+                    "passes_per_step": ps4})
         del p4, d4
         torch.cuda.empty_cache()
         t1 = None
