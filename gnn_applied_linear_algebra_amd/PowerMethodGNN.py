@@ -39,21 +39,44 @@ class PowerMethodGNN(torch.nn.Module):
         gd = to_dev(g, dev).to(out_dtype).reshape(3, -1)
         nrm, n_A = gd[0].expand(K).clone(), gd[1].expand(K).clone()
         tail_done, fused_tail_ok = False, False
+        nrm_reported = None
         if self.num_iter > 0:
-            try:
-                y, ss, work = plan.power_step(b)                 # iteration 1: b is used as given
-                fused_tail_ok = True
-                for _ in range(self.num_iter - 1):
-                    y, ss, work = plan.power_step(y, nrm=torch.sqrt(ss), work=work)
-            except _lib.GlaError as e:
-                if "error -5" not in str(e):
-                    raise
-                y = b
-                for it in range(self.num_iter):                  # unfused path, same arithmetic
-                    y = plan.spmm(y if it == 0 else col_scale_rsqrt(y, ss))
-                    ss = col_dot(y, y)
-            nrm_dev = torch.sqrt(ss)
-            nrm = nrm_dev.to(out_dtype)
+            tmax = plan.power_fused_max_iters(K, b.dtype) if self.num_iter >= 2 else 0
+            blocked = False
+            if tmax >= 2:
+                # temporally blocked: ceil(num_iter / tmax) passes of equal size +- 1, each m iterations in ONE pass over the
+                # matrix (gla_power_fused); the norm the reference reports after an iteration is the ratio of two consecutive
+                # levels' norms, the next pass normalises by the absolute norm of the pass' result
+                kp = -(-self.num_iter // tmax)
+                base, rem = divmod(self.num_iter, kp)
+                try:
+                    y, nrm_abs = b, None
+                    for i in range(kp):
+                        m = base + (1 if i < rem else 0)
+                        y, ssl = plan.power_fused(y, m, nrm=nrm_abs)
+                        nrm_abs = torch.sqrt(ssl[1])
+                        nrm_reported = torch.sqrt(ssl[1] / ssl[0]) if m >= 2 else nrm_abs
+                    ss = ssl[1]
+                    blocked = fused_tail_ok = True
+                except _lib.GlaError as e:                           # (operands the K-wide march does not take: step by step)
+                    if "error -5" not in str(e):
+                        raise
+                    nrm_reported = None
+            if not blocked:
+                try:
+                    y, ss, work = plan.power_step(b)                 # iteration 1: b is used as given
+                    fused_tail_ok = True
+                    for _ in range(self.num_iter - 1):
+                        y, ss, work = plan.power_step(y, nrm=torch.sqrt(ss), work=work)
+                except _lib.GlaError as e:
+                    if "error -5" not in str(e):
+                        raise
+                    y = b
+                    for it in range(self.num_iter):                  # unfused path, same arithmetic
+                        y = plan.spmm(y if it == 0 else col_scale_rsqrt(y, ss))
+                        ss = col_dot(y, y)
+            nrm_dev = torch.sqrt(ss)                             # (the absolute norm of y: what the last layer 3 divides by)
+            nrm = (nrm_dev if nrm_reported is None else nrm_reported).to(out_dtype)
             # Layer 3 of the last iteration (b <- b / n), the Rayleigh layers' A b, n_A = sum b (A b), sum b^2 and the
             # module's [b, b^2] result in ONE pass where the plan has the blocked stencil kernel (gla_power_rayleigh)
             if in_place and fused_tail_ok:

@@ -5,24 +5,23 @@ from . import _lib
 from .plan import plan_for
 
 
-_SCALAR0 = {}
-
-
 def scalar0(g):
     """float(g.reshape(-1)[0]) -- the relaxation weight w = g[0] the kernels take by value (JacobiGNN.py:108).  For a GPU
-    tensor that read is a device-to-host copy which drains the stream on every call; the value is remembered per tensor
-    (storage, offset, dtype) and version counter, so a solver loop that passes the same unmodified `g` reads it once
-    (any in-place write to `g` bumps its version and is read again)."""
+    tensor that read is a device-to-host copy which drains the stream on every call; the value is remembered ON the tensor
+    object (attribute `_gla_scalar0`, keyed on its storage pointer, offset, dtype and in-place version counter), so a solver
+    loop that passes the same unmodified `g` reads it once.  The cache lives and dies with the tensor: a fresh tensor -- even
+    one the allocator places at a recycled address, with version 0 again -- never sees another tensor's value."""
     if not g.is_cuda:
         return float(g.reshape(-1)[0])
-    key = (g.device.index, g.untyped_storage().data_ptr(), g.storage_offset(), g.dtype)
-    hit = _SCALAR0.get(key)
-    if hit is not None and hit[0] == g._version:
+    key = (g.untyped_storage().data_ptr(), g.storage_offset(), g.dtype, g._version)
+    hit = getattr(g, "_gla_scalar0", None)
+    if hit is not None and hit[0] == key:
         return hit[1]
     val = float(g.reshape(-1)[0])
-    if len(_SCALAR0) > 64:
-        _SCALAR0.clear()
-    _SCALAR0[key] = (g._version, val)
+    try:
+        g._gla_scalar0 = (key, val)
+    except Exception:                                # (a tensor subclass that refuses attributes: read every time)
+        pass
     return val
 
 

@@ -69,6 +69,9 @@ SIGNATURES = {
     "gla_col_dot": (_I, [_I, _I64, _I, _P, _I64, _P, _I64, _P, _P, _P]),
     "gla_col_scale_rsqrt": (_I, [_I, _I64, _I, _P, _I64, _P, _P, _I64, _P]),
     "gla_power_work_bytes": (_I64, [_P, _I, _I]),
+    "gla_power_fused_max_iters": (_I, [_P, _I, _I]),
+    "gla_power_fused_work_bytes": (_I64, [_P, _I, _I, _I]),
+    "gla_power_fused": (_I, [_P, _I, _I, _P, _I64, _P, _P, _I64, _P, _P, _I, _P]),
     "gla_power_step": (_I, [_P, _I, _I, _P, _I64, _P, _P, _P, _I64, _P, _P, _I, _P]),
     "gla_segment_reduce": (_I, [_P, _I, _I, _P, _I64, _I, _P, _I64, _P]),
     "gla_segment_stats": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P]),

@@ -1914,7 +1914,15 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
   jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && diag && B && X0, n_iters, plan);
   // K right-hand sides on canonical 5- / 9-point plans: passes of up to GLA_JACOBIK_TS_MAX sweeps (jacobi_marchk_kernel,
   // gla_jacobik.hip), ceil(n / 4) (9-point: n / 3) passes of equal size +- 1; anything it declines keeps one sweep per launch
-  if (K > 1 && n_iters >= 2 && g_tuning.jacobi_fuse == 1 && diag && B && X0 && A->val_dtype == dtype &&
+  if (K > 1 && n_iters >= 2) {
+    // the operand checks of gla_jacobi_sweep, BEFORE any pass writes: the K-wide route below does not go through it
+    const int rc0 = check_plan(A, dtype, K);
+    if (rc0) return rc0;
+    if (A->n_rows > 0 && (!diag || !B || !X0 || X0 == Xout || X0 == Xtmp || ldb < K || ldx0 < K || ldw < K)) return GLA_ERR_INVALID_ARG;
+  }
+  const int vw_k = dtype == GLA_F64 ? 2 : 4;        // 16-byte rhs vectors: both ping-pong buffers must take them, or no pass may start
+  if (K > 1 && n_iters >= 2 && g_tuning.jacobi_fuse == 1 && diag && B && X0 && A->val_dtype == dtype && A->n_rows > 0 &&
+      al16(Xout) && al16(Xtmp) && ldw % vw_k == 0 &&
       A->n_rows * (int64_t)K >= g_tuning.jacobi_min_rows && (gla_dia_canon5(A) || gla_dia_canon9(A))) {
     const int tmax = gla_dia_canon5(A) ? GLA_JACOBIK_TS_MAX : GLA_JACOBIK_TS_MAX - 1;      // (9-point: three sweeps per pass)
     const int k = (n_iters + tmax - 1) / tmax, base = n_iters / k, r = n_iters % k;       // base >= 2 for n_iters >= 2
@@ -1927,7 +1935,7 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
       const int ts = i <= r ? base + 1 : base;
       if (ts >= 2) {
         rc = gla_jacobik_pass(A, dtype, K, diag, B, ldb, src, lsrc, dst, ldw, w, ts, (hipStream_t)stream);
-        if (rc == GLA_ERR_UNSUPPORTED && i == 1) { declined = true; break; }
+        if (rc == GLA_ERR_UNSUPPORTED && i == 1) { declined = true; break; }      // (later passes cannot decline: same plan, buffers checked above)
       } else {
         rc = gla_jacobi_sweep(A, dtype, K, diag, B, ldb, src, lsrc, dst, ldw, w, 0, stream);
       }

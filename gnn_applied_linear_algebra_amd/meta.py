@@ -17,8 +17,7 @@ class MetaLayer(torch.nn.Module):
         self.global_model = global_model
 
     def _fused(self):
-        tags = tuple(getattr(m, "gla_block", None) if m is not None else None
-                     for m in (self.edge_model, self.node_model, self.global_model))
+        tags = tuple(_stock_tag(m) for m in (self.edge_model, self.node_model, self.global_model))
         return _FUSED.get(tags)
 
     def forward(self, x, edge_index, edge_attr=None, u=None, batch=None):
@@ -26,6 +25,21 @@ class MetaLayer(torch.nn.Module):
         if fused is not None:
             return fused(self, x, edge_index, edge_attr, u, batch)
         return generic_forward(self, x, edge_index, edge_attr, u, batch)
+
+
+def _stock_tag(m):
+    """The `gla_block` tag of a model whose `forward` IS the stock one.  The tag is a class attribute, so a user subclass of
+    e.g. JacobiGNN.EdgeUpdate inherits it; if that subclass overrides `forward` (or the instance carries its own), the layer
+    is no longer the reference's block and must run the generic gather / callback sequence, not the fused kernel."""
+    if m is None:
+        return None
+    tag = getattr(m, "gla_block", None)
+    if tag is None:
+        return None
+    stock = next((c for c in type(m).__mro__ if "gla_block" in c.__dict__), None)
+    if stock is None or type(m).forward is not stock.forward or "forward" in getattr(m, "__dict__", {}):
+        return None
+    return tag
 
 
 def generic_forward(layer, x, edge_index, edge_attr=None, u=None, batch=None):

@@ -397,6 +397,33 @@ class CsrPlan:
                                    ptr(work), which, stream_ptr(self.device)))
         return Y, sumsq, work
 
+    def power_fused_max_iters(self, K, dtype):
+        """Power iterations gla_power_fused takes per pass on this plan with K right-hand sides (0: use power_step)."""
+        if self.val_dtype != dtype:
+            return 0
+        return int(lib().gla_power_fused_max_iters(self._h, dtype_code(dtype), int(K)))
+
+    @_on_device
+    def power_fused(self, X, iters, nrm=None, out=None):
+        """`iters` power iterations in ONE pass (gla_power_fused): Y = A^iters (X ./ nrm) and the sums of squares of the last two
+        levels, sumsq [2, K]: sumsq[0] = sum_i (A^(iters-1) (X ./ nrm))[i]^2, sumsq[1] = sum_i Y[i]^2.  X and Y must not alias."""
+        X, K, ldx = _dense(X, self.n_cols, "X")
+        self._need(X.dtype)
+        code = dtype_code(X.dtype)
+        Y = torch.empty((self.n_rows, K), dtype=X.dtype, device=self.device) if out is None else out
+        Y, Ky, ldy = _dense(Y, self.n_rows, "Y")
+        assert Ky == K and Y.dtype == X.dtype
+        if nrm is not None:
+            assert nrm.numel() == K and nrm.dtype == X.dtype and nrm.is_cuda and nrm.is_contiguous()
+        nbytes = int(lib().gla_power_fused_work_bytes(self._h, code, K, int(iters)))
+        if nbytes <= 0:
+            raise _lib.GlaError("gla_power_fused: no kernel for this plan / K / iteration count (error -5)")
+        work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        sumsq = torch.empty((2, K), dtype=X.dtype, device=self.device)
+        check(lib().gla_power_fused(self._h, code, K, ptr(X), ldx, ptr(nrm), ptr(Y), ldy, ptr(sumsq), ptr(work), int(iters),
+                                    stream_ptr(self.device)))
+        return Y, sumsq
+
     @_on_device
     def power_rayleigh(self, Y, nrm, Bout, B2out):
         """The tail of the power method in one pass (gla_power_rayleigh): Bout = Y ./ nrm, B2out = Bout^2; returns
@@ -564,7 +591,7 @@ def invalidate(*tensors):
         cached_copy = getattr(t, "_gla_dev_copy", None)
         if cached_copy is not None:
             invalidate(cached_copy[1])
-        for attr in ("_gla_plan", "_gla_dev_copy", "_gla_gnn_input"):
+        for attr in ("_gla_plan", "_gla_dev_copy", "_gla_gnn_input", "_gla_scalar0"):
             if hasattr(t, attr):
                 try:
                     delattr(t, attr)
@@ -576,15 +603,6 @@ def invalidate(*tensors):
             _PLANS_WITH_VALUES.discard(ref)
         elif plan._val_ref is not None and any(plan._val_ref() is t for t in tensors):
             plan._val_key = plan._val_ref = None
-    _SCALAR_CACHES_CLEAR()
-
-
-def _SCALAR_CACHES_CLEAR():
-    """(the remembered relaxation weights g[0] of GPU-resident `g` tensors, _common.scalar0)"""
-    import sys
-    mod = sys.modules.get(__package__ + "._common")
-    if mod is not None:
-        mod._SCALAR0.clear()
 
 
 _PLANS_WITH_VALUES = set()

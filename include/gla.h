@@ -268,6 +268,20 @@ int gla_power_rayleigh(gla_csr_t A, int dtype, int K, const void* Y, int64_t ldy
                        void* Bout, int64_t ldb, void* B2out, int64_t ldb2, void* nA_out, void* bb_out, void* work,
                        gla_stream_t stream);
 
+/* Temporally blocked power iteration (PowerMethodGNN.py:296-334, the iteration block x `iters`): A is linear, so `iters`
+ * iterations started from a normalised vector are ONE pass of the K-wide march with the intermediate norms as by-products:
+ * Y = A^iters (X ./ nrm_in) (nrm_in == NULL: X as given; the quotient is the IEEE one, as gla_power_step),
+ * sumsq_out[k] = sum_i (A^(iters-1) (X ./ nrm_in))[i,k]^2 and sumsq_out[K + k] = sum_i Y[i,k]^2: the sums of the last two
+ * levels.  The norm the reference reports after the last iteration is sqrt(sumsq[K + k] / sumsq[k]) (iters == 1: the operand
+ * is the normalised vector itself, sqrt(sumsq[K + k])); the next pass divides by sqrt(sumsq[K + k]).  Iterates agree with gla_power_step to rounding (the reference rounds after every division, this
+ * path after every pass).  Canonical 5-point plans: iters <= 5, 9-point: <= 3 (gla_power_fused_max_iters; 0: no kernel for this
+ * plan / K -- K = 1 or a multiple of the 16-byte vector up to 8 vectors).  X and Y must not alias.  work:
+ * gla_power_fused_work_bytes(A, dtype, K, iters). */
+int gla_power_fused_max_iters(gla_csr_t A, int dtype, int K);
+int64_t gla_power_fused_work_bytes(gla_csr_t A, int dtype, int K, int iters);
+int gla_power_fused(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, const void* nrm_in, void* Y, int64_t ldy,
+                    void* sumsq_out, void* work, int iters, gla_stream_t stream);
+
 /* The aggregation primitive on its own: out[i,k] = reduce over the edges e with row(e) = i of src[e,k], src in EDGE
  * order [nnz, K].  op: 0 sum (edge order, = the reference's sequential scatter-add), 1 max, 2 min, 3 mean; rows
  * without edges give 0.  torch_scatter.scatter(src, edgeij_pair[0], dim=0, dim_size=n, reduce=...), e.g.

@@ -1916,3 +1916,127 @@ def test_bench_line_contract():
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["schedule"] == [7, 7, 6] and roof["kernel"].startswith("jacobi_march5_kernel")
     assert d_["value"] > 0 and abs(d_["value"] - 20 * 2 / (d_["ms_per_step"] * 2e-3)) / d_["value"] < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 3: the drop-in boundary fuses only what IS the reference's block; g[0] is never served from another tensor
+# ---------------------------------------------------------------------------------------------------
+def test_metalayer_subclass_overriding_forward_takes_generic_path(golden):
+    """A user subclass of a stock update module inherits its `gla_block` tag; if it overrides `forward`, the layer is not the
+    reference's block any more: MetaLayer must run the generic gather / callback sequence (PyG semantics, as the oracle's
+    MetaLayer does), not the fused kernel."""
+    N = 8
+    ei, ev = lap(golden, N)
+    n = N * N
+    b, x = t(golden[f"N{N}_b"]), t(golden[f"N{N}_x"])
+    J = gla.JacobiGNN
+
+    class HalfEdge(J.EdgeUpdate):                     # c_ij = 0.5 A_ij x_j instead of A_ij x_j
+        def forward(self, vattr_i, vattr_j, edge_attr, g, batch):
+            A = edge_attr[:, 0:1]
+            return torch.cat([A, 0.5 * A * vattr_j[:, 2:3]], 1)
+
+    class Untouched(J.EdgeUpdate):                    # a subclass that changes nothing stays fused
+        pass
+
+    va0 = torch.cat([-4 * torch.ones((n, 1), dtype=torch.float64), b, x], 1)
+    ea0 = torch.cat([ev, torch.zeros_like(ev)], 1)
+    g = torch.tensor([0.7], dtype=torch.float64)
+    layer = gla.MetaLayer(HalfEdge(), J.VertexUpdate(J.edge_to_vertex_aggregation))
+    assert layer._fused() is None
+    assert gla.MetaLayer(Untouched(), J.VertexUpdate(J.edge_to_vertex_aggregation))._fused() is not None
+    patched = J.EdgeUpdate()
+    patched.forward = lambda *a: HalfEdge.forward(patched, *a)          # an instance-level override counts too
+    assert gla.MetaLayer(patched, J.VertexUpdate(J.edge_to_vertex_aggregation))._fused() is None
+    va, ea, _ = layer(d(va0), d(ei), d(ea0), g, batch=None)
+    # the same layer through the oracle's MetaLayer (PyG semantics on the CPU)
+    c = 0.5 * ev[:, 0] * x[ei[1], 0]
+    cbar = torch.zeros(n, dtype=torch.float64).index_add_(0, ei[0], c)
+    want_x = x[:, 0] + 0.7 * (b[:, 0] - cbar) / -4.0
+    eq(ea[:, 1], c)
+    eq(va[:, 2], want_x)
+    # and the stock wiring still gives the reference's sweep (fused)
+    va, _, _ = gla.MetaLayer(J.EdgeUpdate(), J.VertexUpdate(J.edge_to_vertex_aggregation))(d(va0), d(ei), d(ea0), g, batch=None)
+    eq(va, golden[f"N{N}_jacobi_iterate_va"])
+
+
+def test_relaxation_weight_not_served_from_a_recycled_address():
+    """scalar0() remembers g[0] of a GPU-resident g ON the tensor object.  Fresh tensors of different values, each freed before
+    the next is allocated (the caching allocator hands the same address out again, version counter 0 again), must each be
+    read for themselves."""
+    from gnn_applied_linear_algebra_amd._common import scalar0
+    N = 16
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    n = N * N
+    gen = torch.Generator().manual_seed(3)
+    b, x = torch.rand(n, 1, generator=gen, dtype=torch.float64), torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    va = torch.cat([-4 * torch.ones(n, 1, dtype=torch.float64), b, x], 1)
+    ea = torch.cat([ev.cpu(), torch.zeros(ev.shape[0], 1, dtype=torch.float64)], 1)
+    jac = gla.JacobiGNN.JacobiGNN()
+    seen = set()
+    for w in (0.7, 0.5, 0.9, 0.25, 0.6):
+        g = torch.tensor([w], dtype=torch.float64, device=DEV)
+        seen.add(g.data_ptr())
+        assert scalar0(g) == w
+        got = jac(3, d(va), ei, d(ea), g)
+        want = rp.jacobi_forward(3, va, ei.cpu(), ea, torch.tensor([w], dtype=torch.float64))
+        eq(got, want)
+        del g, got
+    g = torch.tensor([0.7], dtype=torch.float64, device=DEV)
+    assert scalar0(g) == 0.7
+    g.fill_(0.3)                                       # in-place write: version counter moves, value is read again
+    assert scalar0(g) == 0.3
+    assert len(seen) < 5 or True                       # (addresses usually repeat; the test does not depend on it)
+
+
+def test_power_fused_pass_matches_step_by_step():
+    """gla_power_fused (m power iterations in one temporally blocked pass, the level norms as by-products) against the
+    step-by-step kernels: Y = A^m (X ./ n) and every level's sum of squares to rounding; 5- and 9-point plans, K = 1 ... 16,
+    fp64 / fp32, every pass size, grids with ragged sizes; then the module (10 iterations = 5 + 5) against the oracle loop."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd.plan import col_dot
+    gen = torch.Generator().manual_seed(91)
+    for name, ei, ev, n, tmax in (("laplacian 301 x 77", *rp.laplacianfun_torch(301, 77), 301 * 77, 5),
+                                  ("fem 9-point 70 x 58", *rp.heateqnfem2dfun([71, 59], [1.0, 4.0]), 70 * 58, 3)):
+        for dtype in (torch.float64, torch.float32):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            tol = 1e-12 if dtype == torch.float64 else 3e-5
+            for K in (1, 2, 4, 8, 16):
+                if dtype == torch.float32 and K in (2,):
+                    assert plan.power_fused_max_iters(K, dtype) == 0      # (a 16-byte vector is four floats)
+                    continue
+                assert plan.power_fused_max_iters(K, dtype) == tmax, (name, dtype, K)
+                x = d((torch.rand(n, K, generator=gen, dtype=torch.float64) - 0.3).to(dtype))
+                nrm = torch.sqrt(col_dot(x, x))
+                for m in range(1, tmax + 1):
+                    for use_nrm in (False, True):
+                        y, ss = plan.power_fused(x, m, nrm=nrm if use_nrm else None)
+                        ref = x / nrm if use_nrm else x
+                        for j in range(m):
+                            prev, ref = ref, plan.spmm(ref)
+                        assert torch.allclose(ss[1], col_dot(ref, ref), rtol=tol * 10, atol=0), (name, dtype, K, m, use_nrm)
+                        assert torch.allclose(ss[0], col_dot(prev, prev), rtol=tol * 10, atol=0), (name, dtype, K, m, use_nrm)
+                        scale = float(ref.abs().max())
+                        assert float((y - ref).abs().max()) <= tol * 50 * scale, (name, dtype, K, m, use_nrm)
+    # the module: K = 1 (the reference's own call) and K = 16, 10 iterations, against the oracle's explicit loop
+    N = 200
+    ei, ev = rp.laplacianfun_torch(N)
+    n = N * N
+    for K in (1, 16):
+        B = torch.rand(n, K, generator=gen, dtype=torch.float64)
+        ea2 = torch.cat([ev, torch.zeros_like(ev)], 1)
+        if K == 1:
+            va, _, g = gla.PowerMethodGNN.PowerMethodGNN(10, return_edge_attr=False)(
+                d(torch.cat([B, torch.zeros_like(B)], 1)), d(ei), d(ea2), torch.zeros(3, dtype=torch.float64), None)
+            want_va, _, want_g = rp.power_forward(10, torch.cat([B, torch.zeros_like(B)], 1), ei, ea2, torch.zeros(3, dtype=torch.float64))
+            close(g, want_g, rtol=1e-11)
+            np.testing.assert_allclose(va.cpu().numpy(), want_va.numpy(), rtol=1e-9, atol=1e-14)
+        else:
+            va, _, g = gla.PowerMethodGNN.PowerMethodGNN(10, return_edge_attr=False)(
+                d(torch.stack([B, torch.zeros_like(B)], 1)), d(ei), d(ea2), torch.zeros(3, K, dtype=torch.float64), None)
+            for k in (0, 7, 15):
+                bk = B[:, k:k + 1]
+                want_va, _, want_g = rp.power_forward(10, torch.cat([bk, torch.zeros_like(bk)], 1), ei, ea2, torch.zeros(3, dtype=torch.float64))
+                close(g[:, k], want_g, rtol=1e-11)
+                np.testing.assert_allclose(va[:, 0, k].cpu().numpy(), want_va[:, 0].numpy(), rtol=1e-9, atol=1e-14)
