@@ -22,12 +22,14 @@ struct TileMap {
   int tiles_per_xcd;
   int xcd_chunk;              // see map_tile
   int lds_cap = 0x7fffffff;   // tiles with more nonzeros than this are single long rows (CSR-adaptive "long" bin)
+  int vec = 0;                // CSR-adaptive "vector" bin: tiles whose rows average >= 32 nonzeros sum a row with 2 .. 64 lanes (option row_sum)
 };
 
 // grid = 8 * tiles_per_xcd workgroups; with chunking the per-XCD count is rounded up to whole chunks so that the
 // slot formula of map_tile is a bijection onto [0, 8 * tiles_per_xcd) (slots >= n_tiles exit at once)
 inline void set_tile_mapping(TileMap& tm) {
   tm.xcd_chunk = g_tuning.xcd_chunk;
+  tm.vec = g_tuning.row_sum;
   const int C = tm.xcd_chunk > 0 ? tm.xcd_chunk : 1;
   const int per_round = GLA_XCDS * C;
   tm.tiles_per_xcd = ((tm.n_tiles + per_round - 1) / per_round) * C;

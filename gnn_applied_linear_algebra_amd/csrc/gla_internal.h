@@ -70,6 +70,9 @@ struct gla_tuning {
   int xcd_chunk = 64;       // consecutive tiles per XCD turn (1 = identity mapping, 0 = one contiguous span per XCD)
   int col16 = 1;            // K = 1 kernels read int16 tile-relative columns when the plan could build them
   int compress = 0;         // 1: gla_csr_set_values also builds the packed stream when the matrix allows it
+  int row_sum = 1;          // K = 1 CSR stream kernel, tiles whose rows average 32 .. 3072 nonzeros: 1 = a row is summed
+                            // by 2 .. 64 lanes (contiguous chunks in edge order + a fixed xor tree: deterministic, agrees with the
+                            // in-order sum to rounding); 0 = one lane per row strictly in edge order (bit-identical to the CPU scatter-add)
   int dia = 1;              // stencil matrices (<= 16 diagonals): K = 1 kernels use the diagonal layout
   int jacobi_fuse = 1;      // gla_jacobi_sweeps on 2-D stencil plans: 0 one sweep per pass, 1 several (temporal blocking; gla_jacobi_sweeps_schedule), 2 up to two
   int jacobi_lines = 0;     // grid lines a workgroup of the fused kernel marches through (0 = one resident round of workgroups)

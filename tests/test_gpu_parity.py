@@ -351,12 +351,23 @@ def test_ragged_unsorted_and_long_rows():
     va_w, ea_w, _ = rp.matvec_layer(X, ei, ev)
     eq(va, va_w)
     eq(ea, ea_w)
-    # dense 100 x 100 weight matrix (MatrixWeightedNorm.py demo): 100 nnz per row, still the in-order path
+    # dense 100 x 100 weight matrix (MatrixWeightedNorm.py demo): 100 nnz per row -- the CSR-adaptive VECTOR bin (rows averaging
+    # 32 nonzeros or more: 2 .. 64 lanes per row, chunked sums + a fixed xor tree): agrees with the in-order sum to rounding;
+    # option row_sum = 0 keeps one lane per row and is bit-exact
     W = torch.rand(100, 100, generator=gen, dtype=torch.float64)
     ei_w = torch.stack([torch.arange(100).repeat_interleave(100), torch.arange(100).repeat(100)])
     x = torch.rand(100, 1, generator=gen, dtype=torch.float64)
+    want_w = rp.matvec_layer(x, ei_w, W.reshape(-1, 1))[0]
     va, _, _ = gnn(d(x), d(ei_w), d(W.reshape(-1, 1)), None)
-    eq(va, rp.matvec_layer(x, ei_w, W.reshape(-1, 1))[0])
+    close(va, want_w, rtol=1e-13)
+    va_again, _, _ = gnn(d(x), d(ei_w), d(W.reshape(-1, 1)), None)
+    eq(va_again, va)                                                # deterministic
+    gla._lib.check(gla._lib.lib().gla_set_option(b"row_sum", 0))
+    try:
+        va, _, _ = gnn(d(x), d(ei_w), d(W.reshape(-1, 1)), None)
+        eq(va, want_w)
+    finally:
+        gla._lib.check(gla._lib.lib().gla_set_option(b"row_sum", 1))
     # one row of 6000 nnz goes to the CSR-adaptive long bin (whole-workgroup chunked sum: tolerance for THAT row); every
     # other row keeps its in-order sum and stays bit-exact
     rows = torch.cat([torch.full((6000,), 5), torch.arange(50)])
@@ -1738,9 +1749,18 @@ def test_random_graphs_property():
         B = (torch.rand(n_rows, K, generator=gen, dtype=torch.float64) - 0.5).to(dtype)
         want = rp.scatter_sum(vals * X[col], row, n_rows)
         chk(lib().gla_set_option(b"compress", 1 if compress else 0))
+        chk(lib().gla_set_option(b"row_sum", 0))                      # strictly in-order row sums: bit-exact for ANY graph
         try:
             plan = gla.CsrPlan(d(ei), n_rows, n_cols)
             plan.set_values(d(vals))
+            # default (row_sum = 1): tiles whose rows average >= 32 nonzeros use the vector bin -- to rounding, deterministic
+            chk(lib().gla_set_option(b"row_sum", 1))
+            y_vec = plan.spmm(d(X))
+            assert torch.equal(y_vec, plan.spmm(d(X)))
+            scale = rp.scatter_sum((vals * X[col]).abs(), row, n_rows)
+            np.testing.assert_allclose(y_vec.cpu().double().numpy(), want.double().numpy(), rtol=0,
+                                       atol=float(scale.max()) * (2e-6 if f32 else 4e-15) + 1e-300)
+            chk(lib().gla_set_option(b"row_sum", 0))
             eq(plan.spmm(d(X)), want)
             eq(plan.residual(d(B), d(X)), B - want)
             eq(plan.edge_products(d(X)), vals * X[col])
@@ -1753,6 +1773,7 @@ def test_random_graphs_property():
                                        atol=(2e-6 if f32 else 1e-15) * K)
         finally:
             chk(lib().gla_set_option(b"compress", 0))
+            chk(lib().gla_set_option(b"row_sum", 1))
 
     check()
 
