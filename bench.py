@@ -643,9 +643,132 @@ def single_gpu(args, gla, dev):
         except Exception as exc:                             # (a side record only: e.g. no RCCL library on the box)
             out["dist_route_one_gpu"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
+    # ---- side: BASELINE config 5 (AMG V-cycle on the heateqnfem2dfun Q1 mesh, 4095^2 = 16.8 M unknowns) on this GPU ----------
+    if side and args.n == 4096:
+        try:
+            out["config5_vcycle"] = side_config5(gla, dev, 4095)
+        except Exception as exc:
+            out["config5_vcycle"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        torch.cuda.empty_cache()
+        # ---- side: non-stencil matrices through the CSR-adaptive kernels (stream / vector / long bins) ----------------------
+        try:
+            out["csr_irregular"] = side_irregular(gla, dev)
+        except Exception as exc:
+            out["csr_irregular"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        torch.cuda.empty_cache()
+
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.n, args.cpu_sweeps)
     emit(out)
+
+
+def _median_us(fn, reps=10, warm=2):
+    import torch
+    ts = []
+    for i in range(reps + warm):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        if i >= warm:
+            ts.append(e0.elapsed_time(e1) * 1e3)
+    return median(ts)
+
+
+def side_config5(gla, dev, m):
+    """BASELINE config 5 on one GPU: V(3,3) cycles of AMGHierarchy on the m x m Q1 FEM mesh of heateqnfem2dfun (grid
+    coarsening): (a) 8 levels with a dense coarsest solve, (b) BASELINE's 3-level shape with a Chebyshev coarsest solve that
+    converges (degree 768 on the 1024^2 level; the degree-4 one the reference's two-grid script uses does not reduce the
+    residual on a level this large).  Setup time, ms per cycle, residual reduction per cycle."""
+    import torch
+    ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 1.0], device=dev)
+    n = m * m
+    A = gla.VCycle._as_sparse(ei, ev, (n, n))
+    gen = torch.Generator().manual_seed(0)
+    b = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
+    rec = {"what": f"AMGHierarchy V(3,3) cycle, Q1 FEM mesh {m}^2 = {n} unknowns, {ei.shape[1]} nonzeros, fp64, grid coarsening"}
+    for key, kw, ncyc in (("levels8_dense_coarsest", dict(levels=8, coarse_solver="dense"), 6),
+                          ("levels3_cheby768_coarsest", dict(levels=3, coarse_solver="cheby", coarse_deg=768), 4)):
+        def build():
+            return gla.VCycle.AMGHierarchy(A, splitting=gla.VCycle.GridSplitting(m, m), min_coarse=500, **kw)
+        H = build()                                          # (first build pays the first touch of every large allocation)
+        torch.cuda.synchronize()
+        del H
+        t0 = time.perf_counter()
+        H = build()
+        torch.cuda.synchronize()
+        setup_ms = 1e3 * (time.perf_counter() - t0)
+        x = torch.zeros_like(b)
+        hist = [float(torch.norm(H.residual(b, x)))]
+        for _ in range(ncyc):
+            x = H.cycle(b, x)
+            hist.append(float(torch.norm(H.residual(b, x))))
+        xs = [x]
+
+        def one():
+            xs[0] = H.cycle(b, xs[0])
+        t_us = _median_us(one, reps=5, warm=1)
+        rates = [hist[i + 1] / hist[i] for i in range(len(hist) - 1)]
+        rec[key] = {"levels": len(H.A), "level_rows": [int(Al.shape[0]) for Al in H.A], "setup_ms": round(setup_ms, 1),
+                    "ms_per_cycle": round(t_us * 1e-3, 3), "residual_history": [float(f"{h:.4e}") for h in hist],
+                    "residual_reduction_per_cycle": [round(r, 4) for r in rates]}
+        del H, x, xs
+        torch.cuda.empty_cache()
+    return rec
+
+
+def side_irregular(gla, dev):
+    """SpMV and one Jacobi sweep on matrices that are NOT stencils (the CSR-adaptive kernels: stream tiles, the vector bin for
+    tiles whose rows average >= 32 nonzeros, the long bin): us per launch, GB/s and fraction of 8 TB/s on SURVEY 8(d)'s bytes
+    (12 nnz + 4 (n + 1) + 16 n / + 32 n; the x gather counted once)."""
+    import torch
+
+    def measure(name, ei, ev, n):
+        nnz = ei.shape[1]
+        plan = gla.CsrPlan(ei, n)
+        plan.set_values(ev)
+        gen = torch.Generator().manual_seed(5)
+        x = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
+        bb = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
+        dg = (torch.rand(n, generator=gen, dtype=torch.float64) + 1.0).to(dev)
+        y, xo = torch.empty_like(x), torch.empty_like(x)
+        t_mv = _median_us(lambda: plan.spmm(x, out=y))
+        t_j = _median_us(lambda: plan.jacobi_sweep(dg, bb, x, xo, 0.7))
+        B_mv, B_j = 12 * nnz + 4 * (n + 1) + 16 * n, 12 * nnz + 4 * (n + 1) + 32 * n
+        lens = torch.bincount(ei[0], minlength=n)
+        return {"matrix": name, "rows": n, "nnz": nnz, "avg_row": round(nnz / n, 2), "max_row": int(lens.max()),
+                "spmv_us": round(t_mv, 1), "spmv_GBps": round(B_mv / t_mv / 1e3, 1), "spmv_frac": round(B_mv / (t_mv * 1e-6) / HBM_PEAK, 4),
+                "jacobi_us": round(t_j, 1), "jacobi_GBps": round(B_j / t_j / 1e3, 1), "jacobi_frac": round(B_j / (t_j * 1e-6) / HBM_PEAK, 4)}
+
+    recs = []
+    m = 4095
+    ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 1.0], device=dev)
+    A = gla.VCycle._as_sparse(ei, ev, (m * m, m * m))
+    H = gla.VCycle.AMGHierarchy(A, levels=3, splitting="pmis", min_coarse=500, coarse_deg=4)
+    for lv in (1, 2):
+        eil, eal = gla.UtilsGNN.coo_to_gnn_input(H.A[lv])
+        recs.append(measure(f"level-{lv} Galerkin operator of the {m}^2 Q1 FEM mesh under pmis_splitting", eil, eal, H.A[lv].shape[0]))
+    del H, A, ei, ev
+    torch.cuda.empty_cache()
+    gen = torch.Generator().manual_seed(11)
+    n = 1_000_000
+    u = torch.rand(n, generator=gen, dtype=torch.float64)
+    lens = (3 * (1 - u) ** (-1.0 / 1.2)).clamp(max=3000).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(n), lens)
+    evp = torch.rand(rows.numel(), 1, generator=gen, dtype=torch.float64) - 0.5
+    for label, cols in (("random columns (the x gather is L2 / Infinity-Cache traffic, not in the byte model)",
+                         torch.randint(0, n, (rows.numel(),), generator=gen)),
+                        ("columns within +-4096 of the row",
+                         (rows + torch.randint(-4096, 4097, (rows.numel(),), generator=gen)).clamp(0, n - 1))):
+        recs.append(measure(f"1 M rows, power-law row lengths 3 .. 3000 (alpha 2.2), {label}", torch.stack([rows, cols]).to(dev), evp.to(dev), n))
+    n = 200_000
+    lens = torch.randint(64, 1025, (n,), generator=gen)
+    rows = torch.repeat_interleave(torch.arange(n), lens)
+    cols = (rows + torch.randint(-4096, 4097, (rows.numel(),), generator=gen)).clamp(0, n - 1)
+    evm = torch.rand(rows.numel(), 1, generator=gen, dtype=torch.float64) - 0.5
+    recs.append(measure("200 k rows of 64 .. 1024 nonzeros (vector bin), columns within +-4096 of the row", torch.stack([rows, cols]).to(dev), evm.to(dev), n))
+    return {"what": "non-stencil matrices through the CSR-adaptive K = 1 kernels (row_sum = 1: vector bin on)", "matrices": recs}
 
 
 def multi_gpu(args, gla, dev, world, rank):

@@ -84,44 +84,65 @@ def _use_lib_comm(group, device, host_loop):
         return True
     return dist.get_backend(group) == "nccl"
 
+def _gather_var(t, group):
+    """All-gather of a tensor whose FIRST dimension differs from rank to rank, by tensor collectives (a count exchange, then one
+    padded all_gather_into_tensor) -- no pickling, no host round trip on RCCL groups.  Returns the list of every rank's tensor
+    (on t's device).  gloo groups with GPU tensors (the one-GPU rehearsals) stage through host memory."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":                   # RCCL moves device memory
+        cdev = t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    else:
+        cdev = torch.device("cpu")
+    cnt = torch.tensor([t.shape[0]], dtype=torch.int64, device=cdev)
+    cnts = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    cnts = [int(c) for c in cnts.tolist()]
+    m = max(cnts + [1])
+    tail = tuple(t.shape[1:])
+    send = torch.zeros((m,) + tail, dtype=t.dtype, device=cdev)
+    send[:t.shape[0]] = t.to(cdev)
+    recv = torch.empty((world * m,) + tail, dtype=t.dtype, device=cdev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return [recv[q * m:q * m + cnts[q]].to(t.device) for q in range(world)]
+
+
 def _publish_rows(ei, ev, row_lo, row_hi, wanted_by_rank, group):
-    """Sparse-row exchange (setup only, object collectives): `wanted_by_rank[q]` = sorted global row ids rank q asks
-    for.  Every rank publishes those of its rows [row_lo, row_hi) that anyone wants; returns the (edge_index, values)
-    of all published rows of OTHER ranks that this rank asked for (CPU -> caller's device), row-sorted."""
+    """Sparse-row exchange (setup only): `wanted_by_rank[q]` = sorted global row ids rank q asks for.  Every rank publishes
+    those of its rows [row_lo, row_hi) that anyone wants (tensor collectives, _gather_var); returns the (edge_index, values)
+    of all published rows of OTHER ranks that this rank asked for, row-sorted, on ei's device."""
     rank = dist.get_rank(group)
     dev = ei.device
     mine = [w[(w >= row_lo) & (w < row_hi)] for q, w in enumerate(wanted_by_rank) if q != rank]
-    pub_ids = torch.unique(torch.cat(mine)) if mine else torch.zeros(0, dtype=torch.int64)
+    pub_ids = torch.unique(torch.cat(mine)) if mine else torch.zeros(0, dtype=torch.int64, device=dev)
     if pub_ids.numel():
         # (a lookup table over this rank's rows: torch.isin sorts the whole edge list, seconds at 10^8 edges)
         flag = torch.zeros(row_hi - row_lo, dtype=torch.bool, device=dev)
         flag[(pub_ids - row_lo).to(dev)] = True
         m = flag[ei[0] - row_lo]
-        pub = (ei[:, m].cpu(), ev.reshape(-1)[m].cpu())
+        pub_i, pub_v = ei[:, m].t().contiguous(), ev.reshape(-1)[m].contiguous()
     else:
-        pub = (torch.zeros((2, 0), dtype=torch.int64), torch.zeros(0, dtype=ev.dtype))
-    pool = [None] * dist.get_world_size(group)
-    dist.all_gather_object(pool, pub, group=group)
-    want = wanted_by_rank[rank]
+        pub_i, pub_v = torch.zeros((0, 2), dtype=torch.int64, device=dev), torch.zeros(0, dtype=ev.dtype, device=dev)
+    pool_i, pool_v = _gather_var(pub_i, group), _gather_var(pub_v, group)
+    want = wanted_by_rank[rank].to(dev)
     got_i, got_v = [], []
-    for q, (pi, pv) in enumerate(pool):
-        if q == rank or pi.shape[1] == 0:
+    for q, (pi, pv) in enumerate(zip(pool_i, pool_v)):
+        if q == rank or pi.shape[0] == 0:
             continue
+        pi = pi.t()
         pos = torch.searchsorted(want, pi[0]).clamp_(max=max(int(want.numel()) - 1, 0))     # `want` is sorted
-        m = want[pos] == pi[0] if want.numel() else torch.zeros(pi.shape[1], dtype=torch.bool)
+        m = want[pos] == pi[0] if want.numel() else torch.zeros(pi.shape[1], dtype=torch.bool, device=dev)
         got_i.append(pi[:, m])
         got_v.append(pv[m])
     if not got_i:
         return torch.zeros((2, 0), dtype=torch.int64, device=dev), torch.zeros(0, dtype=ev.dtype, device=dev)
     gi, gv = torch.cat(got_i, 1), torch.cat(got_v)
     order = torch.argsort(gi[0], stable=True)                  # owners are disjoint row ranges: row-sorted overall
-    return gi[:, order].to(dev), gv[order].to(dev)
+    return gi[:, order].contiguous(), gv[order].contiguous()
 
 
 def _all_wanted(need, group):
-    wanted = [None] * dist.get_world_size(group)
-    dist.all_gather_object(wanted, need.cpu(), group=group)
-    return wanted
+    """Every rank's sorted list of wanted global row ids (tensor collective)."""
+    return _gather_var(need.to(torch.int64).contiguous(), group)
 
 
 class RowBlockPartition:
@@ -164,8 +185,7 @@ class RowBlockPartition:
         off = (col < self.in_lo) | (col >= self.in_hi)
         need = torch.unique(col[off]).cpu()                       # sorted global ids
         if self.distributed:
-            needs = [None] * self.world
-            dist.all_gather_object(needs, need, group=group)
+            needs = [t_.cpu() for t_ in _gather_var(need, group)]
         else:
             needs = [need]
         # send list of rank q = sorted union of q's input entries that any rank needs
@@ -280,40 +300,11 @@ class RowBlockOps:
             p.exchange(X)
             launch(self.ALL)
 
-    def all_reduce_sum(self, t):
-        """Sum over the ranks (power method partial sums): stream-ordered on the library's communicator when there is
-        one, torch.distributed otherwise."""
-        if self.comm is not None and t.is_cuda:
-            return self.comm.all_reduce_sum(t)
-        return self.part.all_reduce_sum(t)
+    # ---- the block extended by ghost grid lines (temporally blocked routes) --------------------------------------------
+    TS_MAX = 8                                               # ghost lines either side = the most sweeps / steps a pass carries
+    ext = None
 
-class RowBlockJacobi(RowBlockOps):
-    """JacobiGNN.forward on a row block: same arguments as the module, local rows only (JacobiGNN.py:138-148).
-
-    Two routes.  (1) One halo exchange per sweep (north_star's wording): interior / boundary tiles of the block's own
-    plan.  (2) `temporal=True` (default) on 2-D stencil blocks with one right-hand side: the temporally blocked kernel
-    of the single-GPU path (5, 4 or 2 sweeps per pass over the data) on the block EXTENDED by ghost lines, with ONE
-    exchange per pass -- the 5 grid lines either side that a pass can depend on -- instead of one per sweep
-    (communication-avoiding; the ghost lines are recomputed redundantly, exactly like the overlap between the line
-    blocks of one GPU).  The ghost rows of the matrix are fetched once at construction, those of b and A_ii once per
-    forward().  Same per-row arithmetic: bit-identical to route (1) and to the single-GPU module."""
-
-    TS_MAX = 8                                               # most sweeps a pass carries (gla.h: gla_jacobi_sweeps_schedule)
-    ext = None                                               # set by _setup_temporal when the route applies
-
-    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None,
-                 host_loop=False, temporal=True):
-        super().__init__(edgeij_pair, edge_attr, n_global, row_lo, row_hi, group, overlap, col_blocks, host_loop)
-        self.ext = None
-        if temporal and col_blocks is None and self.part.world > 1 and edgeij_pair.is_cuda:
-            self._setup_temporal(edgeij_pair, edge_attr)
-        if self.ext is not None:
-            self.mode = ("temporally blocked: one ghost-line exchange per pass of up to 8 sweeps, "
-                         + ("libgla_hip RCCL all-gather on a side stream, interior / boundary line blocks overlapped"
-                            if self.comm is not None else "torch.distributed all-gather (host-ordered)"))
-
-    # ---- temporally blocked route -----------------------------------------------------------------------
-    def _setup_temporal(self, edgeij_pair, edge_attr):
+    def _setup_ghost(self, edgeij_pair, edge_attr, need_jacobi_passes=True):
         """Build the plan of the block extended by TS_MAX ghost lines either side (true global rows for the ghost lines
         within TS_MAX - 1 of the block, fetched from their owners); leaves self.ext = None when the block is not a 2-D
         stencil, too small, or the extended plan does not qualify for the fused kernel."""
@@ -346,7 +337,7 @@ class RowBlockJacobi(RowBlockOps):
             plan = CsrPlan(all_ei - elo, ehi - elo, ehi - elo)
             plan.set_values(all_ev)
             sched = plan.jacobi_schedule(4 * T, all_ev.dtype)
-            good = int(1 < max(sched) <= T and int(plan.info.dia_stride) == S)
+            good = int((not need_jacobi_passes or 1 < max(sched) <= T) and int(plan.info.dia_stride) == S)
             self._sched = plan.jacobi_schedule
         goods = [None] * p.world
         dist.all_gather_object(goods, good, group=p.group)
@@ -358,19 +349,21 @@ class RowBlockJacobi(RowBlockOps):
                         slab=T * S, dtype=all_ev.dtype, dev=dev)
 
     def _ghost_exchange(self, owns, begin_only=False):
-        """ONE all-gather of every rank's first and last TS_MAX grid lines of each vector in `owns` ([n_local] each);
-        returns per vector the (upper, lower) ghost slabs for this rank (None where there is no neighbour).  With the
-        library communicator the gather runs on its side stream: call with begin_only=True, launch work that needs no
-        ghosts, then _ghost_finish()."""
+        """ONE all-gather of every rank's first and last TS_MAX grid lines of each vector in `owns` ([n_local] or [n_local, K]
+        each, rows may be strided); returns per vector the (upper, lower) ghost slabs for this rank, flat (None where there is
+        no neighbour).  With the library communicator the gather runs on its side stream: call with begin_only=True, launch
+        work that needs no ghosts, then _ghost_finish()."""
         e, p = self.ext, self.part
-        m, nv = e["slab"], len(owns)
-        send = torch.cat([piece for own in owns for piece in (own[:m], own[-m:])])
-        recv = torch.empty(p.world * 2 * m * nv, dtype=send.dtype, device=send.device)
+        m = e["slab"]
+        widths = [own.numel() // max(own.shape[0], 1) for own in owns]
+        send = torch.cat([piece.reshape(-1) for own in owns for piece in (own[:m], own[-m:])])
+        chunk = 2 * m * sum(widths)
+        recv = torch.empty(p.world * chunk, dtype=send.dtype, device=send.device)
         if self.comm is not None:
             from ._lib import check, dtype_code, lib, ptr, stream_ptr
             check(lib().gla_comm_all_gather_begin(self.comm._h, dtype_code(send.dtype), ptr(send), ptr(recv),
-                                                  2 * m * nv, stream_ptr(send.device)))
-            self._ghost_pending = (send, recv, nv, True)    # keep the buffers alive until the gather has been waited for
+                                                  chunk, stream_ptr(send.device)))
+            self._ghost_pending = (send, recv, widths, True)    # keep the buffers alive until the gather has been waited for
         else:
             if send.is_cuda and dist.get_backend(p.group) == "gloo":   # rehearsal route: gloo moves host memory
                 recv_h = torch.empty(recv.numel(), dtype=send.dtype)
@@ -378,23 +371,24 @@ class RowBlockJacobi(RowBlockOps):
                 recv = recv_h.to(send.device)
             else:
                 dist.all_gather_into_tensor(recv, send, group=p.group)
-            self._ghost_pending = (send, recv, nv, False)
+            self._ghost_pending = (send, recv, widths, False)
         return None if begin_only else self._ghost_finish()
 
     def _ghost_finish(self):
         e, p = self.ext, self.part
         m = e["slab"]
-        send, recv, nv, on_side_stream = self._ghost_pending
+        send, recv, widths, on_side_stream = self._ghost_pending
         if on_side_stream:
             from ._lib import check, lib, stream_ptr
             check(lib().gla_halo_end(self.comm._h, stream_ptr(recv.device)))
-        chunk = 2 * m * nv                                   # a rank's chunk: per vector [first m | last m]
-        out = []
-        for v in range(nv):
-            ru, rd = e.get("up_src", p.rank - 1), e.get("down_src", p.rank + 1)      # (overridable: one-rank self-halo tests)
-            up = recv[ru * chunk + v * 2 * m + m:ru * chunk + (v + 1) * 2 * m] if e["up"] else None
-            lo = recv[rd * chunk + v * 2 * m:rd * chunk + v * 2 * m + m] if e["down"] else None
+        chunk = 2 * m * sum(widths)                          # a rank's chunk: per vector [first m rows | last m rows]
+        out, base = [], 0
+        ru, rd = e.get("up_src", p.rank - 1), e.get("down_src", p.rank + 1)      # (overridable: one-rank self-halo tests)
+        for w_ in widths:
+            up = recv[ru * chunk + base + m * w_:ru * chunk + base + 2 * m * w_] if e["up"] else None
+            lo = recv[rd * chunk + base:rd * chunk + base + m * w_] if e["down"] else None
             out.append((up, lo))                             # the neighbour above's LAST lines / below's FIRST lines
+            base += 2 * m * w_
         return out
 
     @staticmethod
@@ -422,14 +416,44 @@ class RowBlockJacobi(RowBlockOps):
             check(lib().gla_copy_batch(dtype_code(chunk[0][1].dtype), k, src, dst, cnt, strd, stream_ptr(chunk[0][1].device)))
 
     def _fill_ghosts(self, ext_vecs, slabs):
+        """Ghost lines of the extended vectors ([n_ext] or contiguous [n_ext, K]) from the gathered slabs, one launch."""
         e = self.ext
         pairs = []
         for vec, (upper, lower) in zip(ext_vecs, slabs):
             if upper is not None:
-                pairs.append((upper, vec[:e["off"]]))
+                pairs.append((upper, vec[:e["off"]].reshape(-1)))
             if lower is not None:
-                pairs.append((lower, vec[e["off"] + self.part.n_local:]))
+                pairs.append((lower, vec[e["off"] + self.part.n_local:].reshape(-1)))
         self._copy_batch(pairs)
+
+    def all_reduce_sum(self, t):
+        """Sum over the ranks (power method partial sums): stream-ordered on the library's communicator when there is
+        one, torch.distributed otherwise."""
+        if self.comm is not None and t.is_cuda:
+            return self.comm.all_reduce_sum(t)
+        return self.part.all_reduce_sum(t)
+
+class RowBlockJacobi(RowBlockOps):
+    """JacobiGNN.forward on a row block: same arguments as the module, local rows only (JacobiGNN.py:138-148).
+
+    Two routes.  (1) One halo exchange per sweep (north_star's wording): interior / boundary tiles of the block's own
+    plan.  (2) `temporal=True` (default) on 2-D stencil blocks with one right-hand side: the temporally blocked kernel
+    of the single-GPU path (5, 4 or 2 sweeps per pass over the data) on the block EXTENDED by ghost lines, with ONE
+    exchange per pass -- the 5 grid lines either side that a pass can depend on -- instead of one per sweep
+    (communication-avoiding; the ghost lines are recomputed redundantly, exactly like the overlap between the line
+    blocks of one GPU).  The ghost rows of the matrix are fetched once at construction, those of b and A_ii once per
+    forward().  Same per-row arithmetic: bit-identical to route (1) and to the single-GPU module."""
+
+    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None,
+                 host_loop=False, temporal=True):
+        super().__init__(edgeij_pair, edge_attr, n_global, row_lo, row_hi, group, overlap, col_blocks, host_loop)
+        self.ext = None
+        if temporal and col_blocks is None and self.part.world > 1 and edgeij_pair.is_cuda:
+            self._setup_ghost(edgeij_pair, edge_attr)
+        if self.ext is not None:
+            self.mode = ("temporally blocked: one ghost-line exchange per pass of up to 8 sweeps, "
+                         + ("libgla_hip RCCL all-gather on a side stream, interior / boundary line blocks overlapped"
+                            if self.comm is not None else "torch.distributed all-gather (host-ordered)"))
 
     def _forward_temporal(self, n_iters, va, w):
         import ctypes
@@ -506,6 +530,50 @@ class RowBlockJacobi(RowBlockOps):
         self._ghost_pending = None
         return own(cur).reshape(-1, 1)
 
+    def _forward_temporal_k(self, n_iters, va, w):
+        """K right-hand sides (vertex_attr [n_local, 3, K]) on the block extended by ghost lines: passes of up to four sweeps
+        (canonical 9-point plans: three) -- the K-wide temporally blocked kernel of the single-GPU path, jacobi_marchk_kernel --
+        with ONE exchange of the TS_MAX ghost lines per pass instead of one per sweep; the ghost lines of b and A_ii ride along
+        in the first exchange.  Ghost lines are recomputed redundantly; own rows: the arithmetic of single sweeps, bit for bit.
+        Returns None when the library declines (K not a multiple of the 16-byte vector, ...): exchange-per-sweep route."""
+        from ._lib import check, dtype_code, lib, ptr, stream_ptr
+        e, p = self.ext, self.part
+        n_ext, off, nl = e["n_ext"], e["off"], p.n_local
+        dev, dt, K = va.device, va.dtype, va.shape[2]
+        vw = 16 // va.element_size()
+        if K % vw or not int(e["plan"].info.dia_canon5) in (1, 9):
+            return None
+        tmax = 4 if int(e["plan"].info.dia_canon5) == 1 else 3
+        bufs = e.setdefault("buffers_k", {})
+        buf = bufs.get(K)
+        if buf is None:                                      # persistent extended operands: A_ii, b, two x buffers, one scratch
+            buf = bufs[K] = (torch.ones(n_ext, dtype=dt, device=dev), torch.zeros((n_ext, K), dtype=dt, device=dev),
+                             torch.zeros((n_ext, K), dtype=dt, device=dev), torch.zeros((n_ext, K), dtype=dt, device=dev),
+                             torch.zeros((n_ext, K), dtype=dt, device=dev))
+        d_ext, b_ext, cur, nxt, tmp = buf
+        own = lambda v: v[off:off + nl]                      # noqa: E731
+        own(d_ext).copy_(va[:, 0, 0])
+        own(b_ext).copy_(va[:, 1, :])
+        own(cur).copy_(va[:, 2, :])
+        kp = -(-n_iters // tmax)
+        base, rem = divmod(n_iters, kp)
+        code, st, h = dtype_code(dt), stream_ptr(dev), e["plan"]._h
+        first = True
+        for i in range(kp):
+            ts = base + (1 if i < rem else 0)
+            vecs = [d_ext, b_ext, cur] if first else [cur]
+            first = False
+            self._fill_ghosts(vecs, self._ghost_exchange([own(v) for v in vecs]))
+            rc = lib().gla_jacobi_sweeps(h, code, K, ptr(d_ext), ptr(b_ext), K, ptr(cur), K, ptr(nxt), ptr(tmp), K, w, ts, st)
+            if rc == -5 and i == 0:
+                self._ghost_pending = None
+                return None
+            check(rc)
+            cur, nxt = nxt, cur
+        bufs[K] = (d_ext, b_ext, cur, nxt, tmp)
+        self._ghost_pending = None
+        return own(cur).unsqueeze(1).clone()
+
     def forward(self, n_iters, vertex_attr, g):
         p = self.part
         va = vertex_attr
@@ -514,6 +582,10 @@ class RowBlockJacobi(RowBlockOps):
             if va.stride(1) != 1:
                 va = va.contiguous()
             return self._forward_temporal(int(n_iters), va, scalar0(g))
+        if self.ext is not None and K > 1 and va.dim() == 3 and va.dtype == self.ext["dtype"] and int(n_iters) >= 2:
+            out = self._forward_temporal_k(int(n_iters), va, scalar0(g))
+            if out is not None:
+                return out
         diag = (va[:, 0] if va.dim() == 2 else va[:, 0, 0]).contiguous()
         B = (va[:, 1].reshape(-1, 1) if va.dim() == 2 else va[:, 1, :]).contiguous()
         w = scalar0(g)
@@ -553,11 +625,85 @@ class RowBlockJacobi(RowBlockOps):
         return x.clone() if va.dim() == 2 else x.unsqueeze(1).clone()
 
 class RowBlockCheby(RowBlockOps):
-    """ChebyRelaxGNN(deg).forward on a row block (ChebyGNN.py:324-353); returns (x, r, p, g_out) local rows."""
+    """ChebyRelaxGNN(deg).forward on a row block (ChebyGNN.py:324-353); returns (x, r, p, g_out) local rows.
+
+    Two routes, as for RowBlockJacobi.  (1) One halo exchange per step (north_star's wording).  (2) `temporal=True` (default) on
+    2-D stencil blocks: the fused pass of the single-GPU path (gla_cheby_fused / gla_cheby_fused_next: up to four steps in one
+    pass over the data) on the block extended by TS_MAX ghost lines, ONE ghost-line exchange per pass -- b and x before the
+    first pass, (r, x, p) before every continuation pass.  Ghost lines are recomputed redundantly; per row the arithmetic of
+    the step kernels: bit-identical to route (1) and to the single-GPU module."""
+
+    def __init__(self, edgeij_pair, edge_attr, n_global, row_lo, row_hi, group=None, overlap=True, col_blocks=None,
+                 host_loop=False, temporal=True):
+        super().__init__(edgeij_pair, edge_attr, n_global, row_lo, row_hi, group, overlap, col_blocks, host_loop)
+        self.ext = None
+        if temporal and col_blocks is None and self.part.world > 1 and edgeij_pair.is_cuda:
+            self._setup_ghost(edgeij_pair, edge_attr, need_jacobi_passes=False)
+        if self.ext is not None:
+            self.mode = "temporally blocked: one ghost-line exchange per fused pass of up to 4 Chebyshev steps"
+
+    def _forward_ghost(self, deg, b, x0, g):
+        from .ChebyGNN import _scalars, _g_out
+        e, p = self.ext, self.part
+        n_ext, off, nl, K = e["n_ext"], e["off"], p.n_local, b.shape[1]
+        dev, dt = b.device, b.dtype
+        plan = e["plan"]
+        c, d, alphas, betas = _scalars(g, deg)
+        bufs = e.setdefault("buffers_cheby", {})
+        buf = bufs.get(K)
+        if buf is None:                                      # persistent extended operands: b, two (x, r, p) sets
+            buf = bufs[K] = [torch.zeros((n_ext, K), dtype=dt, device=dev) for _ in range(7)]
+        b_ext, xa, ra, pa, xb, rb, pb = buf
+        own = lambda v: v[off:off + nl]                      # noqa: E731
+        own(b_ext).copy_(b)
+        own(xa).copy_(x0)
+        self._fill_ghosts([b_ext, xa], self._ghost_exchange([own(b_ext), own(xa)]))
+        done = 0
+        for m in range(min(deg, 4), 1, -1):                  # the most steps this plan's fused kernel takes
+            if plan.cheby_fused(b_ext, xa, xb, rb, pb, [float(a) for a in alphas[:m]], [0.0] + [float(v) for v in betas[1:m]]):
+                done = m
+                break
+        if done == 0:
+            self._ghost_pending = None
+            return None
+        mmax = done
+        X, R, P = xb, rb, pb                                 # the iterates after step `done`
+        X2, R2, P2 = xa, ra, pa                              # the other set
+        rest = deg - done
+        sizes = []
+        if rest >= 2:
+            n_pass = -(-rest // mmax)
+            base, extra = divmod(rest, n_pass)
+            sizes = [base + 1] * extra + [base] * (n_pass - extra) if base >= 2 else [2] * (rest // 2) + [1] * (rest % 2)
+        elif rest == 1:
+            sizes = [1]
+        for sz in sizes:
+            vecs = [R, X, P]
+            self._fill_ghosts(vecs, self._ghost_exchange([own(v) for v in vecs]))
+            if sz >= 2 and plan.cheby_fused_next(R, X, P, X2, R2, P2, float(alphas[done - 1]),
+                                                  [float(a) for a in alphas[done:done + sz]],
+                                                  [float(v) for v in betas[done:done + sz]]):
+                X, R, P, X2, R2, P2 = X2, R2, P2, X, R, P
+                done += sz
+                continue
+            for it in range(done + 1, done + sz + 1):        # step kernels on the extended block (R, X in place, P ping-pongs)
+                if it > done + 1:
+                    vecs = [R, X, P]
+                    self._fill_ghosts(vecs, self._ghost_exchange([own(v) for v in vecs]))
+                plan.cheby_steps(P, P2, R, X, [alphas[it - 2]], [alphas[it - 1]], [betas[it - 1]])
+                P, P2 = P2, P
+            done += sz
+        cur = (X, R, P)
+        self._ghost_pending = None
+        return own(cur[0]).clone(), own(cur[1]).clone(), own(cur[2]).clone(), _g_out(c, d, alphas, betas, g)
 
     def forward(self, deg, b, x0, g):
         p = self.part
         K = b.shape[1]
+        if self.ext is not None and deg >= 2 and b.dtype == self.ext["dtype"] and b.is_cuda:
+            out = self._forward_ghost(int(deg), b, x0, g)
+            if out is not None:
+                return out
         gh = g.detach().to("cpu")
         c, d = gh[0], gh[1]
         alpha = 1 / d

@@ -11,7 +11,8 @@ SETUP phase, two routes:
   * `RowBlockAMG.distributed_setup(...)`: NOTHING of nnz size is replicated.  Each rank starts from its row block of
     A and builds, level by level, its rows of S (strength, row-local), of the interpolation weights (row-local; the
     C/F flags of halo columns come from the index-based splitting rule), of P, of A P (after fetching the P rows of
-    its halo columns from their owners), of P^T (after receiving the P entries whose column it owns) and of
+    its halo columns from their owners), of P^T (after receiving the P entries whose column it owns: the entries a rank
+    does not own travel by tensor all-gathers, O(nnz(P)) traffic per level during setup) and of
     A_c = P^T (A P) (after fetching the A P rows of the fine vertices its coarse rows interpolate from).  Every row
     is computed by exactly the kernels, operands and summation order of the single-rank setup, so the hierarchy --
     and with it every cycle -- is bit-identical to the single-rank one (tests/test_gpu_dist.py).  Only O(n) index
@@ -23,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from .ChebyGNN import chebyshev_relax
-from .dist import RowBlockOps, _all_wanted, _publish_rows
+from .dist import RowBlockOps, _all_wanted, _gather_var, _publish_rows
 
 
 def even_blocks(n, world):
@@ -161,12 +162,13 @@ class RowBlockAMG:
             # ---- P^T rows of the own coarse rows: P entries whose column this rank owns, from every rank
             mine = (P_ei[1] >= clo) & (P_ei[1] < chi)
             if self.world > 1:
-                pool = [None] * self.world
-                dist.all_gather_object(pool, (P_ei[:, ~mine].cpu(), P_ev[~mine].cpu()), group=group)
-                o_i = [pi[:, (pi[1] >= clo) & (pi[1] < chi)] for q, (pi, pv) in enumerate(pool) if q != self.rank]
-                o_v = [pv[(pi[1] >= clo) & (pi[1] < chi)] for q, (pi, pv) in enumerate(pool) if q != self.rank]
-                all_i = torch.cat([P_ei[:, mine]] + [t.to(dev) for t in o_i], 1)
-                all_v = torch.cat([P_ev[mine]] + [t.to(dev) for t in o_v])
+                # (tensor collectives; every rank sees every rank's non-owned P entries and keeps those whose column it owns)
+                pool_i = [t_.t() for t_ in _gather_var(P_ei[:, ~mine].t().contiguous(), group)]
+                pool_v = _gather_var(P_ev[~mine].contiguous(), group)
+                o_i = [pi[:, (pi[1] >= clo) & (pi[1] < chi)] for q, pi in enumerate(pool_i) if q != self.rank]
+                o_v = [pv[(pi[1] >= clo) & (pi[1] < chi)] for q, (pi, pv) in enumerate(zip(pool_i, pool_v)) if q != self.rank]
+                all_i = torch.cat([P_ei[:, mine]] + o_i, 1)
+                all_v = torch.cat([P_ev[mine]] + o_v)
             else:
                 all_i, all_v = P_ei[:, mine], P_ev[mine]
             Pt_ei, Pt_ev = sparse_ops.coalesce(torch.stack([all_i[1] - clo, all_i[0]]), all_v, max(chi - clo, 1), n_l)
@@ -193,10 +195,8 @@ class RowBlockAMG:
         self.setup_nnz_local = setup_nnz
         # ---- coarsest operator: gathered to every rank (small), solved redundantly like the single-rank hierarchy
         if self.world > 1:
-            pool = [None] * self.world
-            dist.all_gather_object(pool, (ei.cpu(), ev.cpu()), group=group)
-            c_ei = torch.cat([pi for pi, _ in pool], 1).to(dev)
-            c_ev = torch.cat([pv for _, pv in pool]).to(dev)
+            c_ei = torch.cat([t_.t() for t_ in _gather_var(ei.t().contiguous(), group)], 1)
+            c_ev = torch.cat(_gather_var(ev.contiguous(), group))
         else:
             c_ei, c_ev = ei, ev
         Hc = V.AMGHierarchy(V._as_sparse(c_ei, c_ev, (n_l, n_l)), levels=1, theta_=theta, w=w, **coarse_kwargs)

@@ -93,6 +93,22 @@ def _worker(rank, world, port, overlap, q):
         x, r, p, g_out = ch.forward(4, B[lo:hi].contiguous(), X[lo:hi].contiguous(), gch)
         assert torch.equal(x, v_ref[lo:hi, 1]) and torch.equal(r, v_ref[lo:hi, 2]) and torch.equal(p, v_ref[lo:hi, 3])
         assert torch.equal(g_out, g_ref)
+        # round 3: the ghost-line routes of the fused Chebyshev pass and of the K-wide Jacobi passes (one exchange per pass):
+        # every degree / sweep count, against the single-rank modules, bit for bit; temporal=False keeps one exchange per step
+        if default_layout:
+            assert (ch.ext is not None) == (world == 2), (world, ch.ext is None)
+        for deg in (2, 3, 5, 6, 9):
+            vr, _, gr = gla.ChebyGNN.ChebyRelaxGNN(deg, return_edge_attr=False)(torch.stack([B, X], 1), ei, ev, gch)
+            x, r, p, g_out = ch.forward(deg, B[lo:hi].contiguous(), X[lo:hi].contiguous(), gch)
+            assert torch.equal(x, vr[lo:hi, 1]) and torch.equal(r, vr[lo:hi, 2]) and torch.equal(p, vr[lo:hi, 3]), ("cheby ghost", deg)
+            assert torch.equal(g_out, gr), ("cheby g", deg)
+        ch_ps = RowBlockCheby(ei_l, ev_l, n, lo, hi, overlap=overlap, temporal=False)
+        x, r, p, g_out = ch_ps.forward(4, B[lo:hi].contiguous(), X[lo:hi].contiguous(), gch)
+        assert ch_ps.ext is None and torch.equal(x, v_ref[lo:hi, 1]) and torch.equal(p, v_ref[lo:hi, 3]), "cheby per-step route"
+        vaK, vaK_loc = torch.stack([diag, B, X], 1), torch.stack([diag[lo:hi], B[lo:hi], X[lo:hi]], 1)
+        for its in (2, 3, 4, 7, 9):                           # passes of 2, 3, 4, 4 + 3, 3 + 3 + 3 sweeps
+            assert torch.equal(jac.forward(its, vaK_loc, g), gla.JacobiGNN.JacobiGNN()(its, vaK, ei, ea, g)[lo:hi]), ("jacobi K", its)
+        assert torch.equal(jac_ps.forward(5, vaK_loc, g), gla.JacobiGNN.JacobiGNN()(5, vaK, ei, ea, g)[lo:hi]), "jacobi K per-sweep"
         pw = RowBlockPower(ei_l, ev_l, n, lo, hi, overlap=overlap)
         _, g_pw = pw.forward(5, B[lo:hi].contiguous())
         torch.testing.assert_close(g_pw.cpu(), p_ref.cpu(), rtol=1e-12, atol=0)
@@ -489,3 +505,77 @@ def test_temporal_route_self_halo_rccl(Nx, Ny):
             got = drv.forward(its, va, g)
             assert torch.equal(got.reshape(-1), x), (its, overlap, float((got.reshape(-1) - x).abs().max()))
     torch.cuda.synchronize()
+
+
+def test_k_wide_ghost_routes_self_halo_rccl():
+    """The ghost-line routes of the K-wide Jacobi passes (RowBlockJacobi._forward_temporal_k) and of the fused Chebyshev pass
+    (RowBlockCheby._forward_ghost) over a REAL one-rank RCCL communicator whose upper and lower neighbour are the rank itself
+    (a grid periodic in the line direction): every pass goes through pack -> ncclAllGather on the library's stream -> ghost
+    fill -> one temporally blocked pass.  Reference: the same periodic problem one sweep / one step at a time with the ghost
+    lines refreshed by hand -- identical per-row arithmetic, so bit for bit."""
+    import types
+    import gnn_applied_linear_algebra_amd as gla
+    from gnn_applied_linear_algebra_amd._lib import check, lib
+    from gnn_applied_linear_algebra_amd.dist import LibComm, RowBlockCheby, RowBlockJacobi
+    from gnn_applied_linear_algebra_amd.ChebyGNN import _scalars
+    dev = torch.device("cuda:0")
+    T = RowBlockJacobi.TS_MAX
+    Nx, Ny, K = 96, 120, 4
+    n, n_ext, off = Nx * Ny, Nx * (Ny + 2 * T), Nx * T
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(Nx, Ny=Ny + 2 * T, device=dev)
+    plan = gla.CsrPlan(ei, n_ext)
+    plan.set_values(ev)
+    if plan.jacobi_schedule(2) != (2,):
+        pytest.skip("no temporally blocked kernel under these GLA_OPTIONS")
+    comm = LibComm()
+    gen = torch.Generator().manual_seed(8)
+
+    def periodic(own):                                   # [own's last T lines | own | own's first T lines]
+        return torch.cat([own[-off:], own, own[:off]])
+
+    def driver(cls):
+        drv = cls.__new__(cls)
+        drv.comm, drv.overlap, drv._ghost_pending = comm, True, None
+        drv.part = types.SimpleNamespace(world=1, rank=0, n_local=n, group=None, n_in=n, S=0)
+        drv._sched = plan.jacobi_schedule
+        drv.ext = dict(plan=plan, S=Nx, n_ext=n_ext, off=off, up=True, down=True, slab=T * Nx, dtype=torch.float64, dev=dev,
+                       up_src=0, down_src=0)
+        return drv
+
+    # ---- Jacobi on K right-hand sides
+    va = torch.rand(n, 3, K, generator=gen, dtype=torch.float64).to(dev)
+    va[:, 0, :] = (torch.rand(n, 1, generator=gen, dtype=torch.float64) + 3.0).to(dev)
+    g = torch.tensor([0.7], dtype=torch.float64)
+    d_e, b_e = periodic(va[:, 0, 0].contiguous()), periodic(va[:, 1, :].contiguous())
+    jac = driver(RowBlockJacobi)
+    for its in (2, 4, 7, 9):
+        x = va[:, 2, :].contiguous()
+        try:
+            check(lib().gla_set_option(b"jacobi_fuse", 0))
+            for _ in range(its):
+                x = plan.jacobi_sweeps(d_e, b_e, periodic(x), 0.7, 1)[off:off + n]
+        finally:
+            check(lib().gla_set_option(b"jacobi_fuse", 1))
+        got = jac.forward(its, va, g)
+        assert got.shape == (n, 1, K) and torch.equal(got[:, 0, :], x), ("jacobi K", its)
+    # ---- Chebyshev: fused passes with ghost exchanges vs one step at a time on the periodic extension
+    b = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
+    x0 = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
+    gch = torch.tensor([-3.4, -4.0], dtype=torch.float64)
+    ch = driver(RowBlockCheby)
+    for deg in (2, 4, 5, 8, 9):
+        c, d, alphas, betas = _scalars(gch, deg)
+        xe, be = periodic(x0), periodic(b)
+        re, pe, xo = torch.empty_like(xe), torch.empty_like(xe), torch.empty_like(xe)
+        plan.cheby_first(be, xe, re, pe, xo, float(alphas[0]))
+        x, r, p = xo[off:off + n].clone(), re[off:off + n].clone(), pe[off:off + n].clone()
+        for it in range(2, deg + 1):
+            pe_in, re_io, xe_io = periodic(p), periodic(r), periodic(x)
+            pe_out = torch.empty_like(pe_in)
+            plan.cheby_next(pe_in, pe_out, re_io, xe_io, float(alphas[it - 2]), float(alphas[it - 1]), float(betas[it - 1]))
+            x, r, p = xe_io[off:off + n].clone(), re_io[off:off + n].clone(), pe_out[off:off + n].clone()
+        gx, gr, gp, _ = ch.forward(deg, b, x0, gch)
+        assert torch.equal(gx, x) and torch.equal(gr, r) and torch.equal(gp, p), ("cheby", deg)
+    torch.cuda.synchronize()
+    lib().gla_comm_destroy(comm._h)
+    comm._h = None
