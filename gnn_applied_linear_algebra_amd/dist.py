@@ -27,6 +27,9 @@ class _Done:
     def wait(self):
         return True
 
+
+EXCHANGES = [0]      # collectives on the data path issued by this process (halo / ghost-line all-gathers, vector gathers): for reports
+
 class LibComm:
     """An RCCL communicator owned by libgla_hip (gla_comm_t: ncclCommInitRank + a private communication stream and
     two events, csrc/gla_dist.hip) spanning the ranks of a torch process group.  With it the halo exchange is two
@@ -270,6 +273,15 @@ class RowBlockOps:
                       if self.comm is not None else "host-side: torch.distributed all_gather_into_tensor per sweep, ")
                      + ("interior/boundary overlap" if self.overlap else "no overlap"))
 
+    def io_buffer(self, K, dtype, device):
+        """The [n_in + P * S, K] operand buffer of this operator (local input entries, then the gathered send slots), allocated
+        once per (K, dtype): the exchange overwrites the whole tail, the caller the head."""
+        key = ("io", K, dtype)
+        buf = self._lib_send.get(key)
+        if buf is None:
+            buf = self._lib_send[key] = self.part.new_buffer(K, dtype, device)
+        return buf
+
     def _send_buf(self, X):
         key = (X.shape[1], X.dtype)
         buf = self._lib_send.get(key)
@@ -280,6 +292,8 @@ class RowBlockOps:
     def run(self, X, launch):
         """Exchange X's halo and call launch(which_tiles) for all row tiles, overlapping when enabled."""
         p = self.part
+        if not (p.S == 0 or (p.world == 1 and self.comm is None)):
+            EXCHANGES[0] += 1
         if p.S == 0 or (p.world == 1 and self.comm is None):
             launch(self.ALL)
         elif self.comm is not None:
@@ -355,6 +369,7 @@ class RowBlockOps:
         work that needs no ghosts, then _ghost_finish()."""
         e, p = self.ext, self.part
         m = e["slab"]
+        EXCHANGES[0] += 1
         widths = [own.numel() // max(own.shape[0], 1) for own in owns]
         send = torch.cat([piece.reshape(-1) for own in owns for piece in (own[:m], own[-m:])])
         chunk = 2 * m * sum(widths)
@@ -514,6 +529,11 @@ class RowBlockJacobi(RowBlockOps):
                 if from_aos:
                     check(lib().gla_jacobi_fused_parts_aos(h, code, ptr(va), va.stride(0), off, nl, ptr(d_ext), ptr(b_ext),
                                                            ptr(nxt), w, ts, 1, T, st))
+                    # the AoS interior launch WRITES the contiguous copies of A_ii and b (d_ext / b_ext) for its own lines, and
+                    # the edge blocks read d_ext / b_ext a few lines into that range: the rows were hand-copied above with the
+                    # same values, but two launches touching the same words concurrently is not a property to rely on -- in this
+                    # one pass the edge blocks are ordered after the interior launch
+                    side.wait_stream(main)
                 else:
                     check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, T, st))
                 with torch.cuda.stream(side):

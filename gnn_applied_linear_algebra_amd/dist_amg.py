@@ -1,22 +1,30 @@
 """Multi-rank V-cycle (BASELINE config 5: "3-level AMG ... 8 x MI355X"), distributed by contiguous row blocks.
 
-SOLVE phase (`RowBlockAMG.cycle`): each rank keeps its row block of every level operator A_l, of every prolongation
-P_l (rows: fine block, input vector: coarse partition) and restriction P_l^T (rows: coarse block, input vector: fine
-partition).  A cycle needs, per level, one halo all-gather per Jacobi sweep / residual / restriction / prolongation
-(dist.RowBlockPartition, overlapped with interior tiles) and, on the coarsest level, one all-gather of the whole
-(small) right-hand side, which every rank solves redundantly.
+SOLVE phase (`RowBlockAMG.cycle`): each rank keeps its row block of every DISTRIBUTED level operator A_l -- whole grid lines
+where the level is a 2-D stencil (`line_blocks`) -- of every prolongation P_l (rows: fine block, input vector: coarse
+partition) and restriction P_l^T (rows: coarse block, input vector: fine partition).  Per distributed level a cycle is
+  * pre-smoothing AND the residual of its result in ONE pass of the temporally blocked kernel (gla_jacobi_fused_residual) on
+    the block extended by 8 ghost lines: one ghost-line all-gather of [b, x] (round 2: one halo all-gather per sweep, a
+    separate residual launch with its own exchange);
+  * restriction: one halo all-gather of r; the coarse-grid correction x + P xc in one pass (gla_spmm_add): one halo all-gather
+    of xc; post-smoothing in one pass: one ghost-line all-gather of x
+= 4 exchanges per level instead of n_pre + n_post + 3.  Levels the temporally blocked kernels do not take (blocks of fewer
+than 8 grid lines, non-stencil operators) keep one exchange per sweep.  Operand buffers are allocated once per operator.
+AGGLOMERATION: from the first level with fewer than `agglomerate_below` rows per rank on, the hierarchy is
+replicated -- one all-gather of that level's right-hand side, then every rank runs the rest of the cycle on its own GPU with
+the single-GPU kernels (AMGHierarchy.cycle) and keeps its rows of the correction.  The coarsest level always is.
 
 SETUP phase, two routes:
   * `RowBlockAMG(H)`: every rank builds the whole `AMGHierarchy` H (replicated setup) and keeps its slices;
-  * `RowBlockAMG.distributed_setup(...)`: NOTHING of nnz size is replicated.  Each rank starts from its row block of
-    A and builds, level by level, its rows of S (strength, row-local), of the interpolation weights (row-local; the
-    C/F flags of halo columns come from the index-based splitting rule), of P, of A P (after fetching the P rows of
-    its halo columns from their owners), of P^T (after receiving the P entries whose column it owns: the entries a rank
-    does not own travel by tensor all-gathers, O(nnz(P)) traffic per level during setup) and of
-    A_c = P^T (A P) (after fetching the A P rows of the fine vertices its coarse rows interpolate from).  Every row
-    is computed by exactly the kernels, operands and summation order of the single-rank setup, so the hierarchy --
-    and with it every cycle -- is bit-identical to the single-rank one (tests/test_gpu_dist.py).  Only O(n) index
-    vectors (the C/F flags and the coarse numbering) and the coarsest operator are replicated.
+  * `RowBlockAMG.distributed_setup(...)`: NOTHING of nnz size is replicated on the distributed levels.  Each rank starts from
+    its row block of A and builds, level by level, its rows of S (strength, row-local), of the interpolation weights
+    (row-local; the C/F flags of halo columns come from the index-based splitting rule), of P, of A P (after fetching the P
+    rows of its halo columns from their owners), of P^T (after receiving the P entries whose column it owns: the entries a
+    rank does not own travel by tensor all-gathers, O(nnz(P)) traffic per level during setup) and of A_c = P^T (A P) (after
+    fetching the A P rows of the fine vertices its coarse rows interpolate from).  Every row is computed by exactly the
+    kernels, operands and summation order of the single-rank setup, so the hierarchy -- and with it every cycle -- is
+    bit-identical to the single-rank one (tests/test_gpu_dist.py).  Only O(n) index vectors (the C/F flags and the coarse
+    numbering) and the agglomerated levels are replicated.
 
 Row arithmetic is rank-independent, so the distributed cycle is bit-identical to the single-rank one.
 """
@@ -38,6 +46,15 @@ def even_blocks(n, world):
     return out
 
 
+def line_blocks(n, world, stride=0):
+    """Contiguous, balanced blocks of [0, n) made of WHOLE grid lines of `stride` vertices when the level is an n / stride-line
+    grid with at least one line per rank (what the temporally blocked kernels need); even_blocks otherwise."""
+    stride = int(stride or 0)
+    if stride > 0 and n % stride == 0 and n // stride >= world:
+        return [(lo * stride, hi * stride) for lo, hi in even_blocks(n // stride, world)]
+    return even_blocks(n, world)
+
+
 def _row_slice(ei, ev, lo, hi):
     """Rows [lo, hi) of a coalesced (row-sorted) COO pair."""
     a = int(torch.searchsorted(ei[0].contiguous(), torch.tensor(lo, device=ei.device)))
@@ -45,31 +62,43 @@ def _row_slice(ei, ev, lo, hi):
     return ei[:, a:b].contiguous(), ev.reshape(-1)[a:b].contiguous()
 
 
-class _CoarseSolve:
-    """What the coarsest-level 'solve' needs (taken from an AMGHierarchy whose LAST level is the coarsest operator)."""
+class _Sub:
+    """The replicated part of the hierarchy: an AMGHierarchy and the level of it at which the distributed cycle hands over."""
 
-    def __init__(self, H):
-        self.plan, self.lu, self.bounds = H.plans[-1], H._coarse_lu, H.coarse_bounds
-        self.sweeps, self.deg = H.coarse_sweeps, H.cheby.deg
+    def __init__(self, H, level):
+        self.H, self.level = H, int(level)
 
 
 class RowBlockAMG:
-    def __init__(self, H, group=None, overlap=True):
+    AGGLOMERATE_BELOW = 1 << 16                              # rows per rank below which a level is replicated (default)
+
+    def __init__(self, H, group=None, overlap=True, agglomerate_below=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.w, self.n_pre, self.n_post = H.w, H.n_pre, H.n_post
-        self.n_levels = len(H.A)
-        self.coarse = _CoarseSolve(H)
-        self.blocks = [even_blocks(A.shape[0], self.world) for A in H.A]
+        thr = self.AGGLOMERATE_BELOW if agglomerate_below is None else int(agglomerate_below)
+        n_all = len(H.A)
+        # levels 0 .. n_dist - 1 are distributed; level n_dist (the coarsest at the latest) and everything below it is replicated
+        n_dist = n_all - 1
+        for lv in range(1, n_all):
+            if H.A[lv].shape[0] < thr * self.world:
+                n_dist = lv
+                break
+        self.n_dist, self.n_levels = n_dist, n_all
+        self.sub = _Sub(H, n_dist)
+        strides = [int(H.plans[lv].info.dia_stride) for lv in range(n_all)]
+        self.blocks = [line_blocks(A.shape[0], self.world, strides[lv]) for lv, A in enumerate(H.A)][:n_dist + 1]
         self.A_ops, self.P_ops, self.Pt_ops, self.diag = [], [], [], []
-        for lv, A in enumerate(H.A):
+        for lv in range(n_dist):
+            A = H.A[lv]
             lo, hi = self.blocks[lv][self.rank]
             ei, ea, _, dg = H.gnn[lv]
             e_l, v_l = _row_slice(ei, ea, lo, hi)
             self.A_ops.append(RowBlockOps(e_l, v_l, A.shape[0], lo, hi, group, overlap))
             self.diag.append(dg.reshape(-1)[lo:hi].contiguous())
-        for lv in range(len(H.A) - 1):
+            self._ghost_setup(lv, e_l, v_l)
+        for lv in range(n_dist):
             lo, hi = self.blocks[lv][self.rank]
             clo, chi = self.blocks[lv + 1][self.rank]
             P_ei, P_ev = H.P[lv].coo
@@ -81,12 +110,30 @@ class RowBlockAMG:
             self.Pt_ops.append(RowBlockOps(e_l, v_l, H.A[lv + 1].shape[0], clo, chi, group, overlap,
                                            col_blocks=self.blocks[lv]))
 
+    def _ghost_setup(self, lv, e_l, v_l):
+        """Level lv's block extended by ghost lines (RowBlockOps._setup_ghost) + the extended A_ii with its ghost lines filled:
+        the temporally blocked smoothing passes of this level need one ghost-line exchange each."""
+        ops = self.A_ops[lv]
+        ops.ext = None
+        if self.world > 1 and e_l.is_cuda:
+            ops._setup_ghost(e_l, v_l.reshape(-1, 1))
+        if ops.ext is not None:
+            e = ops.ext
+            dt, dev = e["dtype"], e["dev"]
+            d_ext = torch.ones(e["n_ext"], dtype=dt, device=dev)
+            own = d_ext[e["off"]:e["off"] + ops.part.n_local]
+            own.copy_(self.diag[lv])
+            ops._fill_ghosts([d_ext], ops._ghost_exchange([own]))
+            ops._ghost_pending = None
+            e["amg"] = dict(d=d_ext, b=torch.zeros(e["n_ext"], dtype=dt, device=dev), x=torch.zeros(e["n_ext"], dtype=dt, device=dev))
+
     # ---- distributed setup ---------------------------------------------------------------------------
     @classmethod
     def distributed_setup(cls, A_ei, A_ev, n, levels=3, splitting=None, theta=0.25, w=0.7, n_pre=3, n_post=3,
-                          min_coarse=0, group=None, overlap=True, **coarse_kwargs):
+                          min_coarse=0, group=None, overlap=True, agglomerate_below=None, **coarse_kwargs):
         """Build the hierarchy from THIS RANK'S ROW BLOCK of A: (A_ei, A_ev) = the coalesced (row-sorted, ascending
-        columns) COO entries of rows even_blocks(n, world)[rank], global vertex ids.  `splitting`: an index-based
+        columns) COO entries of rows line_blocks(n, world, splitting.nx)[rank] (whole grid lines when `splitting` is a
+        GridSplitting; even_blocks(n, world)[rank] otherwise), global vertex ids.  `splitting`: an index-based
         rule -- None (every other vertex, as VCycle.default_splitting) or a VCycle.GridSplitting; it is evaluated
         on global vertex ids, so no rank needs another rank's strength graph.  coarse_kwargs go to the coarsest
         level's solver (coarse_solver=, coarse_deg=, coarse_kappa=, coarse_bounds=, coarse_sweeps=), as in
@@ -100,23 +147,27 @@ class RowBlockAMG:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.w, self.n_pre, self.n_post = w, n_pre, n_post
         self.blocks, self.A_ops, self.P_ops, self.Pt_ops, self.diag = [], [], [], [], []
+        thr = cls.AGGLOMERATE_BELOW if agglomerate_below is None else int(agglomerate_below)
         dev = A_ei.device
         ei, ev, n_l = A_ei, A_ev.reshape(-1), int(n)
         grid = splitting                                    # GridSplitting walks down the levels as it is called
+        stride_of = lambda: (grid.nx if isinstance(grid, V.GridSplitting) else 0)      # noqa: E731  (grid lines of the CURRENT level)
         setup_nnz = []
+        blocks = line_blocks(n_l, self.world, stride_of())
         for lv in range(levels):
-            blocks = even_blocks(n_l, self.world)
             lo, hi = blocks[self.rank]
             n_loc = hi - lo
             self.blocks.append(blocks)
+            # this level is the first replicated one: the coarsest at the latest, earlier when it is small (agglomeration)
+            if lv == levels - 1 or n_l <= min_coarse or (lv >= 1 and n_l < thr * self.world):
+                break
             self.A_ops.append(RowBlockOps(ei, ev.reshape(-1, 1), n_l, lo, hi, group, overlap))
             dg = torch.zeros(n_loc, dtype=ev.dtype, device=dev)
             on_diag = ei[0] == ei[1]
             dg[ei[0][on_diag] - lo] = ev[on_diag]
             self.diag.append(dg)
             setup_nnz.append(int(ei.shape[1]))
-            if lv == levels - 1 or n_l <= min_coarse:
-                break
+            self._ghost_setup(lv, ei, ev)
             # ---- C/F flags and coarse numbering: index-based, evaluated on global ids (O(n) vectors, no exchange)
             split_full = V.default_splitting(n_l, dev) if grid is None else grid(_OnDev(dev), None, n_l)
             split_full = split_full.to(dev).reshape(-1)
@@ -142,7 +193,7 @@ class RowBlockAMG:
             P_vals = torch.cat([w_ij[keep], torch.ones(c_rows.numel(), dtype=ev.dtype, device=dev)])
             P_ei, P_ev = sparse_ops.coalesce(torch.stack([P_rows - lo, P_cols]), P_vals, max(n_loc, 1), n_c)
             P_ei = torch.stack([P_ei[0] + lo, P_ei[1]])                       # global fine rows, global coarse columns
-            cblocks = even_blocks(n_c, self.world)
+            cblocks = line_blocks(n_c, self.world, stride_of())         # (the splitting has moved on to the coarse grid)
             clo, chi = cblocks[self.rank]
             self.P_ops.append(RowBlockOps(P_ei, P_ev.reshape(-1, 1), n_l, lo, hi, group, overlap, col_blocks=cblocks))
             # ---- (A P) rows of the own fine rows: needs the P rows of A's halo columns
@@ -190,17 +241,20 @@ class RowBlockAMG:
             AP_ext = sparse_ops.plan_of(torch.stack([torch.searchsorted(fine, B_rows), B_cols]), B_vals,
                                         max(int(fine.numel()), 1), n_c)
             Ac_ei, Ac_ev = sparse_ops.spgemm(Pt_loc, AP_ext)
-            ei, ev, n_l = torch.stack([Ac_ei[0] + clo, Ac_ei[1]]), Ac_ev, n_c
-        self.n_levels = len(self.A_ops)
-        self.setup_nnz_local = setup_nnz
-        # ---- coarsest operator: gathered to every rank (small), solved redundantly like the single-rank hierarchy
+            ei, ev, n_l, blocks = torch.stack([Ac_ei[0] + clo, Ac_ei[1]]), Ac_ev, n_c, cblocks
+        self.n_dist = len(self.A_ops)
+        self.setup_nnz_local = setup_nnz + [int(ei.shape[1])]
+        # ---- the first replicated level's operator: gathered to every rank, the rest of the hierarchy is built (and cycled)
+        #      redundantly by the single-GPU code -- the coarsest level alone, or the agglomerated tail of small levels
         if self.world > 1:
             c_ei = torch.cat([t_.t() for t_ in _gather_var(ei.t().contiguous(), group)], 1)
             c_ev = torch.cat(_gather_var(ev.contiguous(), group))
         else:
             c_ei, c_ev = ei, ev
-        Hc = V.AMGHierarchy(V._as_sparse(c_ei, c_ev, (n_l, n_l)), levels=1, theta_=theta, w=w, **coarse_kwargs)
-        self.coarse = _CoarseSolve(Hc)
+        Hc = V.AMGHierarchy(V._as_sparse(c_ei, c_ev, (n_l, n_l)), levels=levels - self.n_dist, theta_=theta, w=w,
+                            n_pre=n_pre, n_post=n_post, splitting=grid, min_coarse=min_coarse, **coarse_kwargs)
+        self.sub = _Sub(Hc, 0)
+        self.n_levels = self.n_dist + len(Hc.A)
         return self
 
     # ---- local pieces of global vectors -------------------------------------------------------------
@@ -212,6 +266,8 @@ class RowBlockAMG:
         """All ranks get the whole level vector (blocks padded to a common size for the collective)."""
         if self.world == 1:
             return v_local
+        from .dist import EXCHANGES
+        EXCHANGES[0] += 1
         blocks = self.blocks[level]
         m = max(hi - lo for lo, hi in blocks)
         K = v_local.shape[1]
@@ -229,9 +285,9 @@ class RowBlockAMG:
     # ---- distributed operators ----------------------------------------------------------------------
     @staticmethod
     def _apply(ops, v_in, launch):
-        """Put the local input entries into a halo buffer, exchange, run launch(buffer, which) on all tiles."""
+        """Put the local input entries into the operator's (persistent) halo buffer, exchange, run launch(buffer, which)."""
         p = ops.part
-        buf = p.new_buffer(v_in.shape[1], v_in.dtype, v_in.device)
+        buf = ops.io_buffer(v_in.shape[1], v_in.dtype, v_in.device)
         buf[:p.n_in] = v_in
         ops.run(buf, lambda which: launch(buf, which))
 
@@ -242,15 +298,61 @@ class RowBlockAMG:
         return r
 
     def smooth(self, level, n_it, b, x):
+        """n_it sweeps with one halo exchange per sweep (levels without a ghost-line plan)."""
         ops, p = self.A_ops[level], self.A_ops[level].part
         w = float(torch.tensor(self.w, dtype=b.dtype))
-        cur, nxt = p.new_buffer(1, b.dtype, b.device), p.new_buffer(1, b.dtype, b.device)
+        bufs = ops._lib_send.get(("smooth", b.dtype))
+        if bufs is None:
+            bufs = ops._lib_send[("smooth", b.dtype)] = (p.new_buffer(1, b.dtype, b.device), p.new_buffer(1, b.dtype, b.device))
+        cur, nxt = bufs
         cur[:p.n_in] = x
         for _ in range(n_it):
             src, dst = cur, nxt[:p.n_local]
             ops.run(src, lambda which: ops.plan.jacobi_sweep(self.diag[level], b, src, dst, w, which))
             cur, nxt = nxt, cur
         return cur[:p.n_local].clone()
+
+    def _ghost_operands(self, level, b, x):
+        """The extended operands of a ghost-line level with this rank's b (None: keep the last one) and x and their ghost lines."""
+        ops = self.A_ops[level]
+        e = ops.ext
+        a = e["amg"]
+        off, nl = e["off"], ops.part.n_local
+        own = lambda v: v[off:off + nl]                      # noqa: E731
+        vecs = []
+        if b is not None:
+            own(a["b"]).copy_(b.reshape(-1))
+            vecs.append(a["b"])
+        own(a["x"]).copy_(x.reshape(-1))
+        vecs.append(a["x"])
+        ops._fill_ghosts(vecs, ops._ghost_exchange([own(v) for v in vecs]))
+        ops._ghost_pending = None
+        return a["d"], a["b"], a["x"], own
+
+    def presmooth_residual(self, level, b, x):
+        """n_pre sweeps and r = b - A x of the result.  Ghost-line levels: ONE exchange ([b, x] ghost lines) and ONE pass of the
+        temporally blocked kernel (gla_jacobi_fused_residual) on the extended block; other levels: one exchange per sweep + one
+        for the residual.  Per row the arithmetic of single sweeps / gla_residual: bit-identical either way."""
+        ops = self.A_ops[level]
+        w = float(torch.tensor(self.w, dtype=b.dtype))
+        if ops.ext is not None and b.shape[1] == 1 and 1 <= self.n_pre < ops.TS_MAX:      # (n_pre sweeps + the residual level <= ghost lines)
+            d_e, b_e, x_e, own = self._ghost_operands(level, b, x)
+            plan = ops.ext["plan"]
+            xr = plan.jacobi_sweeps_residual(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_pre)
+            if xr is not None:
+                return own(xr[0]).clone(), own(xr[1]).clone()
+            x1 = plan.jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_pre)       # (rows within n_pre lines of the
+            return own(x1).clone(), own(plan.residual(b_e.reshape(-1, 1), x1)).clone()               #  extension's ends are not valid: never read)
+        x = self.smooth(level, self.n_pre, b, x)
+        return x, self.residual(b, x, level)
+
+    def postsmooth(self, level, b, x):
+        ops = self.A_ops[level]
+        w = float(torch.tensor(self.w, dtype=b.dtype))
+        if ops.ext is not None and b.shape[1] == 1 and 1 <= self.n_post <= ops.TS_MAX and 1 <= self.n_pre < ops.TS_MAX:
+            d_e, b_e, x_e, own = self._ghost_operands(level, None, x)      # (b and its ghost lines are still there from the pre-smoothing)
+            return own(ops.ext["plan"].jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_post)).clone()
+        return self.smooth(level, self.n_post, b, x)
 
     def restrict(self, level, r):
         ops = self.Pt_ops[level]
@@ -264,26 +366,26 @@ class RowBlockAMG:
         self._apply(ops, xc, lambda buf, which: ops.plan.spmm(buf, out=out, which=which))
         return out
 
+    def correct(self, level, x, xc):
+        """x + P xc in one pass (gla_spmm_add) after one halo exchange of xc."""
+        ops = self.P_ops[level]
+        out = torch.empty_like(x)
+        self._apply(ops, xc, lambda buf, which: ops.plan.spmm_add(x, buf, out=out, which=which))
+        return out
+
     def cycle(self, b, x, level=0):
         """One V-cycle on this rank's rows: b, x are the LOCAL parts ([n_local, 1]) of the level vectors."""
-        if level == self.n_levels - 1:
-            C = self.coarse
+        if level == self.n_dist:
+            # replicated from here on: one all-gather of the right-hand side, the rest of the cycle on this GPU alone
             lo, hi = self.blocks[level][self.rank]
-            b_full = self.gather(b, level)
-            if C.lu is not None:
-                return torch.linalg.lu_solve(C.lu[0], C.lu[1], b_full)[lo:hi].contiguous()
-            x_full = self.gather(x, level)
-            g = torch.tensor(C.bounds, dtype=b.dtype)
-            for _ in range(C.sweeps):
-                x_full = chebyshev_relax(C.plan, b_full.contiguous(), x_full.contiguous(), g, C.deg,
-                                         need_gathered=False)[0]
+            b_full = self.gather(b, level).contiguous()
+            x_full = self.sub.H.cycle(b_full, torch.zeros_like(b_full), self.sub.level)
             return x_full[lo:hi].contiguous()
-        x = self.smooth(level, self.n_pre, b, x)
-        r = self.residual(b, x, level)
+        x, r = self.presmooth_residual(level, b, x)
         rc = self.restrict(level, r)
         xc = self.cycle(rc, torch.zeros_like(rc), level + 1)
-        x = x + self.prolong(level, xc)
-        return self.smooth(level, self.n_post, b, x)
+        x = self.correct(level, x, xc)
+        return self.postsmooth(level, b, x)
 
 
 class _OnDev:

@@ -205,9 +205,20 @@ def _amg_worker(rank, world, port, q):
         n = m * m
         A = gla.VCycle._as_sparse(ei, ev, (n, n))
         V = gla.VCycle
-        for kwargs in (dict(coarse_solver="dense"), dict(coarse_deg=8)):
-            H = V.AMGHierarchy(A, levels=3, splitting=V.GridSplitting(m, m), **kwargs)
-            D = RowBlockAMG(H, overlap=True)
+        from gnn_applied_linear_algebra_amd import dist as gdist
+        # (agglomerate_below: rows per rank under which a level is replicated.  0: only the coarsest level is -- every other
+        #  level distributed, the ghost-line route wherever a rank holds >= 8 grid lines; 600: level 1 (1024 rows) and below
+        #  run replicated on every rank)
+        for kwargs, agg in ((dict(coarse_solver="dense"), 0), (dict(coarse_deg=8), 0), (dict(coarse_solver="dense"), 600),
+                            (dict(coarse_deg=8, levels=4), 0)):
+            kwargs = dict(kwargs)
+            levels = kwargs.pop("levels", 3)
+            H = V.AMGHierarchy(A, levels=levels, splitting=V.GridSplitting(m, m), **kwargs)
+            D = RowBlockAMG(H, overlap=True, agglomerate_below=agg)
+            assert D.n_dist == (1 if agg else levels - 1), (D.n_dist, agg)
+            assert D.A_ops[0].ext is not None, "level 0: >= 8 grid lines per rank, the ghost-line route"
+            lo0, hi0 = D.blocks[0][rank]
+            assert lo0 % m == 0 and hi0 % m == 0, "row blocks of a stencil level are whole grid lines"
             gen = torch.Generator().manual_seed(5)
             b = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
             x_ref = torch.zeros_like(b)
@@ -215,8 +226,14 @@ def _amg_worker(rank, world, port, q):
             b_loc = D.local(b)
             for _ in range(3):
                 x_ref = H.cycle(b, x_ref)
+                e0 = gdist.EXCHANGES[0]
                 x_loc = D.cycle(b_loc, x_loc)
+                n_ex = gdist.EXCHANGES[0] - e0
                 assert torch.equal(x_loc, D.local(x_ref)), "distributed cycle differs from the single-rank cycle"
+            # exchanges per cycle: 4 per ghost-line level (ghost lines of [b, x]; halo of r; halo of xc; ghost lines of x),
+            # n_pre + n_post + 3 on a level without a ghost-line plan, + 1 gather at the hand-over to the replicated levels
+            ghost_lv = sum(1 for o in D.A_ops if o.ext is not None)
+            assert n_ex == 4 * ghost_lv + 9 * (D.n_dist - ghost_lv) + 1, (n_ex, ghost_lv, D.n_dist)
             r_loc = D.residual(b_loc, x_loc)
             assert torch.equal(r_loc, D.local(H.residual(b, x_ref)))
             rn = torch.sum(r_loc * r_loc).cpu()
@@ -342,19 +359,21 @@ def _amg_dist_setup_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import gnn_applied_linear_algebra_amd as gla
-        from gnn_applied_linear_algebra_amd.dist_amg import RowBlockAMG, even_blocks, _row_slice
+        from gnn_applied_linear_algebra_amd.dist_amg import RowBlockAMG, line_blocks, _row_slice
         dev = torch.device("cuda:0")
         V = gla.VCycle
         m = 63
         n = m * m
         ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 2.0], device=dev)
-        lo, hi = even_blocks(n, world)[rank]
+        lo, hi = line_blocks(n, world, m)[rank]                     # whole grid lines
         e_l, v_l = _row_slice(ei, ev, lo, hi)                       # all this rank is given: its rows of A
-        for kwargs in (dict(coarse_solver="dense"), dict(coarse_deg=8)):
+        for kwargs, agg in ((dict(coarse_solver="dense"), 0), (dict(coarse_deg=8), 0), (dict(coarse_solver="dense"), 600)):
             H = V.AMGHierarchy(V._as_sparse(ei, ev, (n, n)), levels=3, splitting=V.GridSplitting(m, m), **kwargs)
-            D = RowBlockAMG.distributed_setup(e_l, v_l, n, levels=3, splitting=V.GridSplitting(m, m), **kwargs)
-            assert D.n_levels == len(H.A) == 3
-            for lv in range(3):                                     # every level operator: this rank's rows, bit for bit
+            D = RowBlockAMG.distributed_setup(e_l, v_l, n, levels=3, splitting=V.GridSplitting(m, m), agglomerate_below=agg,
+                                              **kwargs)
+            assert D.n_levels == len(H.A) == 3 and D.n_dist == (1 if agg else 2)
+            assert D.A_ops[0].ext is not None
+            for lv in range(D.n_dist):                              # every distributed level operator: this rank's rows, bit for bit
                 h_ei, h_ea, _, h_dg = H.gnn[lv]
                 blo, bhi = D.blocks[lv][rank]
                 w_ei, w_ev = _row_slice(h_ei, h_ea, blo, bhi)
