@@ -837,7 +837,8 @@ def multi_gpu(args, gla, dev, world, rank):
         "roofline": roof,
     }
     del pr, drv
-    torch.cuda.empty_cache()
+    # (the allocator's cache is KEPT: the strong-scaling block below is no larger than this one, and fresh hipMallocs of
+    #  several GB -- first touch, page tables -- cost seconds, tens of seconds when ranks share a GPU in a rehearsal)
 
     # ---- BASELINE config 4: FIXED strong_grid^2 Laplacian cut into `world` row blocks, and the 1-GPU rate of the
     #      same matrix measured by rank 0 alone in this run (the other ranks wait at the barrier) -------------------
@@ -859,7 +860,6 @@ def multi_gpu(args, gla, dev, world, rank):
         rec.update({"bytes_moved_GBps_per_gpu": round(m4 / t4 / 1e9, 1), "frac_per_gpu": round(m4 / t4 / HBM_PEAK, 4),
                     "passes_per_step": ps4})
         del p4, d4
-        torch.cuda.empty_cache()
         t1 = None
         if rank == 0 and not args.single_device:
             jac = gla.JacobiGNN.JacobiGNN()

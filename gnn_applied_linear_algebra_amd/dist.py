@@ -28,6 +28,20 @@ class _Done:
         return True
 
 
+def _tlog(msg, _t=[None]):
+    """Setup-phase progress on stderr when GLA_DIST_LOG is set (rank 0): seconds since the previous mark."""
+    import os
+    if not os.environ.get("GLA_DIST_LOG") or (dist.is_initialized() and dist.get_rank() != 0):
+        return
+    import sys
+    import time
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    now = time.time()
+    print(f"  dist setup: +{0.0 if _t[0] is None else now - _t[0]:6.2f} s  {msg}", file=sys.stderr, flush=True)
+    _t[0] = now
+
+
 EXCHANGES = [0]      # collectives on the data path issued by this process (halo / ghost-line all-gathers, vector gathers): for reports
 
 class LibComm:
@@ -184,7 +198,8 @@ class RowBlockPartition:
         if col.numel() and (int(col.min()) < 0 or int(col.max()) >= in_blocks[-1][1]):
             raise ValueError("edge columns outside the input vector")
 
-        # the off-block input entries this rank reads (setup-time object collective, small)
+        _tlog("partition: blocks known")
+        # the off-block input entries this rank reads
         off = (col < self.in_lo) | (col >= self.in_hi)
         need = torch.unique(col[off]).cpu()                       # sorted global ids
         if self.distributed:
@@ -214,6 +229,7 @@ class RowBlockPartition:
             col_local[off] = self.n_in + slot_d[pos]
         self.edge_index_local = torch.stack([row - self.row_lo, col_local])
         self.n_cols_local = self.n_in + self.halo_size
+        _tlog("partition: halo lists and local column numbering")
         self._send_bufs, self._send_flip = {}, 0
 
     # ---- buffers / exchange -------------------------------------------------------------------------
@@ -261,6 +277,7 @@ class RowBlockOps:
         self.overlap = bool(overlap) and p.world > 1 and p.S > 0
         if self.overlap:
             self.plan.classify_tiles(p.n_in)
+        _tlog("block plan built")
         # exchange route: libgla_hip's own RCCL communicator (stream-ordered, no host wait) for GPU ranks of an RCCL
         # group; torch.distributed collectives driven from Python otherwise (gloo rehearsals, CPU index tests)
         self.comm = None
@@ -342,6 +359,7 @@ class RowBlockOps:
         want = torch.cat([torch.arange(glo, lo), torch.arange(hi, ghi)])
         ev = edge_attr[:, 0] if edge_attr.dim() == 2 else edge_attr
         g_ei, g_ev = _publish_rows(edgeij_pair, ev, lo, hi, _all_wanted(want, p.group), p.group)
+        _tlog("ghost rows of the matrix fetched")
         all_ei = torch.cat([g_ei[:, g_ei[0] < lo], edgeij_pair, g_ei[:, g_ei[0] >= hi]], 1)
         all_ev = torch.cat([g_ev[g_ei[0] < lo], ev.reshape(-1), g_ev[g_ei[0] >= hi]])
         inside = (all_ei[1] >= elo) & (all_ei[1] < ehi)
@@ -353,6 +371,7 @@ class RowBlockOps:
             sched = plan.jacobi_schedule(4 * T, all_ev.dtype)
             good = int((not need_jacobi_passes or 1 < max(sched) <= T) and int(plan.info.dia_stride) == S)
             self._sched = plan.jacobi_schedule
+        _tlog("extended plan built")
         goods = [None] * p.world
         dist.all_gather_object(goods, good, group=p.group)
         if not all(goods):
@@ -593,6 +612,31 @@ class RowBlockJacobi(RowBlockOps):
         bufs[K] = (d_ext, b_ext, cur, nxt, tmp)
         self._ghost_pending = None
         return own(cur).unsqueeze(1).clone()
+
+    def capture_forward(self, n_iters, vertex_attr, g):
+        """forward(n_iters, vertex_attr, g) captured into a HIP graph (torch.cuda.CUDAGraph): returns run(vertex_attr) -> x.
+        The exchange-per-sweep loop is ~6 enqueues per sweep (pack, event record / wait, ncclAllGather on the library's side
+        stream, two launches): 29 us of host time per sweep eager, 17 us replayed (tools/graph_dist_loop.py, one-rank RCCL
+        communicator, bit-identical) -- for hosts that cannot keep the launch queue ahead of ~0.1 ms sweeps.  `g` must be a CPU
+        tensor or already read (no device-to-host copy inside a capture); operands keep the captured shape."""
+        dev = vertex_attr.device
+        static_va = vertex_attr.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                        # warm-up off the capture: lazy allocations, code loads
+            for _ in range(2):
+                self.forward(n_iters, static_va, g)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward(n_iters, static_va, g)
+
+        def run(va):
+            static_va.copy_(va)
+            graph.replay()
+            return out.clone()
+        run.graph = graph
+        return run
 
     def forward(self, n_iters, vertex_attr, g):
         p = self.part

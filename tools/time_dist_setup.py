@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does the construction of dist.RowBlockJacobi spend its time?  W gloo ranks sharing one GPU, an N x (W N) Laplacian
 split in W row blocks; rank 0 runs the constructor under cProfile and prints the top entries.
-Usage: python tools/time_dist_setup.py [N=4096] [W=2]"""
+Usage: [GLA_NX=8192] python tools/time_dist_setup.py [N=4096 lines per rank] [W=2]"""
 import cProfile, os, pstats, sys, time
 import torch, torch.distributed as dist, torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,15 +15,16 @@ def worker(rank, W, N, port):
     import gnn_applied_linear_algebra_amd as gla
     from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi
     dev = torch.device("cuda:0")
-    n_local = N * N
+    Nx = int(os.environ.get("GLA_NX", N))                   # (GLA_NX: grid-line length, N lines per rank)
+    n_local = Nx * N
     lo, hi = rank * n_local, (rank + 1) * n_local
-    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, Ny=N * W, row_range=(lo, hi), device=dev)
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(Nx, Ny=N * W, row_range=(lo, hi), device=dev)
     ev = torch.cat([ev, torch.zeros_like(ev)], 1)
     torch.cuda.synchronize(); dist.barrier()
     t0 = time.time()
     pr = cProfile.Profile() if rank == 0 else None
     if pr: pr.enable()
-    drv = RowBlockJacobi(ei, ev, N * N * W, lo, hi)
+    drv = RowBlockJacobi(ei, ev, Nx * N * W, lo, hi)
     torch.cuda.synchronize()
     if pr: pr.disable()
     dist.barrier()
