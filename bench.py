@@ -565,7 +565,9 @@ def single_gpu(args, gla, dev):
         g3 = torch.zeros(3, K, dtype=torch.float64)
         el_p, ms_p = timed_steps(lambda: pw(vp, pr.ei, pr.edge_attr, g3), 5, 2)
         Bp = 11 * (base + 16 * n * K) + 6 * 8 * n * K
-        Mp = 11 * (mat + 16 * n * K) + 6 * 8 * n * K          # one pass of the matrix + y in / out per iteration, the tail's vectors
+        tmax_p = gla.plan_for(pr.ei, pr.n_local, edge_attr=pr.edge_attr).power_fused_max_iters(K, torch.float64)
+        passes_p = -(-10 // tmax_p) if tmax_p >= 2 else 10   # temporally blocked: up to five iterations per pass (gla_power_fused)
+        Mp = (passes_p + 1) * (mat + 16 * n * K) + 6 * 8 * n * K      # matrix + y in / out per pass (+ the Rayleigh pass), the tail's vectors
         tc, tpw = median(ms_c) * 1e-3, median(ms_p) * 1e-3
         # JacobiGNN on the same 16 right-hand sides (vertex_attr [n, 3, K]): temporally blocked passes of four sweeps
         vj = torch.stack([torch.full_like(b16, -4.0), b16, x16], 1)
@@ -582,7 +584,7 @@ def single_gpu(args, gla, dev):
                     "several steps share a pass (ChebyRelaxGNN(4): ONE temporally blocked pass, gla_cheby_fused)",
             "cheby_deg4_ms": round(tc * 1e3, 3), "cheby_bytes_moved": Mc, "cheby_GBps": round(Mc / tc / 1e9, 1),
             "cheby_frac": round(Mc / tc / HBM_PEAK, 4), "cheby_model_ratio": round(Bc / tc / HBM_PEAK, 4),
-            "power_10its_ms": round(tpw * 1e3, 3), "power_bytes_moved": Mp, "power_GBps": round(Mp / tpw / 1e9, 1),
+            "power_10its_ms": round(tpw * 1e3, 3), "power_passes": passes_p, "power_bytes_moved": Mp, "power_GBps": round(Mp / tpw / 1e9, 1),
             "power_frac": round(Mp / tpw / HBM_PEAK, 4), "power_model_ratio": round(Bp / tpw / HBM_PEAK, 4),
             "jacobi_ms_per_sweep": round(tj * 1e3, 4), "jacobi_bytes_moved_per_sweep": int(Mj16),
             "jacobi_GBps": round(Mj16 / tj / 1e9, 1), "jacobi_frac": round(Mj16 / tj / HBM_PEAK, 4),

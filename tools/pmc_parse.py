@@ -28,7 +28,7 @@ def sweeps_of(name):
 
 
 rows = []
-for f in glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv")):
+for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     rows += list(csv.DictReader(open(f)))
 # the workload's sweeps may be a mix of passes (20 = 7 + 7 + 6): keep the dominant kernel (the one covering most sweeps)
 cover = collections.Counter()
