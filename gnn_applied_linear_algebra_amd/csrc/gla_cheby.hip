@@ -275,6 +275,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
   for (int t = 0; t < DEG; ++t) cr[t] = cx[t] = TV(T(0));
 
   auto do_step = [&](const int jl, const int u) {
+    if ((jl & 1) ^ (((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
     __syncthreads();
     const int pj = (jl + 64) & 1;
     TV* const row_e = buf + pj * LWV + ii * KV + q;          // lines of the parity of jl: [0] left, [KV] own, [2 KV] right
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march9_kernel(
   for (int t = 0; t < DEG; ++t) cr[t] = cx[t] = TV(T(0));
 
   auto do_step = [&](const int jl, const int u) {
+    if ((jl & 1) ^ (((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
     const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
     // LDS rows of the lines jl + 1, jl, jl - 1 (operand of step 1): [0] left, [KV] own, [2 KV] right of this lane's point
     TV* const rw[3] = {buf + s1 * LWV + ii * KV + q, buf + s0 * LWV + ii * KV + q, buf + s2 * LWV + ii * KV + q};

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_marchk_kernel(JacK jv, const
   for (int s = 0; s < NC; ++s) cfull[s] = false;
 
   auto do_step = [&](const int jl, const int u, const int nact) {
+    if ((jl & 1) ^ (((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
     if constexpr (D == 5) {
       // 5-point: a level only needs the i -/+ 1 neighbours of ITS OWN line, which the level below wrote one line step
       // earlier: two lines per level (slot = line parity) and ONE barrier per line step (as jacobi_march5 / cheby_march5)

@@ -1287,6 +1287,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
   for (int s = 0; s < NC; ++s) cfull[s] = false;
 
   auto do_step = [&](const int jl, const int u, const int nact) {
+    if ((jl & 1) ^ (((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
     // LDS rows of the lines jl + 1, jl, jl - 1 (mod 3): level t reads lines jl - t + 2, jl - t + 1, jl - t of level t - 1 --
     // the same three rows rotated by t - 1
     const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
