@@ -2061,3 +2061,66 @@ def test_power_fused_pass_matches_step_by_step():
                 want_va, _, want_g = rp.power_forward(10, torch.cat([bk, torch.zeros_like(bk)], 1), ei, ea2, torch.zeros(3, dtype=torch.float64))
                 close(g[:, k], want_g, rtol=1e-11)
                 np.testing.assert_allclose(va[:, 0, k].cpu().numpy(), want_va[:, 0].numpy(), rtol=1e-9, atol=1e-14)
+
+
+def test_jacobi_march_division_fallback_special_values():
+    """The temporally blocked 5-point pass divides through RN(1 / A_ii) + one Markstein correction and redoes a line step with
+    the IEEE division wherever that is not provably the correctly rounded quotient: zero / -0 / denormal / huge / Inf / NaN
+    numerators, divisors with an all-ones significand, extreme and denormal divisors, rows with holes in the pattern.  Every
+    pass size against single sweeps of the same plan, bit for bit (a NaN matches any NaN: sign / payload follow operand order)."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+    Nx, Ny = 300, 120
+    n = Nx * Ny
+    ei, ev = rp.laplacianfun_torch(Nx, Ny)
+    gen = torch.Generator().manual_seed(21)
+    ev = ev * (1.0 + 0.25 * torch.rand(ev.shape, generator=gen, dtype=torch.float64))
+    keep = torch.ones(ei.shape[1], dtype=torch.bool)
+    holes = (ei[0] % 977 == 5) & (ei[1] == ei[0] - 1)              # some rows lose their left neighbour
+    keep[holes] = False
+    ei, ev = ei[:, keep], ev[keep]
+    b = torch.rand(n, generator=gen, dtype=torch.float64)
+    x = torch.rand(n, generator=gen, dtype=torch.float64)
+    diag = -4.0 - torch.rand(n, generator=gen, dtype=torch.float64)
+    k = torch.arange(n) % 4099
+    b[k == 1] = 0.0
+    x[k == 2] = 0.0
+    b[k == 2] = 0.0
+    diag[k == 3] = float.fromhex("0x1.fffffffffffffp+1")          # all-ones significand
+    diag[k == 4] = 2.0 ** -600                                    # extreme divisor
+    b[k == 5] = 2.0 ** 600
+    b[k == 6] = 2.0 ** -700
+    b[k == 7] = -0.0
+    b[(k == 8) & (torch.arange(n) % 8198 == 8)] = float("inf")
+    b[(k == 9) & (torch.arange(n) % 40990 == 9)] = float("nan")
+    diag[k == 10] = 2.0 ** -1040                                  # denormal divisor
+    b[n // 2:n // 2 + 20 * Nx] = 0.0                              # a region of exact zeros: numerators +-0
+    x[n // 2:n // 2 + 20 * Nx] = torch.where(torch.arange(20 * Nx) % 2 == 0, 0.0, -0.0).to(torch.float64)
+    plan = gla.CsrPlan(d(ei), n)
+    plan.set_values(d(ev))
+    if plan.jacobi_schedule(7) != (7,):
+        pytest.skip("no march kernel under these GLA_OPTIONS")
+    dD, bD, xD = d(diag), d(b.reshape(-1, 1)), d(x.reshape(-1, 1))
+
+    def same(a, w):
+        a, w = a.cpu().reshape(-1), w.cpu().reshape(-1)
+        return bool(((a == w) | (torch.isnan(a) & torch.isnan(w))).all()) and \
+            bool((torch.signbit(a) == torch.signbit(w))[~torch.isnan(a)].all())
+    for ts in (2, 3, 5, 7, 8):
+        try:
+            check(lib().gla_set_option(b"jacobi_fuse", 0))
+            want = plan.jacobi_sweeps(dD, bD, xD, 0.7, ts)
+        finally:
+            check(lib().gla_set_option(b"jacobi_fuse", 1))
+        got = plan.jacobi_sweeps(dD, bD, xD, 0.7, ts)
+        assert plan.jacobi_schedule(ts) == (ts,)
+        assert same(got, want), ts
+        xr = plan.jacobi_sweeps_residual(dD, bD, xD, 0.7, min(ts, 7))
+        if xr is not None:
+            try:
+                check(lib().gla_set_option(b"jacobi_fuse", 0))
+                w2 = plan.jacobi_sweeps(dD, bD, xD, 0.7, min(ts, 7))
+                r2 = plan.residual(bD, w2)
+            finally:
+                check(lib().gla_set_option(b"jacobi_fuse", 1))
+            assert same(xr[0], w2) and same(xr[1], r2), ("residual", ts)
