@@ -48,6 +48,7 @@ struct M5View {
   int64_t S, n_rows, nlines;  // grid line length, rows (= columns), grid lines (the last one may be ragged)
   int32_t edge, nlb;          // multi-GPU interior / boundary split: height of the first / last line block (0: uniform), line blocks
   int64_t aos_off, aos_rows;  // MODE 1: plan row r is row r - aos_off of an AoS tensor of aos_rows rows
+  int64_t aos_wlo, aos_whi;   // MODE 1: grid lines [aos_wlo, aos_whi) get their contiguous copies of A_ii and b written by this launch
 };
 
 // line block lb: lines [J0, J0 + L) of the grid
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       }
       cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all((cu.m & 0x1f) == em && dok) != 0;
       if constexpr (AOS) {                         // the row's owner leaves contiguous copies of A_ii and b
-        if (jl >= 0 && jl < L && owner && live_at(jl)) {
+        if (jl >= 0 && jl < L && owner && live_at(jl) && gj >= dv.aos_wlo && gj < dv.aos_whi) {
           const int64_t r = gj * dv.S + gi;
           diag_out[r] = cu.dg;
           b_out[r] = cu.b;
@@ -362,6 +363,11 @@ int m5_launch(const gla_march5_args& a) {
   dv.aos_off = a.aos_off;
   dv.aos_rows = a.aos_rows >= 0 ? a.aos_rows : A->n_rows;
   const int64_t nlines = dv.nlines;
+  // The interior launch of the multi-GPU split (part 1) leaves the lines the two edge blocks READ (ghost + 2 TS either end,
+  // copied by the host beforehand) alone: the edge launch runs concurrently on a second stream, and the two must not touch
+  // the same words of diag_out / b_out
+  dv.aos_wlo = a.part == 1 ? (int64_t)a.ghost + 2 * TS : 0;
+  dv.aos_whi = a.part == 1 ? dv.nlines - ((int64_t)a.ghost + 2 * TS) : dv.nlines;
   const int bi_eff = GLA_BLOCK - 2 * LV;
   const int nstrips = (int)((A->dia_S + bi_eff - 1) / bi_eff);
   const int part = a.part, ghost = a.ghost;

@@ -548,11 +548,12 @@ class RowBlockJacobi(RowBlockOps):
                 if from_aos:
                     check(lib().gla_jacobi_fused_parts_aos(h, code, ptr(va), va.stride(0), off, nl, ptr(d_ext), ptr(b_ext),
                                                            ptr(nxt), w, ts, 1, T, st))
-                    # the AoS interior launch WRITES the contiguous copies of A_ii and b (d_ext / b_ext) for its own lines, and
-                    # the edge blocks read d_ext / b_ext a few lines into that range: the rows were hand-copied above with the
-                    # same values, but two launches touching the same words concurrently is not a property to rely on -- in this
-                    # one pass the edge blocks are ordered after the interior launch
-                    side.wait_stream(main)
+                    # The AoS interior launch WRITES the contiguous copies of A_ii and b (d_ext / b_ext).  On canonical 5-point
+                    # plans it leaves the T + 2 ts lines either end -- everything the edge blocks read, hand-copied above --
+                    # alone (gla_march5.hip: aos_wlo / aos_whi), so the two launches touch disjoint words.  The other stencil
+                    # kernels write every line they own: there the edge blocks are ordered after the interior launch
+                    if int(e["plan"].info.dia_canon5) != 1:
+                        side.wait_stream(main)
                 else:
                     check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, T, st))
                 with torch.cuda.stream(side):

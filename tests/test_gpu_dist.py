@@ -521,8 +521,17 @@ def test_temporal_route_self_halo_rccl(Nx, Ny):
             check(lib().gla_set_option(b"jacobi_fuse", 1))
         for overlap in (True, False):
             drv.overlap = overlap
+            # poison the persistent extended copies of A_ii and b: the first (AoS) pass must rebuild every row it or a later pass
+            # reads -- the interior launch its lines, the hand copies the lines the edge blocks read -- with no overlap between
+            # what the two concurrent launches write and read
+            nan = float("nan")
+            drv.ext["buffers"] = (torch.full((n_ext,), nan, dtype=torch.float64, device=dev), torch.full((n_ext,), nan, dtype=torch.float64, device=dev),
+                                  torch.zeros(n_ext, dtype=torch.float64, device=dev), torch.zeros(n_ext, dtype=torch.float64, device=dev))
             got = drv.forward(its, va, g)
             assert torch.equal(got.reshape(-1), x), (its, overlap, float((got.reshape(-1) - x).abs().max()))
+            d_ext, b_ext = drv.ext["buffers"][0], drv.ext["buffers"][1]
+            assert torch.equal(d_ext[off:off + n], va[:, 0]) and torch.equal(b_ext[off:off + n], va[:, 1]), (its, overlap)
+            assert torch.equal(d_ext, d_e) and torch.equal(b_ext, b_e), (its, overlap, "ghost lines of A_ii / b")
     torch.cuda.synchronize()
 
 
