@@ -363,19 +363,25 @@ int m5_launch(const gla_march5_args& a) {
   dv.aos_off = a.aos_off;
   dv.aos_rows = a.aos_rows >= 0 ? a.aos_rows : A->n_rows;
   const int64_t nlines = dv.nlines;
-  // The interior launch of the multi-GPU split (part 1) leaves the lines the two edge blocks READ (ghost + 2 TS either end,
-  // copied by the host beforehand) alone: the edge launch runs concurrently on a second stream, and the two must not touch
-  // the same words of diag_out / b_out
-  dv.aos_wlo = a.part == 1 ? (int64_t)a.ghost + 2 * TS : 0;
-  dv.aos_whi = a.part == 1 ? dv.nlines - ((int64_t)a.ghost + 2 * TS) : dv.nlines;
+  // Height of the first / last line block of the multi-GPU split: ghost + LV lines keep the interior blocks off the ghost
+  // lines (an interior block reads x from LV lines above its first line); at least 2 x ghost, so that the edge launch alone
+  // produces the `ghost` own lines either end that the neighbours want next -- their exchange can start when the edge launch
+  // ends, long before the interior launch does.
+  const int edge_h = a.ghost + LV > 2 * a.ghost ? a.ghost + LV : 2 * a.ghost;
+  // The interior launch (part 1) leaves the lines the two edge blocks READ (edge_h + TS either end, copied by the host
+  // beforehand) alone: the edge launch runs concurrently on a second stream, and the two must not touch the same words of
+  // diag_out / b_out
+  dv.aos_wlo = a.part == 1 ? (int64_t)edge_h + TS : 0;
+  dv.aos_whi = a.part == 1 ? dv.nlines - ((int64_t)edge_h + TS) : dv.nlines;
   const int bi_eff = GLA_BLOCK - 2 * LV;
   const int nstrips = (int)((A->dia_S + bi_eff - 1) / bi_eff);
   const int part = a.part, ghost = a.ghost;
   // Interior / boundary split (part 1 / 2, the multi-GPU route): the first and the last `ghost` grid lines of x arrive while
-  // the interior blocks run, so no interior block may read them: the first and the last line block are ghost + LV lines
-  // high (an interior block reads x from LV lines above its first line), everything between is split as for part 0.
+  // the interior blocks run, so no interior block may read them: the first and the last line block are edge_h lines high
+  // (above), everything between is split as for part 0.
   // Grids too short for that (fewer than 2 edge blocks + 1 line) count as boundary as a whole.
-  const int edge = part != 0 && nlines > 2 * (int64_t)(ghost + LV) ? ghost + LV : 0;
+  const int edge = part != 0 && nlines > 2 * (int64_t)edge_h ? edge_h : 0;
+  (void)ghost;
   const int64_t inner_lines = nlines - 2 * edge;
   int lines = g_tuning.jacobi_lines;
   if (lines <= 0) {
@@ -384,7 +390,13 @@ int m5_launch(const gla_march5_args& a) {
     // three or four even where the registers allow more -- fewer, longer streams; one per CU cannot hide a line step
     int per_cu = m5_blocks_per_cu<T, TS, MODE>();
     if (per_cu > 2) per_cu = 2;
-    lines = gla_pick_block_lines(inner_lines, nstrips, 256 * per_cu, 2 * (LV - 1), 2 * LV);
+    // Interior / boundary split: the interior launch leaves 2 x nstrips workgroup slots FREE for the two edge line blocks that
+    // a second stream launches once the ghost lines are in.  A march workgroup takes half a CU's registers, so on a chip full
+    // of interior workgroups the edge launch (and even the small ghost-fill kernel before it) waits for the interior launch
+    // to drain -- 54 us behind it instead of beside it (kernel trace of the one-GPU rehearsal, profiles/r03).
+    int64_t slots = 256 * (int64_t)per_cu;
+    if (edge && slots > 4 * (int64_t)nstrips) slots -= 2 * (int64_t)nstrips;
+    lines = gla_pick_block_lines(inner_lines, nstrips, slots, 2 * (LV - 1), 2 * LV);
     if (lines > 1024) lines = 1024;
   }
   if (lines < 2 * LV) lines = 2 * LV;
@@ -402,6 +414,14 @@ int m5_launch(const gla_march5_args& a) {
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = count;
   set_tile_mapping(tm);
+  if (part != 0 && count <= GLA_XCDS * tm.tiles_per_xcd) {
+    // Interior / boundary split: both launches spread their workgroups EVENLY over the XCDs (chunk = an eighth of the launch).
+    // With the default chunk of 64 the 34 edge workgroups all land on XCD 0 -- which the interior launch has filled -- and the
+    // slots the interior launch leaves free all sit on XCD 7: the edge launch then runs behind the interior one, not beside it.
+    const int C = (count + GLA_XCDS - 1) / GLA_XCDS;
+    tm.xcd_chunk = C > 0 ? C : 1;
+    tm.tiles_per_xcd = tm.xcd_chunk;
+  }
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
   hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV)), grid, block, lds, a.st, dv,

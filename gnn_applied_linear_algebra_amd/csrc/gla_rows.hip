@@ -1403,7 +1403,8 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   // the interior blocks run, so no interior block may read them: the first and the last line block are ghost + TS lines
   // high (an interior block reads x from TS lines above its first line), everything between is split as for part 0.
   // Grids too short for that (fewer than 2 edge blocks + 1 line) count as boundary as a whole.
-  const int edge = part != 0 && nlines > 2 * (int64_t)(ghost + TS) ? ghost + TS : 0;
+  const int edge_h = ghost + TS > 2 * ghost ? ghost + TS : 2 * ghost;     // (at least 2 x ghost: gla_march5.hip)
+  const int edge = part != 0 && nlines > 2 * (int64_t)edge_h ? edge_h : 0;
   const int64_t inner_lines = nlines - 2 * edge;
   int lines = g_tuning.jacobi_lines;
   if (lines <= 0) {
@@ -1415,7 +1416,9 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
       if (per_cu > 2) per_cu = 2;
     }
     else per_cu = sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5);
-    lines = gla_pick_block_lines(inner_lines, nstrips, 256 * per_cu, 2 * (TS - 1), 2 * TS);
+    int64_t slots = 256 * per_cu;                     // (interior / boundary split: room for the two edge line blocks, gla_march5.hip)
+    if (edge && slots > 4 * (int64_t)nstrips) slots -= 2 * (int64_t)nstrips;
+    lines = gla_pick_block_lines(inner_lines, nstrips, slots, 2 * (TS - 1), 2 * TS);
     if (lines > 1024) lines = 1024;
   }
   if (lines < 2 * TS && canon9) lines = 2 * TS;
@@ -1433,6 +1436,11 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = count;
   set_tile_mapping(tm);
+  if (part != 0 && count <= GLA_XCDS * tm.tiles_per_xcd) {      // (both launches of the split spread evenly over the XCDs: gla_march5.hip)
+    const int C = (count + GLA_XCDS - 1) / GLA_XCDS;
+    tm.xcd_chunk = C > 0 ? C : 1;
+    tm.tiles_per_xcd = tm.xcd_chunk;
+  }
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   if constexpr (TS <= JACOBI_TS_MAX9) {
     if (canon9) {                                   // the same march for the canonical 9-point pattern

@@ -509,10 +509,10 @@ class RowBlockJacobi(RowBlockOps):
         # r - off) and leave the contiguous copies of A_ii and b behind; only the few lines the two edge blocks touch are
         # copied by hand.  Otherwise (no library communicator, tiny blocks, single sweeps): one split pass into the
         # extended vectors.
-        aos_first = (self.comm is not None and self.overlap and passes[0] > 1 and n_ext // S > 2 * (T + passes[0])
+        aos_first = (self.comm is not None and self.overlap and passes[0] > 1 and n_ext // S > 2 * (2 * T + passes[0])
                      and va.stride(1) == 1)
         if aos_first:
-            E = (T + 2 * passes[0]) * S                      # rows the first / last edge block reads
+            E = (2 * T + passes[0]) * S                      # rows the first / last edge block (2 T lines high) reads
             pairs = []
             for a, b_ in ((0, E), (n_ext - E, n_ext)):
                 a, b_ = max(a, off), min(b_, off + nl)       # ... that are the rank's own
@@ -523,6 +523,7 @@ class RowBlockJacobi(RowBlockOps):
             outs = (ctypes.c_void_p * 3)(own(d_ext).data_ptr(), own(b_ext).data_ptr(), own(cur).data_ptr())
             check(lib().gla_split_columns(code, nl, 3, ptr(va), va.stride(0) if nl > 1 else 3, outs, st))
         first = True
+        prefetched = False
         spare = nxt
         for i, ts in enumerate(passes):
             if i == len(passes) - 1:                         # the last pass writes into a fresh buffer the caller keeps
@@ -543,7 +544,8 @@ class RowBlockJacobi(RowBlockOps):
                 side = e.get("side_stream")
                 if side is None:
                     side = e["side_stream"] = torch.cuda.Stream(device=dev)
-                self._ghost_exchange(owns, begin_only=True)
+                if not prefetched:
+                    self._ghost_exchange(owns, begin_only=True)
                 side.wait_stream(main)                        # cur / nxt as the previous pass left them
                 if from_aos:
                     check(lib().gla_jacobi_fused_parts_aos(h, code, ptr(va), va.stride(0), off, nl, ptr(d_ext), ptr(b_ext),
@@ -560,6 +562,12 @@ class RowBlockJacobi(RowBlockOps):
                     self._fill_ghosts(vecs, self._ghost_finish())
                     check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 2, T,
                                                        stream_ptr(dev)))
+                    # The edge blocks are 2 T lines high: they alone produce the T own lines either end that the neighbours
+                    # want for the NEXT pass, so its exchange starts here, on the second stream, while the interior launch of
+                    # this pass is still running (nothing of it is left on the critical path of the main stream).
+                    prefetched = i + 1 < len(passes) and passes[i + 1] > 1
+                    if prefetched:
+                        self._ghost_exchange([own(nxt)], begin_only=True)
                 main.wait_stream(side)
             else:
                 self._fill_ghosts(vecs, self._ghost_exchange(owns))
