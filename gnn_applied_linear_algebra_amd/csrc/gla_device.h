@@ -30,9 +30,17 @@ struct TileMap {
 inline void set_tile_mapping(TileMap& tm) {
   tm.xcd_chunk = g_tuning.xcd_chunk;
   tm.vec = g_tuning.row_sum;
-  const int C = tm.xcd_chunk > 0 ? tm.xcd_chunk : 1;
-  const int per_round = GLA_XCDS * C;
-  tm.tiles_per_xcd = ((tm.n_tiles + per_round - 1) / per_round) * C;
+  int C = tm.xcd_chunk > 0 ? tm.xcd_chunk : 1;
+  int rounds = (tm.n_tiles + GLA_XCDS * C - 1) / (GLA_XCDS * C);
+  if (rounds < 1) rounds = 1;
+  if (tm.xcd_chunk > 0) {
+    // the tiles spread EVENLY over the XCDs: the chunk shrinks to an eighth of a round's tiles.  With a fixed chunk of 64 a launch
+    // of 64 tiles (a 16 k-row multigrid level, the edge blocks of the multi-GPU split) ran on XCD 0 alone -- 32 of the 256 CUs
+    C = (tm.n_tiles + GLA_XCDS * rounds - 1) / (GLA_XCDS * rounds);
+    if (C < 1) C = 1;
+    tm.xcd_chunk = C;
+  }
+  tm.tiles_per_xcd = rounds * C;
 }
 
 __device__ __forceinline__ int map_tile(const TileMap& m) {

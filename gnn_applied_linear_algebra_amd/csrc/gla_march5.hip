@@ -414,14 +414,6 @@ int m5_launch(const gla_march5_args& a) {
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = count;
   set_tile_mapping(tm);
-  if (part != 0 && count <= GLA_XCDS * tm.tiles_per_xcd) {
-    // Interior / boundary split: both launches spread their workgroups EVENLY over the XCDs (chunk = an eighth of the launch).
-    // With the default chunk of 64 the 34 edge workgroups all land on XCD 0 -- which the interior launch has filled -- and the
-    // slots the interior launch leaves free all sit on XCD 7: the edge launch then runs behind the interior one, not beside it.
-    const int C = (count + GLA_XCDS - 1) / GLA_XCDS;
-    tm.xcd_chunk = C > 0 ? C : 1;
-    tm.tiles_per_xcd = tm.xcd_chunk;
-  }
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
   hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV)), grid, block, lds, a.st, dv,

@@ -1436,11 +1436,6 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = count;
   set_tile_mapping(tm);
-  if (part != 0 && count <= GLA_XCDS * tm.tiles_per_xcd) {      // (both launches of the split spread evenly over the XCDs: gla_march5.hip)
-    const int C = (count + GLA_XCDS - 1) / GLA_XCDS;
-    tm.xcd_chunk = C > 0 ? C : 1;
-    tm.tiles_per_xcd = tm.xcd_chunk;
-  }
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   if constexpr (TS <= JACOBI_TS_MAX9) {
     if (canon9) {                                   // the same march for the canonical 9-point pattern
