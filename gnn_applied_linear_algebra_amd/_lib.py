@@ -48,6 +48,7 @@ SIGNATURES = {
     "gla_csr_classify_tiles": (_I, [_P, _I64, _P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "gla_spmm": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _I, _P]),
     "gla_spmm_add": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
+    "gla_dense_apply": (_I, [_I, _I64, _I64, _P, _I64, _I, _P, _I64, _P, _I64, _P]),
     "gla_residual": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _P, _I64, _I, _P]),
     "gla_jacobi_sweep": (_I, [_P, _I, _I, _P, _P, _I64, _P, _I64, _P, _I64, _D, _I, _P]),
     "gla_jacobi_sweeps": (_I, [_P, _I, _I, _P, _P, _I64, _P, _I64, _P, _P, _I64, _D, _I, _P]),

@@ -356,6 +356,68 @@ __global__ __launch_bounds__(GLA_BLOCK) void pmis_out_kernel(const int8_t* __res
     split[i] = state[i] >= 0 ? 1 : 0;               // C, or still undecided after max_rounds
 }
 
+
+// ---- coarsest-level solve of a deep V-cycle: Y = M X with M = the (small, dense) inverse of the coarsest operator ------------
+// The reference's coarse "solve" is a Chebyshev relaxation (VCycle.py:218-223); a hierarchy deep enough that the coarsest
+// operator is ~1e3 rows is solved exactly instead.  A triangular-solve pair (rocBLAS trsv through torch.linalg.lu_solve)
+// costs 0.66 ms per cycle at 1024 rows -- a quarter of the 8-level cycle on the 4095^2 mesh -- for 8 MB of data; the inverse
+// applied as a matrix-vector product streams those 8 MB in a few microseconds.  One wave per row, lanes stride the columns,
+// KP right-hand sides per pass; the sum over a row's columns has one fixed order whatever K is (lane-strided partial sums,
+// then a butterfly), so column k of a K-wide call is bit-identical to the K = 1 call on that column.
+template <typename T, int KP>
+__global__ __launch_bounds__(GLA_BLOCK) void dense_apply_kernel(const T* __restrict__ M, int64_t ldm, int64_t n_rows,
+                                                                int64_t n_cols, const T* __restrict__ X, int64_t ldx,
+                                                                T* __restrict__ Y, int64_t ldy, int k0, int K) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (GLA_BLOCK / 64) + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const T* __restrict__ mr = M + row * ldm;
+  T acc[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) acc[k] = (T)0;
+  int64_t j = lane;
+  for (; j + 192 < n_cols; j += 256) {                      // four independent loads of the row in flight
+    const T m0 = mr[j], m1 = mr[j + 64], m2 = mr[j + 128], m3 = mr[j + 192];
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      if (k0 + k < K) {
+        acc[k] = fma(m0, X[j * ldx + k0 + k], acc[k]);
+        acc[k] = fma(m1, X[(j + 64) * ldx + k0 + k], acc[k]);
+        acc[k] = fma(m2, X[(j + 128) * ldx + k0 + k], acc[k]);
+        acc[k] = fma(m3, X[(j + 192) * ldx + k0 + k], acc[k]);
+      }
+  }
+  for (; j < n_cols; j += 64) {
+    const T m0 = mr[j];
+#pragma unroll
+    for (int k = 0; k < KP; ++k)
+      if (k0 + k < K) acc[k] = fma(m0, X[j * ldx + k0 + k], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    T v = acc[k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0 && k0 + k < K) Y[row * ldy + k0 + k] = v;
+  }
+}
+
+template <typename T>
+int dense_apply_impl(int64_t n_rows, int64_t n_cols, const T* M, int64_t ldm, int K, const T* X, int64_t ldx, T* Y,
+                     int64_t ldy, hipStream_t st) {
+  const unsigned nb = (unsigned)((n_rows + GLA_BLOCK / 64 - 1) / (GLA_BLOCK / 64));
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    if (K - k0 == 1)
+      hipLaunchKernelGGL((dense_apply_kernel<T, 1>), dim3(nb), dim3(GLA_BLOCK), 0, st, M, ldm, n_rows, n_cols, X, ldx, Y, ldy, k0, K);
+    else if (K - k0 <= 4)
+      hipLaunchKernelGGL((dense_apply_kernel<T, 4>), dim3(nb), dim3(GLA_BLOCK), 0, st, M, ldm, n_rows, n_cols, X, ldx, Y, ldy, k0, K);
+    else
+      hipLaunchKernelGGL((dense_apply_kernel<T, 8>), dim3(nb), dim3(GLA_BLOCK), 0, st, M, ldm, n_rows, n_cols, X, ldx, Y, ldy, k0, K);
+    GLA_LAUNCH_CHECK();
+  }
+  return GLA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -465,6 +527,20 @@ int gla_coo_coalesce(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t*
                                  (double*)val_out, nnz_out_host, (hipStream_t)stream);
   return coalesce_impl<float>(n_rows, n_cols, nnz, row, col, (const float*)val, val_stride, row_out, col_out,
                               (float*)val_out, nnz_out_host, (hipStream_t)stream);
+}
+
+int gla_dense_apply(int dtype, int64_t n_rows, int64_t n_cols, const void* M, int64_t ldm, int K, const void* X, int64_t ldx,
+                    void* Y, int64_t ldy, gla_stream_t stream) {
+  if ((dtype != GLA_F32 && dtype != GLA_F64) || n_rows < 0 || n_cols < 0 || K < 1 || ldm < n_cols || ldx < K || ldy < K)
+    return GLA_ERR_INVALID_ARG;
+  if (n_rows == 0) return GLA_OK;
+  if (!Y || X == Y || (n_cols > 0 && (!M || !X))) return GLA_ERR_INVALID_ARG;
+  if (n_rows > ((int64_t)1 << 31) - 1) return GLA_ERR_UNSUPPORTED;
+  if (dtype == GLA_F64)
+    return dense_apply_impl<double>(n_rows, n_cols, (const double*)M, ldm, K, (const double*)X, ldx, (double*)Y, ldy,
+                                    (hipStream_t)stream);
+  return dense_apply_impl<float>(n_rows, n_cols, (const float*)M, ldm, K, (const float*)X, ldx, (float*)Y, ldy,
+                                 (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -127,6 +127,13 @@ int gla_spmm(gla_csr_t A, int dtype, int K, const void* X, int64_t ldx, void* Y,
 int gla_spmm_add(gla_csr_t A, int dtype, int K, const void* Z, int64_t ldz, const void* X, int64_t ldx, void* Y,
                  int64_t ldy, int which_tiles, gla_stream_t stream);
 
+/* Y = M X, M dense row-major [n_rows, n_cols] (leading dimension ldm), X [n_cols, K], Y [n_rows, K]; Y must not alias X.
+ * The coarsest-level solve of a deep V-cycle: M = the inverse of the (small) coarsest operator, factored once at setup --
+ * in place of the reference's Chebyshev coarse "solve" (VCycle.py:218-223) where the hierarchy is deep enough for an exact
+ * one.  Column k of the result does not depend on K (fixed summation order per row). */
+int gla_dense_apply(int dtype, int64_t n_rows, int64_t n_cols, const void* M, int64_t ldm, int K, const void* X,
+                    int64_t ldx, void* Y, int64_t ldy, gla_stream_t stream);
+
 /* R = B - A X.  GNNResidual.py:43-132 (r_i = b_i - cbar_i, :110). */
 int gla_residual(gla_csr_t A, int dtype, int K, const void* B, int64_t ldb, const void* X, int64_t ldx,
                  void* R, int64_t ldr, int which_tiles, gla_stream_t stream);

@@ -814,9 +814,60 @@ def test_amg_cycle_multi_rhs_columns():
         if solver == "cheby":
             for k in range(4):
                 eq(X[:, k:k + 1], cols[k])
-        else:                                   # the dense LU solve of the coarsest level is a torch GEMM-style op:
-            for k in range(4):                  # its K = 4 and K = 1 code paths may round differently
-                close(X[:, k:k + 1], cols[k], rtol=1e-10)
+        else:                                   # the coarsest level's inverse applied by gla_dense_apply: a row's sum has
+            for k in range(4):                  # one order whatever K is
+                eq(X[:, k:k + 1], cols[k])
+
+
+def test_dense_apply_and_dense_coarsest_solve():
+    """gla_dense_apply (Y = M X, the coarsest-level solve of a deep V-cycle): against a float64 / extended-precision host
+    product, column by column independent of K (bit for bit), ragged sizes, strided M; the V-cycle with the inverse applied
+    agrees with the LU triangular solves it replaces; argument errors."""
+    from gnn_applied_linear_algebra_amd._lib import check, dtype_code, lib, ptr, stream_ptr, GlaError
+    V = gla.VCycle
+    gen = torch.Generator().manual_seed(77)
+    for dt, tol in ((torch.float64, 1e-13), (torch.float32, 2e-5)):
+        for n_rows, n_cols, K in ((1, 1, 1), (3, 70, 1), (257, 1024, 1), (64, 333, 5), (100, 257, 16), (31, 64, 9)):
+            ld = n_cols + 3
+            Mbuf = d(torch.randn(n_rows, ld, generator=gen, dtype=dt))
+            M = Mbuf[:, :n_cols]
+            X = d(torch.randn(n_cols, K, generator=gen, dtype=dt))
+            Y = torch.full((n_rows, K), float("nan"), dtype=dt, device=DEV)
+            check(lib().gla_dense_apply(dtype_code(dt), n_rows, n_cols, ptr(M), ld, K, ptr(X), K, ptr(Y), K, stream_ptr(DEV)))
+            want = (M.cpu().to(torch.float64).numpy().astype(np.longdouble) @ X.cpu().to(torch.float64).numpy().astype(np.longdouble))
+            scale = (np.abs(M.cpu().numpy()).astype(np.float64) @ np.abs(X.cpu().numpy()).astype(np.float64)) + 1e-300
+            assert np.all(np.abs(Y.cpu().numpy() - want.astype(np.float64)) <= tol * scale), (dt, n_rows, n_cols, K)
+            for k in range(K):                      # column k alone: same bits
+                xk = X[:, k:k + 1].contiguous()
+                yk = torch.empty((n_rows, 1), dtype=dt, device=DEV)
+                check(lib().gla_dense_apply(dtype_code(dt), n_rows, n_cols, ptr(M), ld, 1, ptr(xk), 1, ptr(yk), 1, stream_ptr(DEV)))
+                eq(yk, Y[:, k:k + 1])
+    X = d(torch.zeros(4, 1, dtype=torch.float64))
+    for bad in (lambda: lib().gla_dense_apply(1, 4, 4, ptr(X), 3, 1, ptr(X), 1, ptr(torch.zeros_like(X)), 1, stream_ptr(DEV)),
+                lambda: lib().gla_dense_apply(1, 1, 4, ptr(X), 4, 1, ptr(X), 1, ptr(X), 1, stream_ptr(DEV)),
+                lambda: lib().gla_dense_apply(7, 1, 4, ptr(X), 4, 1, ptr(X), 1, ptr(torch.zeros_like(X)), 1, stream_ptr(DEV))):
+        with pytest.raises(GlaError):
+            check(bad())
+    # the cycle: inverse applied (default) against the triangular solves (DENSE_INVERSE_MAX = 0)
+    m = 127
+    ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 1.0], device=DEV)
+    n = m * m
+    A = V._as_sparse(ei, ev, (n, n))
+    H = V.AMGHierarchy(A, levels=3, splitting=V.GridSplitting(m, m), coarse_solver="dense")
+    assert H._coarse_inv is not None and H._coarse_lu is None and H.A[-1].shape[0] == 1024
+    old = V.AMGHierarchy.DENSE_INVERSE_MAX
+    try:
+        V.AMGHierarchy.DENSE_INVERSE_MAX = 0
+        H_lu = V.AMGHierarchy(A, levels=3, splitting=V.GridSplitting(m, m), coarse_solver="dense")
+    finally:
+        V.AMGHierarchy.DENSE_INVERSE_MAX = old
+    assert H_lu._coarse_inv is None and H_lu._coarse_lu is not None
+    b = d(torch.rand(n, 1, generator=gen, dtype=torch.float64))
+    xa = xb = torch.zeros_like(b)
+    for _ in range(4):
+        xa, xb = H.cycle(b, xa), H_lu.cycle(b, xb)
+        close(xa, xb, rtol=1e-9)
+    assert float(torch.norm(H.residual(b, xa))) < 1e-2 * float(torch.norm(b))
 
 
 def test_coalesce_rejects_out_of_range_index():
