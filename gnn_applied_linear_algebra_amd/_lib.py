@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede loading libgla_hip.so, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgla_hip.so")
+LIB_PATH = os.environ.get("GLA_LIB_PATH") or os.path.join(_HERE, "libgla_hip.so")      # (GLA_LIB_PATH: A/B builds, tools/)
 
 GLA_F32, GLA_F64 = 0, 1
 _DTYPES = {torch.float32: GLA_F32, torch.float64: GLA_F64}

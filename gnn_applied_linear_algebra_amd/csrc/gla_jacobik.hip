@@ -3,11 +3,20 @@
 // JacobiGNN on K right-hand sides (vertex_attr [n, 3, K]: the multi-RHS extension of JacobiGNN.py:138-148; the smoother of a
 // V-cycle run on several right-hand sides at once) is, sweep by sweep, the blocked SpMM kernel with the EpiJacobi epilogue:
 // every sweep streams b, x in and x out (24 K bytes per row) plus the matrix.  Only the last iterate leaves the call, so --
-// exactly like jacobi_march5 / jacobi_march9 (gla_rows.hip) and cheby_march5 (gla_cheby.hip) -- TS sweeps are taken in ONE
-// pass: a workgroup owns a strip of 256 / KV grid points x K right-hand sides (lanes = (point, 16-byte rhs vector)) and
-// marches down the grid lines; the own column of every level lives in registers (h[t][0..2]), LDS carries the i -/+ 1
-// neighbours (three lines per level, slot = line mod 3, one barrier per level and line step), coefficients and b of the last
-// TS lines stay in registers under static names, a wave whose rows all carry the full pattern skips the mask selects.
+// exactly like jacobi_march5 (gla_march5.hip) and cheby_march5 (gla_cheby.hip) -- TS sweeps are taken in ONE pass: a
+// workgroup owns a strip of NT / KV grid points x K right-hand sides (lanes = (point, 16-byte rhs vector)) and marches down
+// the grid lines; the own column of every level lives in registers (h[t][0..2]), LDS carries the i -/+ 1 neighbours,
+// coefficients and b of the last TS lines stay in registers under static names.
+//
+// Round 3, as in gla_march5.hip (the reasons and measurements are in its header):
+//   * strips are aligned with the grid (no lane outside it); a row whose mask is "every neighbour that exists" takes the
+//     unmasked sum -- missing neighbours read +0 (LDS pads, lines beyond the grid), their stored coefficients are zeros;
+//   * the division by A_ii goes through RN(1 / A_ii) (one IEEE division per row and pass, shared by the K right-hand sides)
+//     and one Markstein correction per level and right-hand side; lanes whose operands leave the range the correction is
+//     proven for have the level (9-point) / the line step (5-point) redone with IEEE divisions;
+//   * 512 threads per workgroup where a row is 4 or more 16-byte vectors wide: a strip is then 64 (128) points instead of
+//     32 (64), and the 2 TS halo points either side that every strip recomputes drop from a third to a seventh of the work;
+//   * the two waves that share a SIMD alternate s_setprio every line step in antiphase.
 // Per (row, rhs) the arithmetic of the blocked SpMM kernel + EpiJacobi -- in-order masked sum over the diagonals, then
 // x + (w * (b - sum)) / A_ii (JacobiGNN.py:119) -- so the result is bit-identical to TS single sweeps.
 #include "gla_device.h"
@@ -22,76 +31,132 @@ struct JacK {
 };
 
 template <typename T, int D>
-struct KCoef {                                     // one row's matrix data, A_ii, mask as loaded, row exists
+struct KCoef {                                     // one row's matrix data, A_ii, mask as loaded
   T v[(D + 3) & ~3];                               // (padded to whole 16-byte groups: the compiler keeps the set in registers)
   T dg;
-  int m, lv;
+  int m;
+};
+
+template <typename T> struct KLim;
+template <> struct KLim<double> {
+  static constexpr double dlo = 0x1p-500, dhi = 0x1p500, nlo = 0x1p-450, nhi = 0x1p450;
+  static __device__ __forceinline__ bool all_ones(double v) {
+    return (__builtin_bit_cast(unsigned long long, v) & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
+  }
+};
+template <> struct KLim<float> {
+  static constexpr float dlo = 0x1p-60f, dhi = 0x1p60f, nlo = 0x1p-50f, nhi = 0x1p50f;
+  static __device__ __forceinline__ bool all_ones(float v) { return (__builtin_bit_cast(unsigned, v) & 0x7FFFFFu) == 0x7FFFFFu; }
 };
 
 // D = 5: diagonals (-1,0) (0,-1) (0,0) (0,1) (1,0); D = 9: (a, b) in {-1, 0, 1}^2 row-major
-template <typename T, int KV, int TS, int D>
-__global__ __launch_bounds__(GLA_BLOCK) void jacobi_marchk_kernel(JacK jv, const T* __restrict__ diag,
-                                                                  const T* __restrict__ bvec, int64_t ldb,
-                                                                  const T* __restrict__ x0, int64_t ldx0,
-                                                                  T* __restrict__ xout, int64_t ldxo, T w, int lines,
-                                                                  int nstrips, int64_t nlines, TileMap tm) {
+template <typename T, int KV, int TS, int D, int NT>
+__global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __restrict__ diag, const T* __restrict__ bvec,
+                                                           int64_t ldb, const T* __restrict__ x0, int64_t ldx0,
+                                                           T* __restrict__ xout, int64_t ldxo, T w, int lines, int nstrips,
+                                                           int64_t nlines, TileMap tm) {
   constexpr int VW = 16 / (int)sizeof(T);
-  constexpr int BP = GLA_BLOCK / KV;               // grid points of a strip
+  constexpr int BP = NT / KV;                      // grid points of a strip
   constexpr int LWV = (BP + 2) * KV;               // 16-byte vectors of a line in LDS: point ii at [(1 + ii) * KV + q]
+  constexpr int NSL = D == 5 ? 2 : 3;              // LDS lines per level: 5-point slot = line parity, 9-point slot = line mod 3
   constexpr int NC = TS + 1, U = NC;
   constexpr unsigned FULL = (1u << D) - 1u;
   typedef T TV __attribute__((ext_vector_type(VW)));
   typedef KCoef<T, D> Coef;
+  typedef KLim<T> Lim;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  TV* buf = reinterpret_cast<TV*>(smem_raw);       // 9-point: [TS][3][LWV], slot = line mod 3; 5-point: [TS][2][LWV], slot = parity
+  TV* buf = reinterpret_cast<TV*>(smem_raw);       // [TS][NSL][LWV]
   const int blk = map_tile(tm);
   if (blk < 0) return;
   constexpr int halo = TS, bp_eff = BP - 2 * halo;
   const int lb = blk / nstrips, strip = blk - lb * nstrips;
-  const int64_t J0 = (int64_t)lb * lines, P0 = (int64_t)strip * bp_eff - halo;
+  const int64_t J0 = (int64_t)lb * lines;
   const int L = (int)min((int64_t)lines, nlines - J0);
+  const int64_t S = jv.S;
+  // strip s: interior strips own the middle bp_eff points; the first starts at point 0, the last ends at point S - 1
+  const int64_t P0 = max((int64_t)0, min((int64_t)strip * bp_eff, S - BP));
+  const int64_t own_lo = strip == 0 ? 0 : (int64_t)strip * bp_eff + halo;
+  const int64_t own_hi = strip == nstrips - 1 ? S : (int64_t)strip * bp_eff + BP - halo;
   const int tid = threadIdx.x, ii = tid / KV, q = tid % KV;
+  // the two waves that share a SIMD (NT = 512: waves w and w + 4 of the workgroup; NT = 256: of a CU's two workgroups)
+  const int late = NT >= 512 ? (tid >> 8) & 1 : (((int)blockIdx.x / GLA_XCDS) >> 5) & 1;
   const T* __restrict__ val = static_cast<const T*>(jv.val);
   const int64_t gi = P0 + ii;
-  const bool in_i = gi >= 0 && gi < jv.S;
-  const bool owner = ii >= halo && ii < BP - halo;
+  const bool in_i = gi < S;                        // (false only on grids narrower than a strip)
+  const bool owner = gi >= own_lo && gi < own_hi;
+  const int64_t nfull = jv.n_rows / S;             // whole grid lines
+  const int64_t tail = jv.n_rows - nfull * S;      // points on the ragged last line
+  // the mask of a row at this point of a line when every neighbour that exists is coupled, line-independent part
+  const unsigned em_i = D == 5 ? (31u & ~(gi == 0 ? 2u : 0u) & ~(gi == S - 1 ? 8u : 0u))
+                               : (FULL & ~(gi == 0 ? 0x49u : 0u) & ~(gi == S - 1 ? 0x124u : 0u));
+  // block-relative lines [jlo, jhi) are whole grid lines
+  const int jlo = (int)max((int64_t)-64, -J0), jhi = (int)min((int64_t)L + 64, nfull - J0);
+  const bool wave_in = __all(in_i) != 0;
 
-  auto x0_at = [&](int jl) -> TV {                 // clamped: values of dead rows are never used
-    int64_t flat = (J0 + jl) * jv.S + gi;
-    flat = min(max(flat, (int64_t)0), jv.n_cols - 1);
-    return ldv<TV>(x0 + flat * ldx0 + q * VW);
-  };
+  for (int i = tid; i < TS * NSL * LWV; i += NT) buf[i] = TV(T(0));   // (the pads stay +0: what lies beyond a line's ends)
+  __syncthreads();
+
+  auto row_clamped = [&](int jl) -> int64_t { return min(max((J0 + jl) * S + gi, (int64_t)0), jv.n_rows - 1); };
+  // (bitwise, not short-circuit: hipcc 7.0 dropped the masked move of `uniform || per_lane ? xpre : 0` in one unrolled copy of the
+  // line step -- x^(k) of the next line read as 0 wherever the wave-uniform term was false; profiles/r03/marchk_miscompile.txt)
+  auto live_at = [&](int jl) -> bool { return in_i & (J0 + jl >= 0) & ((J0 + jl) * S + gi < jv.n_rows); };
+  auto x0_load = [&](int jl) -> TV { return ldv<TV>(x0 + row_clamped(jl) * ldx0 + q * VW); };   // NOT touched until the next step
   auto coef_at = [&](int jl) -> Coef {
-    const int64_t gj = J0 + jl, r = gj * jv.S + gi;
-    const bool live = in_i && gj >= 0 && gj < nlines && r < jv.n_rows;
-    const int64_t rc = live ? r : 0;
+    const int64_t rc = row_clamped(jl);
     Coef c;
 #pragma unroll
     for (int d = 0; d < D; ++d) c.v[d] = val[(int64_t)d * jv.n_rows + rc];
     c.dg = diag[rc];
     c.m = (int)jv.mask[rc];
-    c.lv = live;
     return c;
   };
-  auto b_at = [&](int jl) -> TV {                  // b of the row (line J0 + jl, this lane's point), this lane's rhs vector
-    const int64_t gj = J0 + jl, r = gj * jv.S + gi;
-    const bool live = in_i && gj >= 0 && gj < nlines && r < jv.n_rows;
-    return ldv<TV>(bvec + (live ? r : 0) * ldb + q * VW);
-  };
-  auto update = [&](const Coef& c, TV cb, bool full, const TV (&xs)[D], TV ctr) -> TV {
-    TV acc = TV(T(0));
-    if (full) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) acc = acc + c.v[d] * xs[d];
+  auto b_at = [&](int jl) -> TV { return ldv<TV>(bvec + row_clamped(jl) * ldb + q * VW); };
+  auto expected = [&](int jl) -> unsigned {        // (lines inside [jlo, jhi) only)
+    const int64_t gj = J0 + jl;
+    if constexpr (D == 5) {
+      const bool has_down = gj + 1 < nfull || (gj + 1 == nfull && gi < tail);
+      return em_i & ~(gj == 0 ? 1u : 0u) & ~(has_down ? 0u : 16u);
     } else {
-      const int m = c.lv ? c.m : 0;
+      unsigned e = em_i & ~(gj == 0 ? 0x7u : 0u);
+      if (gj + 1 >= nfull) {                       // the line below is the ragged one, or beyond the grid
+        const bool rag = gj + 1 == nfull;
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const TV nxt = acc + c.v[d] * xs[d];
-        acc = ((m >> d) & 1) ? nxt : acc;
+        for (int bb = -1; bb <= 1; ++bb)
+          if (!(rag && gi + bb < tail)) e &= ~(1u << (7 + bb));
       }
+      return e;
     }
-    return ctr + (w * (cb - acc)) / c.dg;
+  };
+  // the generic level: masked in-order sum, IEEE division, +0 for rows outside the matrix
+  auto generic = [&](const Coef& c, TV cb, const TV (&xs)[D], TV ctr, int line) -> TV {
+    const bool lv = live_at(line);
+    const int m = lv ? (int)jv.mask[row_clamped(line)] : 0;          // (not kept per set: this path is rare)
+    TV acc = TV(T(0));
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const TV nxt = acc + c.v[d] * xs[d];
+      acc = ((m >> d) & 1) ? nxt : acc;
+    }
+    const TV xn = ctr + (w * (cb - acc)) / c.dg;
+    return lv ? xn : TV(T(0));
+  };
+  // the fast level: unmasked sum, Markstein division through rc = RN(1 / A_ii); bad: an operand it is not proven for
+  auto fast_level = [&](const Coef& c, TV cb, T rc, const TV (&xs)[D], TV ctr, bool& bad, TV& num_out) -> TV {
+    TV acc = TV(T(0));
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc = acc + c.v[d] * xs[d];
+    const TV num = w * (cb - acc);
+    TV xn;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      const T an = __builtin_fabs(num[e]);
+      bad = bad || !(an > Lim::nlo && an < Lim::nhi);
+      const T q0 = num[e] * rc;
+      const T rem = fma_t(-q0, c.dg, num[e]);
+      xn[e] = ctr[e] + fma_t(rem, rc, q0);
+    }
+    num_out = num;
+    return xn;
   };
 
   constexpr int j_first = -(TS - 1);
@@ -99,65 +164,108 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_marchk_kernel(JacK jv, const
   TV h[TS][3];                                     // h[t]: x^(k+t) of this lane on the last three lines level t produced
 #pragma unroll
   for (int t = 0; t < TS; ++t) h[t][0] = h[t][1] = h[t][2] = TV(T(0));
-  h[0][1] = x0_at(j_first - 1);
-  h[0][2] = x0_at(j_first);
+  {
+    const TV a = x0_load(j_first - 1), b0 = x0_load(j_first);
+    h[0][1] = live_at(j_first - 1) ? a : TV(T(0));
+    h[0][2] = live_at(j_first) ? b0 : TV(T(0));
+  }
   if constexpr (D == 5) {
     buf[((j_first + 64) & 1) * LWV + (1 + ii) * KV + q] = h[0][2];
   } else {
     buf[((j_first - 1 + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][1];
     buf[((j_first + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][2];
   }
-  TV xpre = x0_at(j_first + 1);
+  TV xpre = x0_load(j_first + 1);
   Coef c[NC];                                      // set of line j_first + s lives in c[s % NC]
   TV cb[NC];                                       // ... and the row's b
-  bool cfull[NC];
+  T crc[NC];                                       // RN(1 / A_ii) (1 where the fast division is off anyway)
+  bool cfast[NC];                                  // wave-uniform: a whole grid line, every row with the expected mask and a safe divisor
   c[0] = coef_at(j_first);
   cb[0] = b_at(j_first);
 #pragma unroll
   for (int s = 1; s < NC; ++s) { c[s] = c[0]; cb[s] = cb[0]; }
 #pragma unroll
-  for (int s = 0; s < NC; ++s) cfull[s] = false;
+  for (int s = 0; s < NC; ++s) { cfast[s] = false; crc[s] = T(1); }
+
+  // first use of the set of line jl (loaded a step ago): expected mask, divisor range, reciprocal
+  auto classify = [&](const int jl, const int u) {
+    const Coef& cu = c[u % NC];
+    const T ad = __builtin_fabs(cu.dg);
+    const bool dok = ad >= Lim::dlo && ad <= Lim::dhi && !Lim::all_ones(cu.dg);
+    crc[u % NC] = T(1) / (dok ? cu.dg : T(1));
+    const bool whole = wave_in && jl >= jlo && jl < jhi;
+    cfast[u % NC] = whole && __all(((unsigned)cu.m & FULL) == expected(jl) && dok) != 0;
+  };
 
   auto do_step = [&](const int jl, const int u, const int nact) {
-    if ((jl & 1) ^ (((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
     if constexpr (D == 5) {
       // 5-point: a level only needs the i -/+ 1 neighbours of ITS OWN line, which the level below wrote one line step
       // earlier: two lines per level (slot = line parity) and ONE barrier per line step (as jacobi_march5 / cheby_march5)
       __syncthreads();
       const int pj = (jl + 64) & 1;
+      if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
       TV* const row_e = buf + pj * LWV + ii * KV + q;          // lines of the parity of jl: [0] left, [KV] own, [2 KV] right
       TV* const row_o = buf + (1 - pj) * LWV + ii * KV + q;
-      h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
-      row_o[KV] = xpre;                            // level 0, line jl + 1
-      xpre = x0_at(jl + 2);                        // clamped / dead beyond the block: harmless, never used
+#pragma unroll
+      for (int t = 0; t < TS; ++t) { h[t][0] = h[t][1]; h[t][1] = h[t][2]; }     // (levels only assign h[t][2]: a step is idempotent)
+      const bool whole_next = wave_in && jl + 1 >= jlo && jl + 1 < jhi;
+      h[0][2] = (whole_next | live_at(jl + 1)) ? xpre : TV(T(0));
+      row_o[KV] = h[0][2];                         // level 0, line jl + 1
+      xpre = x0_load(jl + 2);
       c[(u + 1) % NC] = coef_at(jl + 1);
       cb[(u + 1) % NC] = b_at(jl + 1);
-      cfull[u % NC] = __all(c[u % NC].lv && ((unsigned)c[u % NC].m & FULL) == FULL) != 0;   // (at first use)
+      classify(jl, u);
+      __builtin_amdgcn_sched_barrier(0);
+      bool fast = true;
 #pragma unroll
-      for (int t = 1; t <= TS; ++t) {
-        if (t <= nact) {
-          TV* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LWV;   // level t - 1, line jl - (t - 1)
-          const int ci = ((u - (t - 1)) % NC + NC) % NC;
-          const TV xs[5] = {h[t - 1][0], row[0], h[t - 1][1], row[2 * KV], h[t - 1][2]};
-          const TV xn = update(c[ci], cb[ci], cfull[ci], xs, h[t - 1][1]);
-          if (t < TS) {
-            h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
-            row[2 * LWV + KV] = xn;                // level t, same line (same parity)
-          } else if (c[ci].lv && owner) {
-            stv<TV>(xout + ((J0 + jl - (TS - 1)) * jv.S + gi) * ldxo + q * VW, xn);
+      for (int t = 1; t <= TS; ++t)
+        if (t <= nact) fast = fast && cfast[((u - (t - 1)) % NC + NC) % NC];
+      bool bad = false;
+      if (fast) {
+#pragma unroll
+        for (int t = 1; t <= TS; ++t) {
+          if (t <= nact) {
+            TV* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LWV;   // level t - 1, line jl - (t - 1)
+            const int ci = ((u - (t - 1)) % NC + NC) % NC;
+            const TV xs[5] = {h[t - 1][0], row[0], h[t - 1][1], row[2 * KV], h[t - 1][2]};
+            TV num;
+            const TV xn = fast_level(c[ci], cb[ci], crc[ci], xs, h[t - 1][1], bad, num);
+            if (t < TS) { h[t][2] = xn; row[2 * LWV + KV] = xn; }                     // level t, same line (same parity)
+            else if (owner) stv<TV>(xout + ((J0 + jl - (TS - 1)) * S + gi) * ldxo + q * VW, xn);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (!fast || __any(bad)) {
+        asm volatile("" ::: "memory");             // (keeps this path's LDS reads from being merged with the fast path's above the branch)
+#pragma unroll
+        for (int t = 1; t <= TS; ++t) {
+          if (t <= nact) {
+            TV* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LWV;
+            const int ci = ((u - (t - 1)) % NC + NC) % NC;
+            const int line = jl - (t - 1);
+            const TV xs[5] = {h[t - 1][0], row[0], h[t - 1][1], row[2 * KV], h[t - 1][2]};
+            const TV xn = generic(c[ci], cb[ci], xs, h[t - 1][1], line);
+            if (t < TS) { h[t][2] = xn; row[2 * LWV + KV] = xn; }
+            else if (owner && live_at(line)) stv<TV>(xout + ((J0 + line) * S + gi) * ldxo + q * VW, xn);
           }
         }
       }
     } else {
+      // 9-point: a level also needs the i -/+ 1 neighbours of the line BELOW, which the level underneath produces in the same
+      // line step: three lines per level (slot = line mod 3), one barrier per level and line step
+      if ((jl & 1) ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
       const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
       // LDS rows of the lines jl + 1, jl, jl - 1 (level 0): [0] left, [KV] own, [2 KV] right of this lane's point
       TV* const rw[3] = {buf + s1 * LWV + ii * KV + q, buf + s0 * LWV + ii * KV + q, buf + s2 * LWV + ii * KV + q};
-      h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = xpre;
-      rw[0][KV] = xpre;                            // level 0, line jl + 1
-      xpre = x0_at(jl + 2);                        // clamped / dead beyond the block: harmless, never used
+      const bool whole_next = wave_in && jl + 1 >= jlo && jl + 1 < jhi;
+      h[0][0] = h[0][1]; h[0][1] = h[0][2];
+      h[0][2] = (whole_next | live_at(jl + 1)) ? xpre : TV(T(0));
+      rw[0][KV] = h[0][2];                         // level 0, line jl + 1
+      xpre = x0_load(jl + 2);
       c[(u + 1) % NC] = coef_at(jl + 1);
       cb[(u + 1) % NC] = b_at(jl + 1);
-      cfull[u % NC] = __all(c[u % NC].lv && ((unsigned)c[u % NC].m & FULL) == FULL) != 0;   // (at first use)
+      classify(jl, u);
 #pragma unroll
       for (int t = 1; t <= TS; ++t) {
         __syncthreads();
@@ -167,14 +275,28 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_marchk_kernel(JacK jv, const
           TV* const same = rw[t % 3] + (t - 1) * 3 * LWV;
           TV* const above = rw[(t + 1) % 3] + (t - 1) * 3 * LWV;
           const int ci = ((u - (t - 1)) % NC + NC) % NC;
+          const int line = jl - (t - 1);
           const TV xs[9] = {above[0], h[t - 1][0], above[2 * KV], same[0], h[t - 1][1], same[2 * KV],
                             below[0], h[t - 1][2], below[2 * KV]};
-          const TV xn = update(c[ci], cb[ci], cfull[ci], xs, h[t - 1][1]);
+          TV xn;
+          bool live = true;
+          if (cfast[ci]) {
+            bool bad = false;
+            TV num;
+            xn = fast_level(c[ci], cb[ci], crc[ci], xs, h[t - 1][1], bad, num);
+            if (__any(bad)) {                      // same sum, IEEE division
+              asm volatile("" ::: "memory");
+              xn = h[t - 1][1] + num / c[ci].dg;
+            }
+          } else {
+            xn = generic(c[ci], cb[ci], xs, h[t - 1][1], line);
+            live = live_at(line);
+          }
           if (t < TS) {
             h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
             same[3 * LWV + KV] = xn;               // level t, same line (same slot)
-          } else if (c[ci].lv && owner) {
-            stv<TV>(xout + ((J0 + jl - (TS - 1)) * jv.S + gi) * ldxo + q * VW, xn);
+          } else if (owner && live) {
+            stv<TV>(xout + ((J0 + line) * S + gi) * ldxo + q * VW, xn);
           }
         }
       }
@@ -194,10 +316,30 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_marchk_kernel(JacK jv, const
   }
 }
 
+// threads per workgroup: 512 where a row is four or more 16-byte vectors wide (strip of 64 / 128 points instead of 32 / 64)
+template <int KV> struct KThreads { static constexpr int nt = KV >= 4 ? 512 : GLA_BLOCK; };
+
+template <typename T, int KV, int TS, int D>
+int marchk_blocks_per_cu(size_t lds) {
+  constexpr int NT = KThreads<KV>::nt;
+  static int cached = 0;
+  if (!cached) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, jacobi_marchk_kernel<T, KV, TS, D, NT>, NT, lds) != hipSuccess || nb < 1) {
+      (void)hipGetLastError();
+      nb = 1;
+    }
+    const int cap = 2 * GLA_BLOCK / NT;            // two waves per SIMD: more resident workgroups only shorten the streams
+    cached = nb > cap ? cap : nb;
+  }
+  return cached;
+}
+
 template <typename T, int KV, int TS, int D>
 int launch_marchk(gla_csr* A, const T* diag, const T* b, int64_t ldb, const T* x, int64_t ldx, T* xo, int64_t ldxo, T w,
                   hipStream_t st) {
-  constexpr int BP = GLA_BLOCK / KV;
+  constexpr int NT = KThreads<KV>::nt;
+  constexpr int BP = NT / KV;
   constexpr int bp_eff = BP - 2 * TS;
   static_assert(bp_eff >= 1, "strip too narrow");
   JacK jv;
@@ -206,16 +348,28 @@ int launch_marchk(gla_csr* A, const T* diag, const T* b, int64_t ldb, const T* x
   jv.S = A->dia_S;
   jv.n_rows = A->n_rows; jv.n_cols = A->n_cols;
   const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
-  const int nstrips = (int)((A->dia_S + bp_eff - 1) / bp_eff);
+  // the first and the last strip own their outer halo too (nothing lies beyond the grid): S - 2 TS points to share out
+  int64_t ns = (A->dia_S - 2 * TS + bp_eff - 1) / bp_eff;
+  if (ns < 1) ns = 1;
+  const int nstrips = (int)ns;
   const size_t lds = (size_t)TS * (D == 5 ? 2 : 3) * (BP + 2) * KV * 16;
+  if (lds > 64 * 1024) {
+    static bool raised = false;                    // (once per instance: the default dynamic LDS limit is 64 KiB)
+    if (!raised) {
+      GLA_HIP_CHECK(hipFuncSetAttribute((const void*)jacobi_marchk_kernel<T, KV, TS, D, NT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      raised = true;
+    }
+  }
   int lines = g_tuning.jacobi_lines;
-  if (lines <= 0) lines = gla_pick_block_lines(nlines, nstrips, 256 * 2, 2 * (TS - 1), 2 * TS);
+  if (lines <= 0)
+    lines = gla_pick_block_lines(nlines, nstrips, 256 * (int64_t)marchk_blocks_per_cu<T, KV, TS, D>(lds), 2 * (TS - 1), 2 * TS);
   if (lines < 2 * TS) lines = 2 * TS;
   TileMap tm;
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
   set_tile_mapping(tm);
-  hipLaunchKernelGGL((jacobi_marchk_kernel<T, KV, TS, D>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
+  hipLaunchKernelGGL((jacobi_marchk_kernel<T, KV, TS, D, NT>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(NT), lds,
                      st, jv, diag, b, ldb, x, ldx, xo, ldxo, w, lines, nstrips, nlines, tm);
   GLA_LAUNCH_CHECK();
   return GLA_OK;
@@ -229,7 +383,7 @@ int dispatch_ts(int ts, gla_csr* A, const T* diag, const T* b, int64_t ldb, cons
     case 3: return launch_marchk<T, KV, 3, D>(A, diag, b, ldb, x, ldx, xo, ldxo, w, st);
     case 4:
       if constexpr (D == 5) return launch_marchk<T, KV, 4, D>(A, diag, b, ldb, x, ldx, xo, ldxo, w, st);
-      else return GLA_ERR_UNSUPPORTED;               // (9-point, four sweeps: 255 VGPRs, one wave per SIMD)
+      else return GLA_ERR_UNSUPPORTED;               // (9-point, four sweeps: the registers of one wave per SIMD)
     default: return GLA_ERR_UNSUPPORTED;
   }
 }

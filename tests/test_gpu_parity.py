@@ -1923,6 +1923,12 @@ def test_jacobi_multi_rhs_temporal_blocking_bit_identical():
     cases = [("laplacian 130 x 70", *rp.laplacianfun_torch(130, 70), 9100),
              ("laplacian 40 x 9", *rp.laplacianfun_torch(40, 9), 360),
              ("fem 9-point 70 x 58", *rp.heateqnfem2dfun([71, 59], [1.0, 4.0]), 70 * 58)]
+    # grids narrower than a strip, or ending inside a wave (lanes beyond the grid next to live ones: the per-lane "row exists"
+    # select of the x^(k) line -- once miscompiled by hipcc, profiles/r03/marchk_miscompile.txt)
+    for N_ in (16, 40, 63, 100):
+        cases.append((f"laplacian {N_}^2", *rp.laplacianfun_torch(N_), N_ * N_))
+    cases.append(("fem 9-point 63^2", *rp.heateqnfem2dfun([64, 64], [1.0, 1.0]), 63 * 63))
+    cases.append(("fem 9-point 40^2", *rp.heateqnfem2dfun([41, 41], [1.0, 1.0]), 40 * 40))
     ei, ev = _stencil_matrix(150, 40, [(-1, 0), (0, -1), (0, 0), (0, 1), (1, 0)], gen, 0.2)
     cases.append(("5-point with holes", ei, ev, 6000))
     ei, ev = _stencil_matrix(90, 40, [(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)], gen, 0.2)
@@ -2175,3 +2181,55 @@ def test_jacobi_march_division_fallback_special_values():
             finally:
                 check(lib().gla_set_option(b"jacobi_fuse", 1))
             assert same(xr[0], w2) and same(xr[1], r2), ("residual", ts)
+
+
+def test_jacobi_multi_rhs_division_fallback_special_values():
+    """The K-wide temporally blocked passes (jacobi_marchk_kernel) divide like jacobi_march5: RN(1 / A_ii) + a Markstein correction,
+    IEEE division redone wherever that is not provably exact.  Zero / -0 / denormal / huge / Inf / NaN numerators in SOME
+    right-hand sides of a row, all-ones and extreme divisors, holes in the pattern; 5- and 9-point, K = 4 and 16, every pass
+    size, against single sweeps bit for bit (a NaN matches any NaN)."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+
+    def same(a, w):
+        a, w = a.cpu().reshape(-1), w.cpu().reshape(-1)
+        return bool(((a == w) | (torch.isnan(a) & torch.isnan(w))).all()) and \
+            bool((torch.signbit(a) == torch.signbit(w))[~torch.isnan(a)].all())
+    gen = torch.Generator().manual_seed(33)
+    Nx, Ny = 300, 90
+    n = Nx * Ny
+    for name, (ei, ev) in (("5-point", rp.laplacianfun_torch(Nx, Ny)),
+                           ("9-point", rp.heateqnfem2dfun([Nx + 1, Ny + 1], [1.0, 2.0]))):
+        assert int(ei.max()) + 1 == n
+        ev = ev.reshape(-1) * (1.0 + 0.25 * torch.rand(ev.numel(), generator=gen, dtype=torch.float64))
+        keep = ~((ei[0] % 977 == 5) & (ei[1] == ei[0] - 1))           # some rows lose their left neighbour
+        ei_, ev_ = ei[:, keep], ev[keep]
+        plan = gla.CsrPlan(d(ei_), n)
+        plan.set_values(d(ev_))
+        for K in (4, 16):
+            b = torch.rand(n, K, generator=gen, dtype=torch.float64)
+            x = torch.rand(n, K, generator=gen, dtype=torch.float64)
+            diag = 3.0 + torch.rand(n, generator=gen, dtype=torch.float64)
+            k = torch.arange(n) % 4099
+            b[k == 1, 0] = 0.0
+            x[k == 2, 1] = 0.0
+            b[k == 2, 1] = 0.0
+            diag[k == 3] = float.fromhex("0x1.fffffffffffffp+1")      # all-ones significand
+            diag[k == 4] = 2.0 ** -600                                # extreme divisor
+            b[k == 5, K - 1] = 2.0 ** 600
+            b[k == 6, 2] = 2.0 ** -700
+            b[k == 7, :] = -0.0
+            b[(k == 8) & (torch.arange(n) % 8198 == 8), 3] = float("inf")
+            b[(k == 9) & (torch.arange(n) % 40990 == 9), 0] = float("nan")
+            diag[k == 10] = 2.0 ** -1040                              # denormal divisor
+            b[n // 2:n // 2 + 12 * Nx, :] = 0.0                       # a region of exact zeros: numerators +-0
+            x[n // 2:n // 2 + 12 * Nx, :] = torch.where(torch.arange(12 * Nx) % 2 == 0, 0.0, -0.0).to(torch.float64).reshape(-1, 1)
+            dD, bD, xD = d(diag), d(b), d(x)
+            for ts in (2, 3, 4, 7):
+                try:
+                    check(lib().gla_set_option(b"jacobi_fuse", 0))
+                    want = plan.jacobi_sweeps(dD, bD, xD, 0.7, ts)
+                finally:
+                    check(lib().gla_set_option(b"jacobi_fuse", 1))
+                got = plan.jacobi_sweeps(dD, bD, xD, 0.7, ts)
+                assert same(got, want), (name, K, ts)
