@@ -178,12 +178,12 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_fused_dia2d_kernel(
 // Rows above a step's first valid line carry garbage through the first line steps; it never reaches a stored value
 // (step t is valid from line -(DEG - t) on, and a valid line only reads valid lines of the step below).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int KV, int DEG, int VW = 16 / (int)sizeof(T)>      // VW = 1: one right-hand side (lanes = points)
-__global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
+template <typename T, int KV, int DEG, int VW = 16 / (int)sizeof(T), int NT = GLA_BLOCK>      // VW = 1: one right-hand side (lanes = points)
+__global__ __launch_bounds__(NT) void cheby_march5_kernel(
     Cheb2D cv, const T* __restrict__ bvec, int64_t ldb, const T* __restrict__ x0, int64_t ldx0, T* __restrict__ xout,
     int64_t ldxo, T* __restrict__ rout, int64_t ldr, T* __restrict__ pout, int64_t ldp, T* __restrict__ pprev,
     int64_t ldpp, T* __restrict__ bcopy, int64_t ldbc, int lines, int nstrips, int64_t nlines, TileMap tm) {
-  constexpr int BP = GLA_BLOCK / KV;               // grid points of a strip
+  constexpr int BP = NT / KV;               // grid points of a strip
   constexpr int LWV = (BP + 2) * KV;               // 16-byte vectors of a line in LDS: point ii at [(1 + ii) * KV + q]
   constexpr int NC = DEG + 1, U = NC;
   typedef T TV __attribute__((ext_vector_type(VW)));
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
   for (int t = 0; t < DEG; ++t) cr[t] = cx[t] = TV(T(0));
 
   auto do_step = [&](const int jl, const int u) {
-    if ((jl & 1) ^ (((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
+    if ((jl & 1) ^ (NT >= 512 ? ((int)threadIdx.x >> 8) & 1 : ((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
     __syncthreads();
     const int pj = (jl + 64) & 1;
     TV* const row_e = buf + pj * LWV + ii * KV + q;          // lines of the parity of jl: [0] left, [KV] own, [2 KV] right
@@ -343,12 +343,12 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march5_kernel(
 // The same pass for the canonical 9-point pattern ((a, b) in {-1, 0, 1}^2: the Q1 FEM operator): a row also needs the i -/+ 1
 // neighbours of the operand's line BELOW, which the step underneath produces in the same line step -- three lines per step in
 // LDS (slot = line mod 3), one barrier per step and line step (as jacobi_march9_kernel).
-template <typename T, int KV, int DEG, int VW = 16 / (int)sizeof(T)>
-__global__ __launch_bounds__(GLA_BLOCK) void cheby_march9_kernel(
+template <typename T, int KV, int DEG, int VW = 16 / (int)sizeof(T), int NT = GLA_BLOCK>
+__global__ __launch_bounds__(NT) void cheby_march9_kernel(
     Cheb2D cv, const T* __restrict__ bvec, int64_t ldb, const T* __restrict__ x0, int64_t ldx0, T* __restrict__ xout,
     int64_t ldxo, T* __restrict__ rout, int64_t ldr, T* __restrict__ pout, int64_t ldp, T* __restrict__ pprev,
     int64_t ldpp, T* __restrict__ bcopy, int64_t ldbc, int lines, int nstrips, int64_t nlines, TileMap tm) {
-  constexpr int BP = GLA_BLOCK / KV;               // grid points of a strip
+  constexpr int BP = NT / KV;               // grid points of a strip
   constexpr int LWV = (BP + 2) * KV;               // 16-byte vectors of a line in LDS: point ii at [(1 + ii) * KV + q]
   constexpr int NC = DEG + 1, U = NC;
   typedef T TV __attribute__((ext_vector_type(VW)));
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void cheby_march9_kernel(
   for (int t = 0; t < DEG; ++t) cr[t] = cx[t] = TV(T(0));
 
   auto do_step = [&](const int jl, const int u) {
-    if ((jl & 1) ^ (((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
+    if ((jl & 1) ^ (NT >= 512 ? ((int)threadIdx.x >> 8) & 1 : ((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
     const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
     // LDS rows of the lines jl + 1, jl, jl - 1 (operand of step 1): [0] left, [KV] own, [2 KV] right of this lane's point
     TV* const rw[3] = {buf + s1 * LWV + ii * KV + q, buf + s0 * LWV + ii * KV + q, buf + s2 * LWV + ii * KV + q};
@@ -538,13 +538,17 @@ template <typename T, int KV, int DEG>
 int launch_cheby_fused(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, const T* x0, int64_t ldx0, T* xout,
                        int64_t ldxo, T* r, int64_t ldr, T* p, int64_t ldp, T* pprev, int64_t ldpp, T* bcopy, int64_t ldbc,
                        hipStream_t st) {
-  constexpr int BP = GLA_BLOCK / KV;
+  const bool canon = g_tuning.jacobi_march && gla_dia_canon5(A);
+  const bool canon9 = g_tuning.jacobi_march && gla_dia_canon9(A);
+  // march kernels, rows of four or more 16-byte vectors: 512 threads per workgroup -- a strip of 64 / 128 points instead of
+  // 32 / 64, so the 2 DEG halo points either side that every strip recomputes are a seventh of its work, not a third
+  constexpr int NTM = KV >= 4 ? 512 : GLA_BLOCK;
+  const int NTrun = (canon || canon9) ? NTM : GLA_BLOCK;
+  const int BP = NTrun / KV;
   const int bp_eff = BP - 2 * DEG * cv.B;
   if (bp_eff < 1) return GLA_ERR_UNSUPPORTED;
   const int64_t nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
   const int nstrips = (int)((A->dia_S + bp_eff - 1) / bp_eff);
-  const bool canon = g_tuning.jacobi_march && gla_dia_canon5(A);
-  const bool canon9 = g_tuning.jacobi_march && gla_dia_canon9(A);
   if (A->dia_D > CH_DMAX && !canon9) return GLA_ERR_UNSUPPORTED;
   if (canon9 && DEG > 3) return GLA_ERR_UNSUPPORTED;              // (9-point, four steps, K-wide: > 256 VGPRs; the caller fuses three)
   const size_t lds = canon ? (size_t)DEG * 2 * (BP + 2) * KV * 16
@@ -553,20 +557,32 @@ int launch_cheby_fused(gla_csr* A, const Cheb2D& cv, const T* b, int64_t ldb, co
   // the march kernel: two workgroups per CU, as for the Jacobi march)
   int lines = g_tuning.jacobi_lines;
   if (lines <= 0) {
-    const int64_t per_cu = (canon || canon9) ? 2 : std::min<int64_t>(3, (160 * 1024) / (int64_t)lds);
+    const int64_t per_cu = (canon || canon9) ? 2 * GLA_BLOCK / NTrun : std::min<int64_t>(3, (160 * 1024) / (int64_t)lds);
     lines = gla_pick_block_lines(nlines, nstrips, 256 * (per_cu > 0 ? per_cu : 1), 2 * (DEG - 1), 2 * DEG);
   }
   TileMap tm;
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
   set_tile_mapping(tm);
-  if (canon)
-    hipLaunchKernelGGL((cheby_march5_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
+  constexpr int VWT = 16 / (int)sizeof(T);
+  if (canon) {
+    auto* kern = cheby_march5_kernel<T, KV, DEG, VWT, NTM>;
+    if (lds > 64 * 1024) {                          // (once per instance: the default dynamic LDS limit is 64 KiB)
+      static bool raised = false;
+      if (!raised) { GLA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = true; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(NTM), lds,
                        st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
-  else if (canon9) {
-    if constexpr (DEG <= 3)
-      hipLaunchKernelGGL((cheby_march9_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
+  } else if (canon9) {
+    if constexpr (DEG <= 3) {
+      auto* kern = cheby_march9_kernel<T, KV, DEG, VWT, NTM>;
+      if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) { GLA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = true; }
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(NTM), lds,
                          st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);
+    }
   } else
     hipLaunchKernelGGL((cheby_fused_dia2d_kernel<T, KV, DEG>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds,
                        st, cv, b, ldb, x0, ldx0, xout, ldxo, r, ldr, p, ldp, pprev, ldpp, bcopy, ldbc, lines, nstrips, nlines, tm);

@@ -232,8 +232,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void col_dot_stage2(const T* __restrict_
 
 // Sum of per-lane vectors over the lanes of a workgroup that share tid % KV (KV a power of two <= 32): xor-shuffles
 // inside each wave, then the four wave results through LDS in wave order.  Fixed order; the result is valid in lanes
-// tid < KV.  `sh` holds 4 * KV vectors.
-template <int KV, typename V>
+// tid < KV.  `sh` holds NW * KV vectors (NW = waves of the workgroup).
+template <int KV, typename V, int NW = 4>
 __device__ __forceinline__ V block_lane_group_sum(V v, V* sh) {
   const int tid = threadIdx.x;
 #pragma unroll
@@ -247,7 +247,11 @@ __device__ __forceinline__ V block_lane_group_sum(V v, V* sh) {
   if ((tid & 63) < KV) sh[(tid >> 6) * KV + (tid & 63)] = v;
   __syncthreads();
   V tot = V();
-  if (tid < KV) tot = ((sh[tid] + sh[KV + tid]) + sh[2 * KV + tid]) + sh[3 * KV + tid];
+  if (tid < KV) {
+    tot = sh[tid] + sh[KV + tid];
+#pragma unroll
+    for (int w = 2; w < NW; ++w) tot = tot + sh[w * KV + tid];
+  }
   return tot;
 }
 

@@ -44,13 +44,17 @@ __device__ __forceinline__ bool sig_all_ones(T v) {
 // strip-major sequence, every workgroup the same number of line steps whatever the strip count -- 14 % slower at K = 16,
 // the shared points then come from HBM.)  gla_pick_block_lines takes several rounds of shorter blocks when the strip count
 // quantises badly against the 512 resident workgroups.
-template <typename T, int VW, int KV, int TS, int D>
-__global__ __launch_bounds__(GLA_BLOCK) void power_march_kernel(PowK pv, const T* __restrict__ x0, int64_t ldx0,
+// threads per workgroup: 512 where a row is four or more 16-byte vectors wide -- a strip of 64 / 128 points instead of 32 / 64,
+// so the 2 TS halo points either side that every strip recomputes are a fifth of its work instead of almost a half (K = 16, TS = 5)
+template <int KV> struct PowThreads { static constexpr int nt = KV >= 4 ? 512 : GLA_BLOCK; };
+
+template <typename T, int VW, int KV, int TS, int D, int NT>
+__global__ __launch_bounds__(NT) void power_march_kernel(PowK pv, const T* __restrict__ x0, int64_t ldx0,
                                                                 const T* __restrict__ nrm, T* __restrict__ yout, int64_t ldy,
                                                                 T* __restrict__ partials, int lines, int nstrips,
                                                                 int64_t nlines, TileMap tm) {
   constexpr int K = KV * VW;
-  constexpr int BP = GLA_BLOCK / KV;               // grid points of a strip
+  constexpr int BP = NT / KV;                      // grid points of a strip
   constexpr int LWV = (BP + 2) * KV;               // lane vectors of a line in LDS: point ii at [(1 + ii) * KV + q]
   constexpr int NC = TS + 1, U = NC;
   constexpr unsigned FULL = (1u << D) - 1u;
@@ -64,7 +68,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void power_march_kernel(PowK pv, const T
   const int tid = threadIdx.x, ii = tid / KV, q = tid % KV;
   const T* __restrict__ val = static_cast<const T*>(pv.val);
   const bool owner = ii >= halo && ii < BP - halo;
-  const int late = ((blockIdx.x / GLA_XCDS) >> 5) & 1;      // (priority alternation between a CU's two workgroups: gla_march5.hip)
+  // (priority alternation between the two waves that share a SIMD: gla_march5.hip; NT = 512: waves w and w + 4 of the workgroup)
+  const int late = NT >= 512 ? (tid >> 8) & 1 : ((blockIdx.x / GLA_XCDS) >> 5) & 1;
 
   // this lane's divisors (the absolute norm of the previous pass' result per right-hand side), as EpiPower::gx
   TV dn, drn;
@@ -145,7 +150,13 @@ __global__ __launch_bounds__(GLA_BLOCK) void power_march_kernel(PowK pv, const T
     if constexpr (TS == 1) {                       // (the level below the last is the operand itself: line 0 of the block)
       if (owner && in_i && L > 0 && J0 * pv.S + gi < pv.n_rows) sq[0] = sq[0] + h[0][2] * h[0][2];
     }
-    TV xpre = x0_at(j_first + 1);                  // (normalised when it is consumed: the load stays in flight)
+    // x^(k) is fetched PD line steps ahead.  PD = 3 measured no gain over 1 at K = 16 (5.41 ms per 10 iterations either way):
+    // the pass is not bound by the loads in flight -- the counters (profiles/r03/pmc_k16_summary.txt) show the VALU ~46 % busy
+    // and a quarter of the wave time in s_waitcnt at two waves per SIMD: dependent-latency bound, like the levels of one line step.
+    constexpr int PD = 1;
+    TV xq[PD];                                     // xq[i]: line jl + 1 + i (normalised when consumed: the loads stay in flight)
+#pragma unroll
+    for (int i = 0; i < PD; ++i) xq[i] = x0_at(j_first + 1 + i);
     Coef c[NC];
     bool cfull[NC];
     c[0] = coef_at(j_first);
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void power_march_kernel(PowK pv, const T
       }
     };
     auto do_step = [&](const int jl, const int u, const int nact) {
-      const TV x1 = normalised(xpre);
+      const TV x1 = normalised(xq[0]);
       if constexpr (TS == 1) {                     // (the level below the last is the operand itself)
         const int64_t gj = J0 + jl + 1;
         if (owner && in_i && jl + 1 >= 0 && jl + 1 < L && gj * pv.S + gi < pv.n_rows) sq[0] = sq[0] + x1 * x1;
@@ -177,7 +188,9 @@ __global__ __launch_bounds__(GLA_BLOCK) void power_march_kernel(PowK pv, const T
         TV* const row_o = buf + (1 - pj) * LWV + ii * KV + q;
         h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = x1;
         row_o[KV] = x1;                            // level 0, line jl + 1
-        xpre = x0_at(jl + 2);
+#pragma unroll
+        for (int i = 0; i + 1 < PD; ++i) xq[i] = xq[i + 1];
+        xq[PD - 1] = x0_at(jl + 1 + PD);
         c[(u + 1) % NC] = coef_at(jl + 1);
         cfull[u % NC] = __all(c[u % NC].lv && ((unsigned)c[u % NC].m & FULL) == FULL) != 0;   // (at first use)
 #pragma unroll
@@ -199,7 +212,9 @@ __global__ __launch_bounds__(GLA_BLOCK) void power_march_kernel(PowK pv, const T
         TV* const rw[3] = {buf + s1 * LWV + ii * KV + q, buf + s0 * LWV + ii * KV + q, buf + s2 * LWV + ii * KV + q};
         h[0][0] = h[0][1]; h[0][1] = h[0][2]; h[0][2] = x1;
         rw[0][KV] = x1;
-        xpre = x0_at(jl + 2);
+#pragma unroll
+        for (int i = 0; i + 1 < PD; ++i) xq[i] = xq[i + 1];
+        xq[PD - 1] = x0_at(jl + 1 + PD);
         c[(u + 1) % NC] = coef_at(jl + 1);
         cfull[u % NC] = __all(c[u % NC].lv && ((unsigned)c[u % NC].m & FULL) == FULL) != 0;
 #pragma unroll
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void power_march_kernel(PowK pv, const T
   TV* sh = buf;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const TV tot = block_lane_group_sum<KV>(sq[t], sh);
+    const TV tot = block_lane_group_sum<KV, TV, NT / 64>(sq[t], sh);
     if (tid < KV) {
 #pragma unroll
       for (int i = 0; i < VW; ++i) partials[((int64_t)blk * 2 + t) * K + tid * VW + i] = tot[i];
@@ -255,12 +270,13 @@ struct PowGeom { int lines, nstrips, nblocks; int64_t nlines; };
 
 template <int KV, int TS>
 PowGeom pow_geom(const gla_csr* A) {
-  constexpr int BP = GLA_BLOCK / KV, bp_eff = BP - 2 * TS;
+  constexpr int NT = PowThreads<KV>::nt;
+  constexpr int BP = NT / KV, bp_eff = BP - 2 * TS;
   PowGeom g;
   g.nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
   g.nstrips = (int)((A->dia_S + bp_eff - 1) / bp_eff);
   int lines = g_tuning.jacobi_lines;
-  if (lines <= 0) lines = gla_pick_block_lines(g.nlines, g.nstrips, 256 * 2, 2 * (TS - 1), 2 * TS);
+  if (lines <= 0) lines = gla_pick_block_lines(g.nlines, g.nstrips, 256 * (2 * GLA_BLOCK / NT), 2 * (TS - 1), 2 * TS);
   if (lines < 2 * TS) lines = 2 * TS;
   g.lines = lines;
   g.nblocks = (int)(((g.nlines + lines - 1) / lines) * g.nstrips);
@@ -269,7 +285,8 @@ PowGeom pow_geom(const gla_csr* A) {
 
 template <typename T, int VW, int KV, int TS, int D>
 int launch_power(gla_csr* A, const T* x, int64_t ldx, const T* nrm, T* y, int64_t ldy, T* sumsq, T* work, hipStream_t st) {
-  constexpr int BP = GLA_BLOCK / KV, K = KV * VW;
+  constexpr int NT = PowThreads<KV>::nt;
+  constexpr int BP = NT / KV, K = KV * VW;
   static_assert(BP - 2 * TS >= 1, "strip too narrow");
   PowK pv;
   pv.val = A->dia_val;
@@ -282,7 +299,12 @@ int launch_power(gla_csr* A, const T* x, int64_t ldx, const T* nrm, T* y, int64_
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = g.nblocks;
   set_tile_mapping(tm);
-  hipLaunchKernelGGL((power_march_kernel<T, VW, KV, TS, D>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(GLA_BLOCK), lds, st,
+  auto* kern = power_march_kernel<T, VW, KV, TS, D, NT>;
+  if (lds > 64 * 1024) {                            // (once per instance: the default dynamic LDS limit is 64 KiB)
+    static bool raised = false;
+    if (!raised) { GLA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = true; }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(NT), lds, st,
                      pv, x, ldx, nrm, y, ldy, work, g.lines, g.nstrips, g.nlines, tm);
   GLA_LAUNCH_CHECK();
   // second stage: one workgroup per (level, rhs), workgroup partials added in block order

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Workload for rocprofv3 --pmc passes over BASELINE config 3's kernels: ChebyRelaxGNN(4) (one fused pass,
-cheby_march5_kernel) and PowerMethodGNN(10) (spmm_dia2d_kernel<EpiPower> x 10 + the fused Rayleigh tail) on the
+cheby_march5_kernel), PowerMethodGNN(10) (two power_march_kernel passes + the fused Rayleigh tail) and JacobiGNN(8 sweeps:
+two jacobi_marchk_kernel passes) on the
 4096^2 Laplacian with 16 right-hand sides, plus a calibration add of known volume (FETCH_SIZE x 2 on gfx950)."""
 import os
 import sys
@@ -21,9 +22,15 @@ cheb = gla.ChebyGNN.ChebyRelaxGNN(4, return_edge_attr=False)
 powm = gla.PowerMethodGNN.PowerMethodGNN(10, return_edge_attr=False)
 g2 = torch.tensor([-3.4, -4.0], dtype=torch.float64)
 g3 = torch.zeros(3, K, dtype=torch.float64)
+jac = gla.JacobiGNN.JacobiGNN()
+va3 = torch.rand(n, 3, K, generator=gen, dtype=torch.float64).to(dev)
+va3[:, 0, :] = -4.0
+ea2 = torch.cat([ev, torch.zeros_like(ev)], 1)
+gw = torch.tensor([0.7], dtype=torch.float64)
 for _ in range(2):
     out = cheb(va, ei, ev, g2)
     outp = powm(va, ei, ev, g3)
+    outj = jac(8, va3, ei, ea2, gw)
 torch.cuda.synchronize()
 a = torch.rand(64 * 1024 * 1024, dtype=torch.float64, device=dev)
 c = torch.rand(64 * 1024 * 1024, dtype=torch.float64, device=dev)
