@@ -569,12 +569,12 @@ def single_gpu(args, gla, dev):
         passes_p = -(-10 // tmax_p) if tmax_p >= 2 else 10   # temporally blocked: up to five iterations per pass (gla_power_fused)
         Mp = (passes_p + 1) * (mat + 16 * n * K) + 6 * 8 * n * K      # matrix + y in / out per pass (+ the Rayleigh pass), the tail's vectors
         tc, tpw = median(ms_c) * 1e-3, median(ms_p) * 1e-3
-        # JacobiGNN on the same 16 right-hand sides (vertex_attr [n, 3, K]): temporally blocked passes of four sweeps
+        # JacobiGNN on the same 16 right-hand sides (vertex_attr [n, 3, K]): temporally blocked passes of five sweeps
         vj = torch.stack([torch.full_like(b16, -4.0), b16, x16], 1)
         _, ms_j = timed_steps(lambda: jac(args.sweeps, vj, pr.ei, pr.edge_attr, pr.g), 3, 1)
         tj = median(ms_j) * 1e-3 / args.sweeps
         Bj16 = base + 8 * n + 24 * n * K
-        passes16 = max(1, -(-args.sweeps // 4)) if bool(info.dia_canon5) else args.sweeps        # (gla_jacobi_sweeps, K > 1: passes of <= 4)
+        passes16 = max(1, -(-args.sweeps // 5)) if bool(info.dia_canon5) else args.sweeps        # (gla_jacobi_sweeps, K > 1: passes of <= 5)
         Mj16 = (mat + 8 * n + 24 * n * K) * passes16 / args.sweeps                              # bytes moved per sweep
         del vj
         out["config3_k16"] = {

@@ -138,7 +138,7 @@ struct gla_march5_args {
 int gla_march5_pass(const gla_march5_args& a);
 
 // jacobik.hip: `sweeps` (2 .. GLA_JACOBIK_TS_MAX) Jacobi sweeps of K right-hand sides in one temporally blocked pass
-constexpr int GLA_JACOBIK_TS_MAX = 4;
+constexpr int GLA_JACOBIK_TS_MAX = 5;
 int gla_jacobik_pass(gla_csr* A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X, int64_t ldx,
                      void* Xout, int64_t ldxo, double w, int sweeps, hipStream_t st);
 

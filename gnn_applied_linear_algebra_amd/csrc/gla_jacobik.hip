@@ -384,6 +384,9 @@ int dispatch_ts(int ts, gla_csr* A, const T* diag, const T* b, int64_t ldb, cons
     case 4:
       if constexpr (D == 5) return launch_marchk<T, KV, 4, D>(A, diag, b, ldb, x, ldx, xo, ldxo, w, st);
       else return GLA_ERR_UNSUPPORTED;               // (9-point, four sweeps: the registers of one wave per SIMD)
+    case 5:
+      if constexpr (D == 5) return launch_marchk<T, KV, 5, D>(A, diag, b, ldb, x, ldx, xo, ldxo, w, st);
+      else return GLA_ERR_UNSUPPORTED;
     default: return GLA_ERR_UNSUPPORTED;
   }
 }

@@ -1960,7 +1960,7 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
   if (K > 1 && n_iters >= 2 && g_tuning.jacobi_fuse == 1 && diag && B && X0 && A->val_dtype == dtype && A->n_rows > 0 &&
       al16(Xout) && al16(Xtmp) && ldw % vw_k == 0 &&
       A->n_rows * (int64_t)K >= g_tuning.jacobi_min_rows && (gla_dia_canon5(A) || gla_dia_canon9(A))) {
-    const int tmax = gla_dia_canon5(A) ? GLA_JACOBIK_TS_MAX : GLA_JACOBIK_TS_MAX - 1;      // (9-point: three sweeps per pass)
+    const int tmax = gla_dia_canon5(A) ? GLA_JACOBIK_TS_MAX : 3;      // (5-point: five sweeps per pass, 9-point: three)
     const int k = (n_iters + tmax - 1) / tmax, base = n_iters / k, r = n_iters % k;       // base >= 2 for n_iters >= 2
     const void* src = X0;
     int64_t lsrc = ldx0;

@@ -579,7 +579,7 @@ class RowBlockJacobi(RowBlockOps):
         return own(cur).reshape(-1, 1)
 
     def _forward_temporal_k(self, n_iters, va, w):
-        """K right-hand sides (vertex_attr [n_local, 3, K]) on the block extended by ghost lines: passes of up to four sweeps
+        """K right-hand sides (vertex_attr [n_local, 3, K]) on the block extended by ghost lines: passes of up to five sweeps
         (canonical 9-point plans: three) -- the K-wide temporally blocked kernel of the single-GPU path, jacobi_marchk_kernel --
         with ONE exchange of the TS_MAX ghost lines per pass instead of one per sweep; the ghost lines of b and A_ii ride along
         in the first exchange.  Ghost lines are recomputed redundantly; own rows: the arithmetic of single sweeps, bit for bit.
@@ -591,7 +591,7 @@ class RowBlockJacobi(RowBlockOps):
         vw = 16 // va.element_size()
         if K % vw or not int(e["plan"].info.dia_canon5) in (1, 9):
             return None
-        tmax = 4 if int(e["plan"].info.dia_canon5) == 1 else 3
+        tmax = 5 if int(e["plan"].info.dia_canon5) == 1 else 3
         bufs = e.setdefault("buffers_k", {})
         buf = bufs.get(K)
         if buf is None:                                      # persistent extended operands: A_ii, b, two x buffers, one scratch

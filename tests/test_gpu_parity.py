@@ -1914,7 +1914,7 @@ def test_cheby_fused_randomised():
 
 
 def test_jacobi_multi_rhs_temporal_blocking_bit_identical():
-    """gla_jacobi_sweeps on K right-hand sides takes up to four (9-point: three) sweeps per pass on canonical stencil plans
+    """gla_jacobi_sweeps on K right-hand sides takes up to five (9-point: three) sweeps per pass on canonical stencil plans
     (jacobi_marchk_kernel): bit-identical to single sweeps for K = 2 ... 16, sweep counts 1 ... 11, 5- / 9-point patterns,
     holes, ragged grids, fp64 / fp32, operands with leading dimensions; through plan.jacobi_sweeps and JacobiGNN [n, 3, K]."""
     default_layout_only()
@@ -2225,7 +2225,7 @@ def test_jacobi_multi_rhs_division_fallback_special_values():
             b[n // 2:n // 2 + 12 * Nx, :] = 0.0                       # a region of exact zeros: numerators +-0
             x[n // 2:n // 2 + 12 * Nx, :] = torch.where(torch.arange(12 * Nx) % 2 == 0, 0.0, -0.0).to(torch.float64).reshape(-1, 1)
             dD, bD, xD = d(diag), d(b), d(x)
-            for ts in (2, 3, 4, 7):
+            for ts in (2, 3, 4, 5, 7, 10):
                 try:
                     check(lib().gla_set_option(b"jacobi_fuse", 0))
                     want = plan.jacobi_sweeps(dD, bD, xD, 0.7, ts)
