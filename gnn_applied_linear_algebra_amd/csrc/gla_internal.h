@@ -142,6 +142,10 @@ constexpr int GLA_JACOBIK_TS_MAX = 5;
 int gla_jacobik_pass(gla_csr* A, int dtype, int K, const void* diag, const void* B, int64_t ldb, const void* X, int64_t ldx,
                      void* Xout, int64_t ldxo, double w, int sweeps, hipStream_t st);
 
+// powerk.hip: the Rayleigh tail of the power method as a one-level pass of the march kernel (gla_power_rayleigh tries it first)
+int gla_power_tail_pass(gla_csr* A, int dtype, int K, const void* Y, int64_t ldy, const void* nrm, void* Bout, int64_t ldb,
+                        void* B2out, int64_t ldb2, void* nA_out, void* bb_out, void* work, int64_t work_bytes, hipStream_t st);
+
 // plan.hip
 int gla_sort_rows_stable(int64_t nnz, int64_t n_rows, const int64_t* row, int32_t* perm_out,
                          uint32_t* keys_sorted, hipStream_t stream);

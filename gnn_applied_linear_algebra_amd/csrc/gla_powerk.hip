@@ -48,11 +48,16 @@ __device__ __forceinline__ bool sig_all_ones(T v) {
 // so the 2 TS halo points either side that every strip recomputes are a fifth of its work instead of almost a half (K = 16, TS = 5)
 template <int KV> struct PowThreads { static constexpr int nt = KV >= 4 ? 512 : GLA_BLOCK; };
 
-template <typename T, int VW, int KV, int TS, int D, int NT>
+// TAIL (TS = 1 only; gla_power_rayleigh: layer 3 of the last iteration and the two Rayleigh layers, PowerMethodGNN.py:187-294,
+// with the module's [b, b^2] result): level 0 is b = operand ./ nrm, level 1 is A b; b goes to yout and b^2 to y2out, A b is
+// not stored; the sums are sum b^2 (first K partials) and sum b (A b) (second K).
+template <typename T, int VW, int KV, int TS, int D, int NT, bool TAIL = false>
 __global__ __launch_bounds__(NT) void power_march_kernel(PowK pv, const T* __restrict__ x0, int64_t ldx0,
-                                                                const T* __restrict__ nrm, T* __restrict__ yout, int64_t ldy,
-                                                                T* __restrict__ partials, int lines, int nstrips,
-                                                                int64_t nlines, TileMap tm) {
+                                                         const T* __restrict__ nrm, T* __restrict__ yout, int64_t ldy,
+                                                         T* __restrict__ partials, int lines, int nstrips,
+                                                         int64_t nlines, TileMap tm, T* __restrict__ y2out = nullptr,
+                                                         int64_t ldy2 = 0) {
+  static_assert(!TAIL || TS == 1, "the Rayleigh tail is a one-level pass");
   constexpr int K = KV * VW;
   constexpr int BP = NT / KV;                      // grid points of a strip
   constexpr int LWV = (BP + 2) * KV;               // lane vectors of a line in LDS: point ii at [(1 + ii) * KV + q]
@@ -148,7 +153,14 @@ __global__ __launch_bounds__(NT) void power_march_kernel(PowK pv, const T* __res
       buf[((j_first + 63) % 3) * LWV + (1 + ii) * KV + q] = h[0][2];
     }
     if constexpr (TS == 1) {                       // (the level below the last is the operand itself: line 0 of the block)
-      if (owner && in_i && L > 0 && J0 * pv.S + gi < pv.n_rows) sq[0] = sq[0] + h[0][2] * h[0][2];
+      if (owner && in_i && L > 0 && J0 * pv.S + gi < pv.n_rows) {
+        const TV b2 = h[0][2] * h[0][2];
+        sq[0] = sq[0] + b2;
+        if constexpr (TAIL) {
+          stv<TV>(yout + (J0 * pv.S + gi) * ldy + q * VW, h[0][2]);
+          stv<TV>(y2out + (J0 * pv.S + gi) * ldy2 + q * VW, b2);
+        }
+      }
     }
     // x^(k) is fetched PD line steps ahead.  PD = 3 measured no gain over 1 at K = 16 (5.41 ms per 10 iterations either way):
     // the pass is not bound by the loads in flight -- the counters (profiles/r03/pmc_k16_summary.txt) show the VALU ~46 % busy
@@ -166,11 +178,15 @@ __global__ __launch_bounds__(NT) void power_march_kernel(PowK pv, const T* __res
     for (int s = 0; s < NC; ++s) cfull[s] = false;
 
     // level t of row (line, this lane's point) is xn: the last two levels are summed, the last one goes to HBM
-    auto finish = [&](const Coef& cc, int t, int line, TV xn) {
+    auto finish = [&](const Coef& cc, int t, int line, TV xn, TV ctr) {      // ctr: the row's value on the level below
       if (t >= TS - 1 && t >= 1) {
         if (cc.lv && owner && line >= 0 && line < L) {
-          sq[t - (TS - 1)] = sq[t - (TS - 1)] + xn * xn;
-          if (t == TS) stv<TV>(yout + ((J0 + line) * pv.S + gi) * ldy + q * VW, xn);
+          if constexpr (TAIL) {
+            sq[1] = sq[1] + ctr * xn;                // y_i = b_i (A b)_i, n_A = sum y   (PowerMethodGNN.py:209-266)
+          } else {
+            sq[t - (TS - 1)] = sq[t - (TS - 1)] + xn * xn;
+            if (t == TS) stv<TV>(yout + ((J0 + line) * pv.S + gi) * ldy + q * VW, xn);
+          }
         }
       }
     };
@@ -178,7 +194,14 @@ __global__ __launch_bounds__(NT) void power_march_kernel(PowK pv, const T* __res
       const TV x1 = normalised(xq[0]);
       if constexpr (TS == 1) {                     // (the level below the last is the operand itself)
         const int64_t gj = J0 + jl + 1;
-        if (owner && in_i && jl + 1 >= 0 && jl + 1 < L && gj * pv.S + gi < pv.n_rows) sq[0] = sq[0] + x1 * x1;
+        if (owner && in_i && jl + 1 >= 0 && jl + 1 < L && gj * pv.S + gi < pv.n_rows) {
+          const TV b2 = x1 * x1;
+          sq[0] = sq[0] + b2;
+          if constexpr (TAIL) {
+            stv<TV>(yout + (gj * pv.S + gi) * ldy + q * VW, x1);
+            stv<TV>(y2out + (gj * pv.S + gi) * ldy2 + q * VW, b2);
+          }
+        }
       }
       if constexpr (D == 5) {
         __syncthreads();
@@ -204,7 +227,7 @@ __global__ __launch_bounds__(NT) void power_march_kernel(PowK pv, const T* __res
               h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
               row[2 * LWV + KV] = xn;
             }
-            finish(c[ci], t, jl - (t - 1), xn);
+            finish(c[ci], t, jl - (t - 1), xn, h[t - 1][1]);
           }
         }
       } else {
@@ -232,7 +255,7 @@ __global__ __launch_bounds__(NT) void power_march_kernel(PowK pv, const T* __res
               h[t][0] = h[t][1]; h[t][1] = h[t][2]; h[t][2] = xn;
               same[3 * LWV + KV] = xn;
             }
-            finish(c[ci], t, jl - (t - 1), xn);
+            finish(c[ci], t, jl - (t - 1), xn, h[t - 1][1]);
           }
         }
       }
@@ -305,12 +328,72 @@ int launch_power(gla_csr* A, const T* x, int64_t ldx, const T* nrm, T* y, int64_
     if (!raised) { GLA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); raised = true; }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(NT), lds, st,
-                     pv, x, ldx, nrm, y, ldy, work, g.lines, g.nstrips, g.nlines, tm);
+                     pv, x, ldx, nrm, y, ldy, work, g.lines, g.nstrips, g.nlines, tm, (T*)nullptr, (int64_t)0);
   GLA_LAUNCH_CHECK();
   // second stage: one workgroup per (level, rhs), workgroup partials added in block order
   hipLaunchKernelGGL((col_dot_stage2<T>), dim3(2 * K), dim3(GLA_BLOCK), 0, st, work, g.nblocks, 2 * K, sumsq);
   GLA_LAUNCH_CHECK();
   return GLA_OK;
+}
+
+// second stage of the Rayleigh tail: column k < K of the block partials -> bb_out[k] (sum b^2), column K + k -> nA_out[k]
+template <typename T>
+__global__ __launch_bounds__(GLA_BLOCK) void tail_sums_kernel(const T* __restrict__ partial, int nblocks, int K,
+                                                              T* __restrict__ bb_out, T* __restrict__ nA_out) {
+  __shared__ T red[GLA_BLOCK];                   // one workgroup per column, fixed-order tree (as col_dot_stage2)
+  const int tid = threadIdx.x, k = blockIdx.x;
+  T acc = T(0);
+  for (int b = tid; b < nblocks; b += GLA_BLOCK) acc = acc + partial[(int64_t)b * 2 * K + k];
+  red[tid] = acc;
+  __syncthreads();
+  for (int st = GLA_BLOCK / 2; st > 0; st >>= 1) {
+    if (tid < st) red[tid] = red[tid] + red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) (k < K ? bb_out[k] : nA_out[k - K]) = red[0];
+}
+
+template <typename T, int VW, int KV, int D>
+int launch_power_tail(gla_csr* A, const T* y, int64_t ldy, const T* nrm, T* bout, int64_t ldb, T* b2out, int64_t ldb2,
+                      T* nA_out, T* bb_out, T* work, int64_t work_bytes, hipStream_t st) {
+  constexpr int NT = PowThreads<KV>::nt;
+  constexpr int BP = NT / KV, K = KV * VW;
+  static_assert(BP - 2 >= 1, "strip too narrow");
+  PowK pv;
+  pv.val = A->dia_val;
+  pv.mask = A->dia_mask;
+  pv.S = A->dia_S;
+  pv.n_rows = A->n_rows; pv.n_cols = A->n_cols;
+  const PowGeom g = pow_geom<KV, 1>(A);
+  if ((int64_t)g.nblocks * 2 * K * (int64_t)sizeof(T) > work_bytes) return GLA_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)(D == 5 ? 2 : 3) * (BP + 2) * KV * VW * sizeof(T);
+  TileMap tm;
+  tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
+  tm.n_tiles = g.nblocks;
+  set_tile_mapping(tm);
+  hipLaunchKernelGGL((power_march_kernel<T, VW, KV, 1, D, NT, true>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(NT), lds, st,
+                     pv, y, ldy, nrm, bout, ldb, work, g.lines, g.nstrips, g.nlines, tm, b2out, ldb2);
+  GLA_LAUNCH_CHECK();
+  hipLaunchKernelGGL((tail_sums_kernel<T>), dim3(2 * K), dim3(GLA_BLOCK), 0, st, work, g.nblocks, K, bb_out, nA_out);
+  GLA_LAUNCH_CHECK();
+  return GLA_OK;
+}
+
+template <typename T, int VW, int D>
+int pow_tail_dispatch_kv(int kv, gla_csr* A, const T* y, int64_t ldy, const T* nrm, T* bout, int64_t ldb, T* b2out, int64_t ldb2,
+                         T* nA_out, T* bb_out, T* work, int64_t work_bytes, hipStream_t st) {
+  if constexpr (VW == 1) {
+    return kv == 1 ? launch_power_tail<T, 1, 1, D>(A, y, ldy, nrm, bout, ldb, b2out, ldb2, nA_out, bb_out, work, work_bytes, st)
+                   : GLA_ERR_UNSUPPORTED;
+  } else {
+    switch (kv) {
+      case 1: return launch_power_tail<T, VW, 1, D>(A, y, ldy, nrm, bout, ldb, b2out, ldb2, nA_out, bb_out, work, work_bytes, st);
+      case 2: return launch_power_tail<T, VW, 2, D>(A, y, ldy, nrm, bout, ldb, b2out, ldb2, nA_out, bb_out, work, work_bytes, st);
+      case 4: return launch_power_tail<T, VW, 4, D>(A, y, ldy, nrm, bout, ldb, b2out, ldb2, nA_out, bb_out, work, work_bytes, st);
+      case 8: return launch_power_tail<T, VW, 8, D>(A, y, ldy, nrm, bout, ldb, b2out, ldb2, nA_out, bb_out, work, work_bytes, st);
+      default: return GLA_ERR_UNSUPPORTED;
+    }
+  }
 }
 
 // (levels per pass the register file carries at two workgroups per CU: 5 on the 5-point pattern, 3 on the 9-point one)
@@ -393,6 +476,33 @@ int64_t gla_power_fused_work_bytes(gla_csr_t A, int dtype, int K, int iters) {
   const int nb = pow_blocks(kv, iters, A);
   return nb < 0 ? 0 : (int64_t)nb * 2 * K * (dtype == GLA_F64 ? 8 : 4);
 }
+
+}  // extern "C"
+
+// The Rayleigh tail of PowerMethodGNN on canonical stencil plans as a one-level pass of the march kernel: B = Y ./ nrm (as
+// gla_power_step divides), B2 = B .* B, nA_out[k] = sum_i B[i,k] (A B)[i,k], bb_out[k] = sum_i B[i,k]^2.  GLA_ERR_UNSUPPORTED when the
+// plan / K / alignment / work area does not qualify: gla_power_rayleigh then runs its blocked-SpMM tail.
+int gla_power_tail_pass(gla_csr* A, int dtype, int K, const void* Y, int64_t ldy, const void* nrm, void* Bout, int64_t ldb,
+                        void* B2out, int64_t ldb2, void* nA_out, void* bb_out, void* work, int64_t work_bytes, hipStream_t st) {
+  int vw, kv;
+  if (!pow_plan_ok(A) || !pow_shape(dtype, K, vw, kv) || gla_power_fused_max_iters(A, dtype, K) < 1) return GLA_ERR_UNSUPPORTED;
+  if (vw > 1 && (!al16(Y) || !al16(Bout) || !al16(B2out) || ldy % vw != 0 || ldb % vw != 0 || ldb2 % vw != 0)) return GLA_ERR_UNSUPPORTED;
+  const bool c5 = gla_dia_canon5(A);
+  if (dtype == GLA_F64) {
+    typedef double T;
+    if (vw == 1) return c5 ? pow_tail_dispatch_kv<T, 1, 5>(kv, A, (const T*)Y, ldy, (const T*)nrm, (T*)Bout, ldb, (T*)B2out, ldb2, (T*)nA_out, (T*)bb_out, (T*)work, work_bytes, st)
+                           : pow_tail_dispatch_kv<T, 1, 9>(kv, A, (const T*)Y, ldy, (const T*)nrm, (T*)Bout, ldb, (T*)B2out, ldb2, (T*)nA_out, (T*)bb_out, (T*)work, work_bytes, st);
+    return c5 ? pow_tail_dispatch_kv<T, 2, 5>(kv, A, (const T*)Y, ldy, (const T*)nrm, (T*)Bout, ldb, (T*)B2out, ldb2, (T*)nA_out, (T*)bb_out, (T*)work, work_bytes, st)
+              : pow_tail_dispatch_kv<T, 2, 9>(kv, A, (const T*)Y, ldy, (const T*)nrm, (T*)Bout, ldb, (T*)B2out, ldb2, (T*)nA_out, (T*)bb_out, (T*)work, work_bytes, st);
+  }
+  typedef float T;
+  if (vw == 1) return c5 ? pow_tail_dispatch_kv<T, 1, 5>(kv, A, (const T*)Y, ldy, (const T*)nrm, (T*)Bout, ldb, (T*)B2out, ldb2, (T*)nA_out, (T*)bb_out, (T*)work, work_bytes, st)
+                         : pow_tail_dispatch_kv<T, 1, 9>(kv, A, (const T*)Y, ldy, (const T*)nrm, (T*)Bout, ldb, (T*)B2out, ldb2, (T*)nA_out, (T*)bb_out, (T*)work, work_bytes, st);
+  return c5 ? pow_tail_dispatch_kv<T, 4, 5>(kv, A, (const T*)Y, ldy, (const T*)nrm, (T*)Bout, ldb, (T*)B2out, ldb2, (T*)nA_out, (T*)bb_out, (T*)work, work_bytes, st)
+            : pow_tail_dispatch_kv<T, 4, 9>(kv, A, (const T*)Y, ldy, (const T*)nrm, (T*)Bout, ldb, (T*)B2out, ldb2, (T*)nA_out, (T*)bb_out, (T*)work, work_bytes, st);
+}
+
+extern "C" {
 
 // `iters` power iterations in one pass: Y = A^iters (X ./ nrm_in) (nrm_in == nullptr: X as given), sumsq_out[k] =
 // sum_i (A^(iters-1) (X ./ nrm_in))[i, k]^2, sumsq_out[K + k] = sum_i Y[i, k]^2.  X and Y must not alias.  work:

@@ -2101,6 +2101,11 @@ int gla_power_rayleigh(gla_csr_t A, int dtype, int K, const void* Y, int64_t ldy
     const int64_t half = power_partials(A) * K + (int64_t)DOT_BLOCKS_MAX * K;      // elements of one gla_power_step work area
     T* w1 = (T*)work;
     T* w2 = w1 + half;
+    if (g_tuning.jacobi_fuse == 1) {                  // canonical stencil plans: one level of the march kernel (gla_powerk.hip)
+      const int rt = gla_power_tail_pass(A, dtype, K, Y, ldy, nrm_in, Bout, ldb, B2out, ldb2, nA_out, bb_out, work,
+                                         2 * half * (int64_t)sizeof(T), st);
+      if (rt != GLA_ERR_UNSUPPORTED) return rt;
+    }
     EpiRayleigh<T> epi{{nullptr, 0, (const T*)nrm_in, (const T*)rnrm_in, w1}, (const T*)Y, ldy, (T*)Bout, ldb, (T*)B2out, ldb2, w2};
     const int kv = dia2d_kv<T>(A, K, (const T*)Y, ldy, epi, 0);
     if (!kv) return GLA_ERR_UNSUPPORTED;              // (no blocked stencil kernel for this plan / K: unfused tail)

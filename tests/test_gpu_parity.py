@@ -1852,8 +1852,9 @@ def test_relaxation_weight_cache_follows_in_place_updates():
 def test_power_rayleigh_tail_fused():
     """gla_power_rayleigh (layer 3 of the last power iteration + both Rayleigh layers + the [b, b^2] result in one pass):
     b and b^2 bit-identical to the unfused tail (gla_col_scale_rsqrt, square), n_A = sum b (A b) and sum b^2 to rounding
-    (block partials instead of gla_col_dot's order); 5- and 9-point plans, K = 2 ... 16, fp64 / fp32; declined (None)
-    for K = 1 and non-stencil plans."""
+    (block partials instead of gla_col_dot's order); 5- and 9-point plans, K = 1 ... 16, fp64 / fp32 -- on canonical stencil
+    plans a one-level pass of the power march kernel (gla_power_tail_pass), which also serves K = 1; declined (None) on
+    non-stencil plans."""
     default_layout_only()
     from gnn_applied_linear_algebra_amd.plan import col_dot, col_scale_rsqrt
     gen = torch.Generator().manual_seed(77)
@@ -1862,8 +1863,8 @@ def test_power_rayleigh_tail_fused():
         for dtype in (torch.float64, torch.float32):
             plan = gla.CsrPlan(d(ei), n)
             plan.set_values(d(ev.to(dtype)))
-            for K in (2, 4, 8, 16):
-                if dtype == torch.float32 and K < 4:
+            for K in (1, 2, 4, 8, 16):
+                if dtype == torch.float32 and K in (2,):
                     continue                                   # (a 16-byte vector is four floats)
                 y = d(torch.rand(n, K, generator=gen, dtype=torch.float64).to(dtype) - 0.3)
                 ss = col_dot(y, y)
@@ -1878,9 +1879,14 @@ def test_power_rayleigh_tail_fused():
                 tol = 1e-12 if dtype == torch.float64 else 2e-5
                 assert torch.allclose(got[0], col_dot(b, plan.spmm(b)), rtol=tol, atol=0), (name, dtype, K)
                 assert torch.allclose(got[1], col_dot(b, b), rtol=tol, atol=0), (name, dtype, K)
-            y1 = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
-            r1 = torch.zeros(n, 2, 1, dtype=dtype, device=DEV)
-            assert plan.power_rayleigh(y1, torch.sqrt(col_dot(y1, y1)), r1[:, 0, :], r1[:, 1, :]) is None
+    # a non-stencil plan: no fused tail
+    ei, ev = rp.laplacianfun_torch(40, 30)
+    perm = torch.randperm(1200, generator=gen)
+    plan = gla.CsrPlan(d(perm[ei]), 1200)
+    plan.set_values(d(ev))
+    y1 = d(torch.rand(1200, 2, generator=gen, dtype=torch.float64))
+    r1 = torch.zeros(1200, 2, 2, dtype=torch.float64, device=DEV)
+    assert plan.power_rayleigh(y1, torch.sqrt(col_dot(y1, y1)), r1[:, 0, :], r1[:, 1, :]) is None
 
 
 def test_jacobi_march_randomised():
