@@ -460,6 +460,30 @@ class RowBlockOps:
                 pairs.append((lower, vec[e["off"] + self.part.n_local:].reshape(-1)))
         self._copy_batch(pairs)
 
+    def ext_tensor(self, *trailing, dtype=None):
+        """An operand allocated WITH its ghost rows: the rank's own-row view [n_local, *trailing] of a zero tensor
+        [n_ext, *trailing].  The ghost-line routes (RowBlockJacobi on [n_local, 3, K], RowBlockCheby's b and x0) read such an
+        operand in place -- ghost rows are filled around it, nothing is copied: a plain tensor costs one copy into the
+        extended block per call (2 x 4.2 GB for b and x at 4096^2 x 16, more than half of what the fused Chebyshev pass
+        itself moves).  Without a ghost-line route: an ordinary tensor."""
+        e, nl = self.ext, self.part.n_local
+        if e is None:
+            return torch.zeros((nl, *trailing), dtype=dtype or torch.float64,
+                               device=self.plan.device if hasattr(self, "plan") else None)
+        full = torch.zeros((e["n_ext"], *trailing), dtype=dtype or e["dtype"], device=e["dev"])
+        view = full[e["off"]:e["off"] + nl]
+        view._gla_ext = full
+        return view
+
+    def _ext_of(self, t, trailing):
+        """The extended tensor behind an own-row view made by ext_tensor() (None for any other tensor)."""
+        full, e = getattr(t, "_gla_ext", None), self.ext
+        if full is None or e is None or full.shape[0] != e["n_ext"] or tuple(full.shape[1:]) != tuple(trailing) \
+                or full.dtype != t.dtype or full.device != t.device or not full.is_contiguous() \
+                or t.shape[0] != self.part.n_local or t.data_ptr() != full[e["off"]:].data_ptr():
+            return None
+        return full
+
     def all_reduce_sum(self, t):
         """Sum over the ranks (power method partial sums): stream-ordered on the library's communicator when there is
         one, torch.distributed otherwise."""
@@ -601,26 +625,39 @@ class RowBlockJacobi(RowBlockOps):
         d_ext, b_ext, cur, nxt, tmp = buf
         own = lambda v: v[off:off + nl]                      # noqa: E731
         own(d_ext).copy_(va[:, 0, 0])
-        own(b_ext).copy_(va[:, 1, :])
-        own(cur).copy_(va[:, 2, :])
+        va_full = self._ext_of(va, (3, K))                   # vertex_attr allocated by ext_tensor(3, K): read in place
+        if va_full is None:
+            own(b_ext).copy_(va[:, 1, :])
+            own(cur).copy_(va[:, 2, :])
+            b_op, ldb = b_ext, K
+        else:
+            b_op, ldb = va_full[:, 1, :], 3 * K              # (the library takes leading dimensions)
         kp = -(-n_iters // tmax)
         base, rem = divmod(n_iters, kp)
         code, st, h = dtype_code(dt), stream_ptr(dev), e["plan"]._h
         first = True
+        scratch = [cur, nxt]
         for i in range(kp):
             ts = base + (1 if i < rem else 0)
-            vecs = [d_ext, b_ext, cur] if first else [cur]
+            x_op, ldx = cur, K
+            if first and va_full is not None:                # ghost lines of whole AoS rows (A_ii, b, x: one vector 3 K wide)
+                vecs = [d_ext, va_full.reshape(n_ext, 3 * K)]
+                x_op, ldx = va_full[:, 2, :], 3 * K
+            else:
+                vecs = [d_ext, b_ext, cur] if first else [cur]
             first = False
             self._fill_ghosts(vecs, self._ghost_exchange([own(v) for v in vecs]))
-            rc = lib().gla_jacobi_sweeps(h, code, K, ptr(d_ext), ptr(b_ext), K, ptr(cur), K, ptr(nxt), ptr(tmp), K, w, ts, st)
+            if i == kp - 1:                                  # the last pass writes into a buffer the caller keeps (no clone)
+                nxt = torch.empty((n_ext, K), dtype=dt, device=dev)
+            rc = lib().gla_jacobi_sweeps(h, code, K, ptr(d_ext), ptr(b_op), ldb, ptr(x_op), ldx, ptr(nxt), ptr(tmp), K, w, ts, st)
             if rc == -5 and i == 0:
                 self._ghost_pending = None
                 return None
             check(rc)
             cur, nxt = nxt, cur
-        bufs[K] = (d_ext, b_ext, cur, nxt, tmp)
+        bufs[K] = (d_ext, b_ext, scratch[0], scratch[1], tmp)
         self._ghost_pending = None
-        return own(cur).unsqueeze(1).clone()
+        return own(cur).unsqueeze(1)
 
     def capture_forward(self, n_iters, vertex_attr, g):
         """forward(n_iters, vertex_attr, g) captured into a HIP graph (torch.cuda.CUDAGraph): returns run(vertex_attr) -> x.
@@ -728,12 +765,26 @@ class RowBlockCheby(RowBlockOps):
             buf = bufs[K] = [torch.zeros((n_ext, K), dtype=dt, device=dev) for _ in range(7)]
         b_ext, xa, ra, pa, xb, rb, pb = buf
         own = lambda v: v[off:off + nl]                      # noqa: E731
-        own(b_ext).copy_(b)
-        own(xa).copy_(x0)
-        self._fill_ghosts([b_ext, xa], self._ghost_exchange([own(b_ext), own(xa)]))
+        b_full, x_full = self._ext_of(b, (K,)), self._ext_of(x0, (K,))      # operands allocated by ext_tensor(K): read in place
+        if b_full is None:
+            own(b_ext).copy_(b)
+        else:
+            b_ext = b_full
+        x_in = xa                                            # the first pass's x operand (xa itself stays a scratch destination)
+        if x_full is None:
+            own(xa).copy_(x0)
+        else:
+            x_in = x_full
+        self._fill_ghosts([b_ext, x_in], self._ghost_exchange([own(b_ext), own(x_in)]))
+        # The LAST pass writes into extended buffers allocated for this call and the caller gets their own-row views: no
+        # clone of x, r, p (three K-wide copies were 12.6 GB at 4096^2 x 16 -- more than the fused pass itself moves).  Every
+        # ghost row of an output is written by the kernel before anything reads it: torch.empty is enough.
+        fresh = lambda: [torch.empty((n_ext, K), dtype=dt, device=dev) for _ in range(3)]   # noqa: E731
+        if deg <= 4:
+            xb, rb, pb = fresh()
         done = 0
         for m in range(min(deg, 4), 1, -1):                  # the most steps this plan's fused kernel takes
-            if plan.cheby_fused(b_ext, xa, xb, rb, pb, [float(a) for a in alphas[:m]], [0.0] + [float(v) for v in betas[1:m]]):
+            if plan.cheby_fused(b_ext, x_in, xb, rb, pb, [float(a) for a in alphas[:m]], [0.0] + [float(v) for v in betas[1:m]]):
                 done = m
                 break
         if done == 0:
@@ -750,15 +801,20 @@ class RowBlockCheby(RowBlockOps):
             sizes = [base + 1] * extra + [base] * (n_pass - extra) if base >= 2 else [2] * (rest // 2) + [1] * (rest % 2)
         elif rest == 1:
             sizes = [1]
-        for sz in sizes:
+        owned = deg <= 4 and done == deg                     # (X, R, P) are this call's own buffers
+        for i_sz, sz in enumerate(sizes):
             vecs = [R, X, P]
             self._fill_ghosts(vecs, self._ghost_exchange([own(v) for v in vecs]))
+            if sz >= 2 and i_sz == len(sizes) - 1:           # the last pass: fresh destination set
+                X2, R2, P2 = fresh()
             if sz >= 2 and plan.cheby_fused_next(R, X, P, X2, R2, P2, float(alphas[done - 1]),
                                                   [float(a) for a in alphas[done:done + sz]],
                                                   [float(v) for v in betas[done:done + sz]]):
                 X, R, P, X2, R2, P2 = X2, R2, P2, X, R, P
                 done += sz
+                owned = i_sz == len(sizes) - 1
                 continue
+            owned = False
             for it in range(done + 1, done + sz + 1):        # step kernels on the extended block (R, X in place, P ping-pongs)
                 if it > done + 1:
                     vecs = [R, X, P]
@@ -768,6 +824,8 @@ class RowBlockCheby(RowBlockOps):
             done += sz
         cur = (X, R, P)
         self._ghost_pending = None
+        if owned:
+            return own(cur[0]), own(cur[1]), own(cur[2]), _g_out(c, d, alphas, betas, g)
         return own(cur[0]).clone(), own(cur[1]).clone(), own(cur[2]).clone(), _g_out(c, d, alphas, betas, g)
 
     def forward(self, deg, b, x0, g):

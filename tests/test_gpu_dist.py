@@ -586,6 +586,11 @@ def test_k_wide_ghost_routes_self_halo_rccl():
             check(lib().gla_set_option(b"jacobi_fuse", 1))
         got = jac.forward(its, va, g)
         assert got.shape == (n, 1, K) and torch.equal(got[:, 0, :], x), ("jacobi K", its)
+        va_e = jac.ext_tensor(3, K)                      # operand allocated with its ghost rows: read in place, same bits
+        va_e.copy_(va)
+        assert jac._ext_of(va_e, (3, K)) is not None and jac._ext_of(va, (3, K)) is None
+        got_e = jac.forward(its, va_e, g)
+        assert torch.equal(got_e, got) and torch.equal(va_e, va), ("jacobi K, ext operand", its)
     # ---- Chebyshev: fused passes with ghost exchanges vs one step at a time on the periodic extension
     b = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
     x0 = torch.rand(n, K, generator=gen, dtype=torch.float64).to(dev)
@@ -604,6 +609,12 @@ def test_k_wide_ghost_routes_self_halo_rccl():
             x, r, p = xe_io[off:off + n].clone(), re_io[off:off + n].clone(), pe_out[off:off + n].clone()
         gx, gr, gp, _ = ch.forward(deg, b, x0, gch)
         assert torch.equal(gx, x) and torch.equal(gr, r) and torch.equal(gp, p), ("cheby", deg)
+        b_e, x_e = ch.ext_tensor(K), ch.ext_tensor(K)    # operands allocated with their ghost rows
+        b_e.copy_(b)
+        x_e.copy_(x0)
+        ex, er, ep, _ = ch.forward(deg, b_e, x_e, gch)
+        assert torch.equal(ex, x) and torch.equal(er, r) and torch.equal(ep, p), ("cheby, ext operands", deg)
+        assert torch.equal(b_e, b) and torch.equal(x_e, x0), ("cheby: operands untouched", deg)
     torch.cuda.synchronize()
     lib().gla_comm_destroy(comm._h)
     comm._h = None
