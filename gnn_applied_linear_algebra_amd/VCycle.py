@@ -321,6 +321,16 @@ class AMGHierarchy:
                                     y.stride(0), stream_ptr(b.device)))
         return y
 
+    def _zero_guess(self, like):
+        """The zero initial guess of a coarse level: one read-only buffer per (shape, dtype) instead of a fill launch per level
+        and cycle (every consumer -- the smoothers, the coarsest solve -- is out of place)."""
+        cache = self.__dict__.setdefault("_zeros", {})
+        key = (tuple(like.shape), like.dtype, like.device)
+        z = cache.get(key)
+        if z is None:
+            z = cache[key] = torch.zeros_like(like)
+        return z
+
     def residual(self, b, x, level=0):
         """r = b - A_level x (GNNResidual on the level's plan)."""
         return self.plans[level].residual(b.contiguous(), x.contiguous())
@@ -381,6 +391,6 @@ class AMGHierarchy:
             x = self._smooth(level, self.n_pre, b, x)
             r = self.residual(b, x, level)
         rc = self.Pt[level].spmm(r)
-        xc = self.cycle(rc, torch.zeros_like(rc), level + 1)
+        xc = self.cycle(rc, self._zero_guess(rc), level + 1)
         x = self.P[level].spmm_add(x.contiguous(), xc.contiguous())       # x + P xc in one pass (gla_spmm_add)
         return self._smooth(level, self.n_post, b, x)
