@@ -381,22 +381,46 @@ class RowBlockOps:
         self.ext = dict(plan=plan, S=S, elo=elo, ehi=ehi, n_ext=ehi - elo, off=lo - elo, up=up, down=down,
                         slab=T * S, dtype=all_ev.dtype, dev=dev)
 
-    def _ghost_exchange(self, owns, begin_only=False):
+    def _ghost_exchange(self, owns, begin_only=False, st=None):
         """ONE all-gather of every rank's first and last TS_MAX grid lines of each vector in `owns` ([n_local] or [n_local, K]
         each, rows may be strided); returns per vector the (upper, lower) ghost slabs for this rank, flat (None where there is
         no neighbour).  With the library communicator the gather runs on its side stream: call with begin_only=True, launch
-        work that needs no ghosts, then _ghost_finish()."""
+        work that needs no ghosts, then _ghost_finish().  `st`: the HIP stream (ctypes pointer) everything is ordered on;
+        default: torch's current stream."""
         e, p = self.ext, self.part
         m = e["slab"]
         EXCHANGES[0] += 1
         widths = [own.numel() // max(own.shape[0], 1) for own in owns]
-        send = torch.cat([piece.reshape(-1) for own in owns for piece in (own[:m], own[-m:])])
         chunk = 2 * m * sum(widths)
+        if self.comm is not None and all(own.dim() == 1 for own in owns):
+            # (the hot case: single-rhs vectors.)  Persistent send / receive buffers per layout, packed by ONE gla_copy_batch launch
+            # on the given stream: no torch operator, hence no stream context and no allocator call on this path -- the host
+            # cost of a pass is what bounds small blocks (profiles/r03/dist_route_host_cost.txt)
+            from ._lib import check, dtype_code, lib, ptr, stream_ptr
+            dt, dev = owns[0].dtype, owns[0].device
+            key = ("xbuf", tuple(widths), dt)
+            bufs = self._lib_send.get(key) if hasattr(self, "_lib_send") else None
+            if bufs is None:
+                bufs = (torch.empty(chunk, dtype=dt, device=dev), torch.empty(p.world * chunk, dtype=dt, device=dev))
+                if not hasattr(self, "_lib_send"):
+                    self._lib_send = {}
+                self._lib_send[key] = bufs
+            send, recv = bufs
+            st = stream_ptr(dev) if st is None else st
+            pairs, pos = [], 0
+            for own in owns:
+                pairs += [(own[:m], send[pos:pos + m]), (own[-m:], send[pos + m:pos + 2 * m])]
+                pos += 2 * m
+            self._copy_batch(pairs, st)
+            check(lib().gla_comm_all_gather_begin(self.comm._h, dtype_code(dt), ptr(send), ptr(recv), chunk, st))
+            self._ghost_pending = (send, recv, widths, True)
+            return None if begin_only else self._ghost_finish(st)
+        send = torch.cat([piece.reshape(-1) for own in owns for piece in (own[:m], own[-m:])])
         recv = torch.empty(p.world * chunk, dtype=send.dtype, device=send.device)
         if self.comm is not None:
             from ._lib import check, dtype_code, lib, ptr, stream_ptr
             check(lib().gla_comm_all_gather_begin(self.comm._h, dtype_code(send.dtype), ptr(send), ptr(recv),
-                                                  chunk, stream_ptr(send.device)))
+                                                  chunk, stream_ptr(send.device) if st is None else st))
             self._ghost_pending = (send, recv, widths, True)    # keep the buffers alive until the gather has been waited for
         else:
             if send.is_cuda and dist.get_backend(p.group) == "gloo":   # rehearsal route: gloo moves host memory
@@ -406,15 +430,15 @@ class RowBlockOps:
             else:
                 dist.all_gather_into_tensor(recv, send, group=p.group)
             self._ghost_pending = (send, recv, widths, False)
-        return None if begin_only else self._ghost_finish()
+        return None if begin_only else self._ghost_finish(st)
 
-    def _ghost_finish(self):
+    def _ghost_finish(self, st=None):
         e, p = self.ext, self.part
         m = e["slab"]
         send, recv, widths, on_side_stream = self._ghost_pending
         if on_side_stream:
             from ._lib import check, lib, stream_ptr
-            check(lib().gla_halo_end(self.comm._h, stream_ptr(recv.device)))
+            check(lib().gla_halo_end(self.comm._h, stream_ptr(recv.device) if st is None else st))
         chunk = 2 * m * sum(widths)                          # a rank's chunk: per vector [first m rows | last m rows]
         out, base = [], 0
         ru, rd = e.get("up_src", p.rank - 1), e.get("down_src", p.rank + 1)      # (overridable: one-rank self-halo tests)
@@ -426,9 +450,9 @@ class RowBlockOps:
         return out
 
     @staticmethod
-    def _copy_batch(pairs):
-        """dst[:] = src for every (src, dst) pair of 1-D tensors (src may be strided) in ONE launch (gla_copy_batch); plain
-        copies for CPU tensors."""
+    def _copy_batch(pairs, st=None):
+        """dst[:] = src for every (src, dst) pair of 1-D tensors (src may be strided) in ONE launch (gla_copy_batch) on the HIP
+        stream `st` (default: torch's current stream); plain copies for CPU tensors."""
         pairs = [(s_, d_) for s_, d_ in pairs if d_.numel()]
         if not pairs:
             return
@@ -447,9 +471,10 @@ class RowBlockOps:
             dst = (ctypes.c_void_p * k)(*[d_.data_ptr() for _, d_ in chunk])
             cnt = (ctypes.c_int64 * k)(*[d_.numel() for _, d_ in chunk])
             strd = (ctypes.c_int64 * k)(*[max(1, s_.stride(0)) for s_, _ in chunk])
-            check(lib().gla_copy_batch(dtype_code(chunk[0][1].dtype), k, src, dst, cnt, strd, stream_ptr(chunk[0][1].device)))
+            check(lib().gla_copy_batch(dtype_code(chunk[0][1].dtype), k, src, dst, cnt, strd,
+                                       stream_ptr(chunk[0][1].device) if st is None else st))
 
-    def _fill_ghosts(self, ext_vecs, slabs):
+    def _fill_ghosts(self, ext_vecs, slabs, st=None):
         """Ghost lines of the extended vectors ([n_ext] or contiguous [n_ext, K]) from the gathered slabs, one launch."""
         e = self.ext
         pairs = []
@@ -458,7 +483,7 @@ class RowBlockOps:
                 pairs.append((upper, vec[:e["off"]].reshape(-1)))
             if lower is not None:
                 pairs.append((lower, vec[e["off"] + self.part.n_local:].reshape(-1)))
-        self._copy_batch(pairs)
+        self._copy_batch(pairs, st)
 
     def ext_tensor(self, *trailing, dtype=None):
         """An operand allocated WITH its ghost rows: the rank's own-row view [n_local, *trailing] of a zero tensor
@@ -568,8 +593,9 @@ class RowBlockJacobi(RowBlockOps):
                 side = e.get("side_stream")
                 if side is None:
                     side = e["side_stream"] = torch.cuda.Stream(device=dev)
+                st_side = ctypes.c_void_p(side.cuda_stream)
                 if not prefetched:
-                    self._ghost_exchange(owns, begin_only=True)
+                    self._ghost_exchange(owns, begin_only=True, st=st)
                 side.wait_stream(main)                        # cur / nxt as the previous pass left them
                 if from_aos:
                     check(lib().gla_jacobi_fused_parts_aos(h, code, ptr(va), va.stride(0), off, nl, ptr(d_ext), ptr(b_ext),
@@ -582,16 +608,15 @@ class RowBlockJacobi(RowBlockOps):
                         side.wait_stream(main)
                 else:
                     check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 1, T, st))
-                with torch.cuda.stream(side):
-                    self._fill_ghosts(vecs, self._ghost_finish())
-                    check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 2, T,
-                                                       stream_ptr(dev)))
-                    # The edge blocks are 2 T lines high: they alone produce the T own lines either end that the neighbours
-                    # want for the NEXT pass, so its exchange starts here, on the second stream, while the interior launch of
-                    # this pass is still running (nothing of it is left on the critical path of the main stream).
-                    prefetched = i + 1 < len(passes) and passes[i + 1] > 1
-                    if prefetched:
-                        self._ghost_exchange([own(nxt)], begin_only=True)
+                # (everything below is ordered on the second stream by explicit stream pointers: library calls only)
+                self._fill_ghosts(vecs, self._ghost_finish(st_side), st_side)
+                check(lib().gla_jacobi_fused_parts(h, code, ptr(d_ext), ptr(b_ext), ptr(cur), ptr(nxt), w, ts, 2, T, st_side))
+                # The edge blocks are 2 T lines high: they alone produce the T own lines either end that the neighbours
+                # want for the NEXT pass, so its exchange starts here, on the second stream, while the interior launch of
+                # this pass is still running (nothing of it is left on the critical path of the main stream).
+                prefetched = i + 1 < len(passes) and passes[i + 1] > 1
+                if prefetched:
+                    self._ghost_exchange([own(nxt)], begin_only=True, st=st_side)
                 main.wait_stream(side)
             else:
                 self._fill_ghosts(vecs, self._ghost_exchange(owns))
