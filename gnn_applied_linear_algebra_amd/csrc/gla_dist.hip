@@ -93,6 +93,7 @@ struct gla_comm {
   int rank = 0, nranks = 1, device = 0;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // gla_dist_jacobi_temporal: compute stream <-> second stream
 };
 
 extern "C" {
@@ -120,6 +121,8 @@ int gla_comm_create(const void* id_host, int rank, int nranks, gla_comm_t* out) 
   GLA_HIP_CHECK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
   GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   *out = c;
   return GLA_OK;
 }
@@ -130,6 +133,8 @@ int gla_comm_destroy(gla_comm_t c) {
   if (c->comm && g_rccl.ok) g_rccl.comm_destroy(c->comm);
   if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
   if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   delete c;
   return GLA_OK;
@@ -231,6 +236,110 @@ int gla_dist_jacobi_sweeps(gla_csr_t A, gla_comm_t c, int dtype, int K, const vo
     void* t = cur;
     cur = nxt;
     nxt = t;
+  }
+  return GLA_OK;
+}
+
+// JacobiGNN.forward (JacobiGNN.py:138-148) on a row block of whole grid lines EXTENDED by `ghost` ghost lines either side
+// (where a neighbour exists), temporally blocked: passes[i] sweeps in pass i, ONE all-gather of every rank's first and last
+// `ghost` lines per pass.  The whole call is enqueued from here on two streams (dist.py, RowBlockJacobi._forward_temporal
+// describes the same sequence driven from Python; ~45 us of interpreter time per pass are what this saves):
+//
+//   main   [pack + all-gather(0)]  interior(0) ........... wait  interior(1) ........... wait  ...
+//   side            wait: ghosts(0) edge(0) pack + all-gather(1) |     ghosts(1) edge(1) pack + all-gather(2) | ...
+//
+// The first pass reads A_ii, b, x from the AoS rows `va` (own rows only: plan row r = tensor row r - off) and leaves the
+// contiguous copies d_ext / b_ext behind; the few lines its edge blocks touch are copied by hand first.  The edge blocks are
+// 2 x ghost lines high, so they alone produce the own lines the neighbours want next: the next exchange starts when they end.
+// xa / xb: extended scratch iterates (xa receives the edge window of x first); x_last: the extended buffer the LAST pass writes.
+// send: 6 m elements, recv: nranks x 6 m (m = ghost x line length).  Canonical 5-point plans, every pass of 2 sweeps or more,
+// blocks of more than 2 (2 ghost + passes[0]) lines; GLA_ERR_UNSUPPORTED otherwise (the caller drives the general route).
+int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* va, int64_t ldva, int64_t off, int64_t n_local,
+                             void* d_ext, void* b_ext, void* xa, void* xb, void* x_last, void* send, void* recv, int ghost,
+                             int up, int down, int up_src, int down_src, double w, const int* passes, int n_passes,
+                             gla_stream_t main_stream, gla_stream_t side_stream) {
+  if (!A || !c || !va || !d_ext || !b_ext || !xa || !xb || !x_last || !send || !recv || !passes || n_passes < 1 || ldva < 3 ||
+      ghost < 1 || (dtype != GLA_F32 && dtype != GLA_F64) || off < 0 || n_local < 1 || xa == xb || x_last == xa || x_last == xb)
+    return GLA_ERR_INVALID_ARG;
+  if (!gla_dia_canon5(A) || A->dia_S <= 0) return GLA_ERR_UNSUPPORTED;
+  const int64_t S = A->dia_S, n_ext = A->n_rows, m = (int64_t)ghost * S;
+  if (n_ext % S != 0 || off + n_local > n_ext || (up && off != m) || (!up && off != 0) ||
+      (down && n_ext - off - n_local != m) || (!down && n_ext != off + n_local) || n_local < 2 * m)
+    return GLA_ERR_UNSUPPORTED;
+  for (int i = 0; i < n_passes; ++i)
+    if (passes[i] < 2 || passes[i] > ghost) return GLA_ERR_UNSUPPORTED;
+  if (n_ext / S <= 2 * (int64_t)(2 * ghost + passes[0])) return GLA_ERR_UNSUPPORTED;
+  if ((up && (up_src < 0 || up_src >= c->nranks)) || (down && (down_src < 0 || down_src >= c->nranks))) return GLA_ERR_INVALID_ARG;
+  hipStream_t mn = (hipStream_t)main_stream, sd = (hipStream_t)side_stream;
+  const size_t esz = dtype == GLA_F64 ? 8 : 4;
+  auto at = [&](const void* p, int64_t elems) -> const void* { return (const char*)p + (size_t)elems * esz; };
+  auto atw = [&](void* p, int64_t elems) -> void* { return (char*)p + (size_t)elems * esz; };
+  int rc;
+  void* cur = xa;
+  void* nxt = n_passes == 1 ? x_last : xb;
+  // ---- pass 0 ---------------------------------------------------------------------------------------------------------------
+  {
+    const int ts = passes[0];
+    const int64_t E = (int64_t)(2 * ghost + ts) * S;          // rows the first / last edge block reads
+    void* dst3[3] = {d_ext, b_ext, cur};
+    const void* src[8]; void* dst[8]; int64_t cnt[8], strd[8];
+    int k = 0;
+    const int64_t win[2][2] = {{0, E}, {n_ext - E, n_ext}};
+    for (int wdx = 0; wdx < 2; ++wdx) {
+      const int64_t a = win[wdx][0] > off ? win[wdx][0] : off;
+      const int64_t b = win[wdx][1] < off + n_local ? win[wdx][1] : off + n_local;
+      if (a >= b) continue;
+      for (int col = 0; col < 3; ++col) {
+        src[k] = at(va, (a - off) * ldva + col); dst[k] = atw(dst3[col], a); cnt[k] = b - a; strd[k] = ldva; ++k;
+      }
+    }
+    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, mn); if (rc) return rc; }
+    k = 0;                                                    // send = per column [first m own rows | last m own rows]
+    for (int col = 0; col < 3; ++col) {
+      src[k] = at(va, col); dst[k] = atw(send, 2 * m * col); cnt[k] = m; strd[k] = ldva; ++k;
+      src[k] = at(va, (n_local - m) * ldva + col); dst[k] = atw(send, 2 * m * col + m); cnt[k] = m; strd[k] = ldva; ++k;
+    }
+    rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, mn); if (rc) return rc;
+    rc = gla_comm_all_gather_begin(c, dtype, send, recv, 6 * m, mn); if (rc) return rc;
+    GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
+    GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
+    rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, ghost, mn); if (rc) return rc;
+    rc = gla_halo_end(c, sd); if (rc) return rc;
+    k = 0;
+    for (int col = 0; col < 3; ++col) {                       // the neighbour above's LAST lines / below's FIRST lines
+      if (up) { src[k] = at(recv, (int64_t)up_src * 6 * m + 2 * m * col + m); dst[k] = dst3[col]; cnt[k] = m; strd[k] = 1; ++k; }
+      if (down) { src[k] = at(recv, (int64_t)down_src * 6 * m + 2 * m * col); dst[k] = atw(dst3[col], off + n_local); cnt[k] = m; strd[k] = 1; ++k; }
+    }
+    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return rc; }
+    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 2, ghost, sd); if (rc) return rc;
+  }
+  // ---- passes 1 .. ----------------------------------------------------------------------------------------------------------
+  for (int i = 1; i <= n_passes; ++i) {
+    // on the second stream: the result of pass i - 1 is complete at its ends -> start the exchange of pass i, then join
+    if (i < n_passes) {
+      const void* src[2] = {at(nxt, off), at(nxt, off + n_local - m)};
+      void* dst[2] = {send, atw(send, m)};
+      const int64_t cnt[2] = {m, m};
+      rc = gla_copy_batch(dtype, 2, src, dst, cnt, nullptr, sd); if (rc) return rc;
+      rc = gla_comm_all_gather_begin(c, dtype, send, recv, 2 * m, sd); if (rc) return rc;
+    }
+    GLA_HIP_CHECK(hipEventRecord(c->ev_join, sd));
+    GLA_HIP_CHECK(hipStreamWaitEvent(mn, c->ev_join, 0));
+    if (i == n_passes) break;
+    { void* t = cur; cur = nxt; nxt = t; }
+    if (i == 1) nxt = xb == cur ? xa : xb;                    // (pass 0 wrote xb or x_last; from now on ping-pong xa / xb)
+    if (i == n_passes - 1) nxt = x_last;
+    const int ts = passes[i];
+    GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
+    GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
+    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 1, ghost, mn); if (rc) return rc;
+    rc = gla_halo_end(c, sd); if (rc) return rc;
+    const void* src[2]; void* dst[2]; int64_t cnt[2];
+    int k = 0;
+    if (up) { src[k] = at(recv, (int64_t)up_src * 2 * m + m); dst[k] = cur; cnt[k] = m; ++k; }
+    if (down) { src[k] = at(recv, (int64_t)down_src * 2 * m); dst[k] = atw(cur, off + n_local); cnt[k] = m; ++k; }
+    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, nullptr, sd); if (rc) return rc; }
+    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 2, ghost, sd); if (rc) return rc;
   }
   return GLA_OK;
 }

@@ -560,6 +560,29 @@ class RowBlockJacobi(RowBlockOps):
         # extended vectors.
         aos_first = (self.comm is not None and self.overlap and passes[0] > 1 and n_ext // S > 2 * (2 * T + passes[0])
                      and va.stride(1) == 1)
+        if aos_first and min(passes) > 1 and int(e["plan"].info.dia_canon5) == 1 and e.get("c_route", True):
+            # the whole call -- every pass's exchange, interior launch, ghost fill, edge launch and the next exchange -- enqueued
+            # by ONE library call on this stream and a second one (csrc/gla_dist.hip: gla_dist_jacobi_temporal)
+            m = T * S
+            xb = e.get("xbufs")
+            if xb is None or xb[0].dtype != dt:
+                xb = e["xbufs"] = (torch.empty(6 * m, dtype=dt, device=dev), torch.empty(p.world * 6 * m, dtype=dt, device=dev))
+            side = e.get("side_stream")
+            if side is None:
+                side = e["side_stream"] = torch.cuda.Stream(device=dev)
+            x_last = torch.empty(n_ext, dtype=dt, device=dev)
+            arr = (ctypes.c_int * len(passes))(*passes)
+            rc = lib().gla_dist_jacobi_temporal(h, self.comm._h, code, ptr(va), va.stride(0), off, nl, ptr(d_ext), ptr(b_ext),
+                                                ptr(cur), ptr(nxt), ptr(x_last), ptr(xb[0]), ptr(xb[1]), T, int(e["up"]),
+                                                int(e["down"]), int(e.get("up_src", p.rank - 1)), int(e.get("down_src", p.rank + 1)),
+                                                w, arr, len(passes), st, ctypes.c_void_p(side.cuda_stream))
+            if rc == 0:
+                EXCHANGES[0] += len(passes)
+                self._ghost_pending = None
+                return own(x_last).reshape(-1, 1)
+            if rc != -5:
+                check(rc)
+            e["c_route"] = False                             # (the library declined this block: Python-driven route from now on)
         if aos_first:
             E = (2 * T + passes[0]) * S                      # rows the first / last edge block (2 T lines high) reads
             pairs = []

@@ -394,6 +394,19 @@ int gla_dist_jacobi_sweeps(gla_csr_t A, gla_comm_t comm, int dtype, int K, const
                            int64_t ldb, void* Xa, void* Xb, int64_t n_in, const int32_t* send_idx, int64_t n_send,
                            int64_t S, void* send_buf, double w, int n_iters, int overlap, gla_stream_t stream);
 
+/* JacobiGNN.forward on a row block of whole grid lines extended by `ghost_lines` ghost lines either side, temporally blocked:
+ * passes[i] sweeps in pass i with ONE all-gather of every rank's first / last ghost lines per pass, the whole call enqueued from
+ * C on two streams (interior line blocks on `main_stream`; ghost fill, the two edge line blocks and the NEXT pass's exchange on
+ * `side_stream`).  vertex_attr: the rank's own AoS rows [n_local, >= 3] = [A_ii, b, x] (plan row r = tensor row r - row_offset);
+ * diag_ext / b_ext / xa / xb / x_last: extended work vectors (plan rows), the result is in x_last at plan-row positions; send:
+ * 6 m elements, recv: nranks x 6 m (m = ghost_lines x grid line length).  up / down: a neighbour above / below exists (its rank:
+ * up_src / down_src).  Canonical 5-point plans, passes of 2 .. ghost_lines sweeps; GLA_ERR_UNSUPPORTED otherwise.  The multi-GPU
+ * form of JacobiGNN.py:138-148 (BASELINE.json north_star; the reference has no distributed code). */
+int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* vertex_attr, int64_t ld, int64_t row_offset,
+                             int64_t n_local, void* diag_ext, void* b_ext, void* xa, void* xb, void* x_last, void* send,
+                             void* recv, int ghost_lines, int up, int down, int up_src, int down_src, double w,
+                             const int* passes, int n_passes, gla_stream_t main_stream, gla_stream_t side_stream);
+
 /* ---- builders ----------------------------------------------------------------------------------- */
 /* 5-point negative Laplacian on an Ny x Nx grid (reference: Ny == Nx == N), COO sorted row-major with
  * ascending columns: row/col int64 [nnz], val [nnz], nnz = 5*Nx*Ny - 2*Nx - 2*Ny.
