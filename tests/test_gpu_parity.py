@@ -1904,6 +1904,21 @@ def test_jacobi_march_randomised():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_power_randomised():
+    """tools/fuzz_power.py: 80 random grid shapes (narrow, short, ragged) / 5- and 9-point patterns with holes / K / pass sizes /
+    block heights through gla_power_fused and the Rayleigh tail pass, against the step-by-step kernels to rounding."""
+    import os
+    default_layout_only()
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GLA_OPTIONS", None)
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_power.py"), "80", "3"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_cheby_fused_randomised():
     """tools/fuzz_cheby_fused.py: 120 random grids / 5-point-type and 9-point patterns / K / degrees / dtypes through
     chebyshev_relax (fused pass + C-side step loop) against one kernel per step, bit for bit."""
