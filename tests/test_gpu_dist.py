@@ -477,7 +477,7 @@ def test_jacobi_fused_parts_and_library_all_gather():
     assert torch.equal(recv, send)
 
 
-@pytest.mark.parametrize("Nx,Ny", [(300, 200), (70, 40)])
+@pytest.mark.parametrize("Nx,Ny", [(300, 200), (70, 40), (1000, 64), (257, 49)])
 def test_temporal_route_self_halo_rccl(Nx, Ny):
     """dist.RowBlockJacobi._forward_temporal with a REAL (one-rank) RCCL communicator: the rank's upper and lower neighbour
     are the rank itself (a grid periodic in the line direction), so every pass goes through pack -> ncclAllGather on the
@@ -511,7 +511,7 @@ def test_temporal_route_self_halo_rccl(Nx, Ny):
     def periodic(own):                                   # [own's last T lines | own | own's first T lines]
         return torch.cat([own[-off:], own, own[:off]])
     d_e, b_e = periodic(va[:, 0].contiguous()), periodic(va[:, 1].contiguous())
-    for its in (2, 7, 9, 20):
+    for its in (2, 7, 9, 16, 20, 23):
         x = va[:, 2].contiguous()
         try:
             check(lib().gla_set_option(b"jacobi_fuse", 0))
