@@ -339,10 +339,10 @@ class RowBlockAMG:
             d_e, b_e, x_e, own = self._ghost_operands(level, b, x)
             plan = ops.ext["plan"]
             xr = plan.jacobi_sweeps_residual(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_pre)
-            if xr is not None:
-                return own(xr[0]).clone(), own(xr[1]).clone()
+            if xr is not None:                               # (fresh extended tensors: the caller keeps their own-row views, no copy)
+                return own(xr[0]), own(xr[1])
             x1 = plan.jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_pre)       # (rows within n_pre lines of the
-            return own(x1).clone(), own(plan.residual(b_e.reshape(-1, 1), x1)).clone()               #  extension's ends are not valid: never read)
+            return own(x1), own(plan.residual(b_e.reshape(-1, 1), x1))                               #  extension's ends are not valid: never read)
         x = self.smooth(level, self.n_pre, b, x)
         return x, self.residual(b, x, level)
 
@@ -351,7 +351,7 @@ class RowBlockAMG:
         w = float(torch.tensor(self.w, dtype=b.dtype))
         if ops.ext is not None and b.shape[1] == 1 and 1 <= self.n_post <= ops.TS_MAX and 1 <= self.n_pre < ops.TS_MAX:
             d_e, b_e, x_e, own = self._ghost_operands(level, None, x)      # (b and its ghost lines are still there from the pre-smoothing)
-            return own(ops.ext["plan"].jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_post)).clone()
+            return own(ops.ext["plan"].jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_post))
         return self.smooth(level, self.n_post, b, x)
 
     def restrict(self, level, r):
@@ -379,11 +379,16 @@ class RowBlockAMG:
             # replicated from here on: one all-gather of the right-hand side, the rest of the cycle on this GPU alone
             lo, hi = self.blocks[level][self.rank]
             b_full = self.gather(b, level).contiguous()
-            x_full = self.sub.H.cycle(b_full, torch.zeros_like(b_full), self.sub.level)
+            x_full = self.sub.H.cycle(b_full, self.sub.H._zero_guess(b_full), self.sub.level)
             return x_full[lo:hi].contiguous()
         x, r = self.presmooth_residual(level, b, x)
         rc = self.restrict(level, r)
-        xc = self.cycle(rc, torch.zeros_like(rc), level + 1)
+        zeros = self.__dict__.setdefault("_zeros", {})       # the zero initial guess of a coarse level: one read-only buffer per
+        key = (tuple(rc.shape), rc.dtype)                    # shape, not a fill launch per level and cycle
+        z = zeros.get(key)
+        if z is None:
+            z = zeros[key] = torch.zeros_like(rc)
+        xc = self.cycle(rc, z, level + 1)
         x = self.correct(level, x, xc)
         return self.postsmooth(level, b, x)
 
