@@ -485,7 +485,7 @@ class RowBlockOps:
                 pairs.append((lower, vec[e["off"] + self.part.n_local:].reshape(-1)))
         self._copy_batch(pairs, st)
 
-    def ext_tensor(self, *trailing, dtype=None):
+    def ext_tensor(self, *trailing, dtype=None, zero=True):
         """An operand allocated WITH its ghost rows: the rank's own-row view [n_local, *trailing] of a zero tensor
         [n_ext, *trailing].  The ghost-line routes (RowBlockJacobi on [n_local, 3, K], RowBlockCheby's b and x0) read such an
         operand in place -- ghost rows are filled around it, nothing is copied: a plain tensor costs one copy into the
@@ -495,7 +495,8 @@ class RowBlockOps:
         if e is None:
             return torch.zeros((nl, *trailing), dtype=dtype or torch.float64,
                                device=self.plan.device if hasattr(self, "plan") else None)
-        full = torch.zeros((e["n_ext"], *trailing), dtype=dtype or e["dtype"], device=e["dev"])
+        alloc = torch.zeros if zero else torch.empty         # (zero=False: the caller writes every own row; ghost rows get filled)
+        full = alloc((e["n_ext"], *trailing), dtype=dtype or e["dtype"], device=e["dev"])
         view = full[e["off"]:e["off"] + nl]
         view._gla_ext = full
         return view

@@ -323,11 +323,16 @@ class RowBlockAMG:
         if b is not None:
             own(a["b"]).copy_(b.reshape(-1))
             vecs.append(a["b"])
-        own(a["x"]).copy_(x.reshape(-1))
-        vecs.append(a["x"])
+        x_full = ops._ext_of(x, (1,))                        # x allocated with its ghost rows (correct() does): used in place
+        if x_full is not None:
+            x_e = x_full.reshape(-1)
+        else:
+            own(a["x"]).copy_(x.reshape(-1))
+            x_e = a["x"]
+        vecs.append(x_e)
         ops._fill_ghosts(vecs, ops._ghost_exchange([own(v) for v in vecs]))
         ops._ghost_pending = None
-        return a["d"], a["b"], a["x"], own
+        return a["d"], a["b"], x_e, own
 
     def presmooth_residual(self, level, b, x):
         """n_pre sweeps and r = b - A x of the result.  Ghost-line levels: ONE exchange ([b, x] ghost lines) and ONE pass of the
@@ -369,7 +374,10 @@ class RowBlockAMG:
     def correct(self, level, x, xc):
         """x + P xc in one pass (gla_spmm_add) after one halo exchange of xc."""
         ops = self.P_ops[level]
-        out = torch.empty_like(x)
+        a_ops = self.A_ops[level]
+        # the result is the post-smoother's operand: allocated with the ghost rows of the level's extended block, so that the
+        # smoothing pass reads it in place
+        out = a_ops.ext_tensor(1, dtype=x.dtype, zero=False) if (a_ops.ext is not None and x.shape[1] == 1) else torch.empty_like(x)
         self._apply(ops, xc, lambda buf, which: ops.plan.spmm_add(x, buf, out=out, which=which))
         return out
 
