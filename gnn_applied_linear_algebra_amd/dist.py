@@ -59,14 +59,14 @@ class LibComm:
         self.world = dist.get_world_size(group) if distributed else 1
         self.rank = dist.get_rank(group) if distributed else 0
         ident = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            check(lib().gla_comm_unique_id(ident))
+        rc0 = int(lib().gla_comm_unique_id(ident)) if self.rank == 0 else 0
         if self.world > 1:
-            box = [bytes(ident.raw)]
+            box = [rc0, bytes(ident.raw)]                    # (rank 0's status travels with the id: every rank fails or none)
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast_object_list(box, src=src, group=group,
                                        device=torch.device("cuda", torch.cuda.current_device()))
-            ident = ctypes.create_string_buffer(box[0], 128)
+            rc0, ident = int(box[0]), ctypes.create_string_buffer(box[1], 128)
+        check(rc0)
         self._h = ctypes.c_void_p()
         check(lib().gla_comm_create(ident, self.rank, self.world, ctypes.byref(self._h)))
 
@@ -79,10 +79,37 @@ class LibComm:
         return c
 
     @classmethod
+    def try_for_group(cls, group=None):
+        """for_group(group), or None ON EVERY RANK when the library's communicator cannot be set up on one of them (librccl not
+        loadable through dlopen, ncclGetUniqueId / ncclCommInitRank refusing): the caller then drives torch.distributed's own
+        collectives -- slower (host-ordered), never silent: the reason goes to stderr and the driver's `mode` (bench.py's
+        `config.exchange`) names the route that ran."""
+        import sys
+        fkey = ("unavailable", id(group), torch.cuda.current_device())
+        if fkey in cls._cache:
+            return None
+        c, err = None, None
+        try:
+            c = cls.for_group(group)
+        except Exception as e:                               # noqa: BLE001 -- any failure takes every rank to the fallback
+            err = e
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            ok = torch.tensor([1 if c is not None else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                c = None
+        if c is None:
+            cls._cache[fkey] = True
+            print(f"gnn_applied_linear_algebra_amd.dist: libgla_hip's RCCL communicator is unavailable "
+                  f"({err if err is not None else 'another rank could not create it'}); halo exchanges go through "
+                  f"torch.distributed collectives on this group", file=sys.stderr, flush=True)
+        return c
+
+    @classmethod
     def release_all(cls):
         from ._lib import lib
         for c in cls._cache.values():
-            if c._h:
+            if isinstance(c, cls) and c._h:
                 lib().gla_comm_destroy(c._h)
                 c._h = None
         cls._cache.clear()
@@ -282,8 +309,9 @@ class RowBlockOps:
         # group; torch.distributed collectives driven from Python otherwise (gloo rehearsals, CPU index tests)
         self.comm = None
         if p.world > 1 and p.S > 0 and _use_lib_comm(group, edgeij_pair.device, host_loop):
-            self.comm = LibComm.for_group(group)
-            self.send_idx32 = p.send_idx.to(torch.int32).contiguous()
+            self.comm = LibComm.try_for_group(group)
+            if self.comm is not None:
+                self.send_idx32 = p.send_idx.to(torch.int32).contiguous()
         self._lib_send = {}
         self.mode = ("no exchange" if p.world == 1 or p.S == 0 else
                      ("library-side: gla_halo_begin/end on libgla_hip's RCCL communicator, event-ordered, "
