@@ -636,6 +636,52 @@ def single_gpu(args, gla, dev):
                         "RCCL communicator, neighbours = the rank itself), same block size and sweeps as the headline",
                 "value": round(args.sweeps / td, 2), "unit": "sweeps/s", "ms_per_step": round(td * 1e3, 4),
                 "fraction_of_headline_step": round((median(step_ms) * 1e-3) / td, 4)}
+            # ... and the K = 16 ghost-line routes of config 3 the same way (one exchange per pass of five Jacobi sweeps / per
+            # fused Chebyshev pass), plain operands and operands allocated with their ghost rows (drv.ext_tensor: read in place)
+            if args.n == 4096:
+                try:
+                    from gnn_applied_linear_algebra_amd.dist import RowBlockCheby
+                    K16 = 16
+
+                    def k_driver(cls):
+                        d_ = cls.__new__(cls)
+                        d_.comm, d_.overlap, d_._ghost_pending, d_._lib_send = comm_, True, None, {}
+                        d_.part = types.SimpleNamespace(world=1, rank=0, n_local=Nn * Nn, group=None, n_in=Nn * Nn, S=0)
+                        d_._sched = plan_e.jacobi_schedule
+                        d_.ext = dict(plan=plan_e, S=Nn, n_ext=Nn * (Nn + 2 * T_), off=Nn * T_, up=True, down=True, slab=T_ * Nn,
+                                      dtype=torch.float64, dev=dev, up_src=0, down_src=0)
+                        return d_
+                    genk = torch.Generator().manual_seed(7)
+                    vj = torch.rand(Nn * Nn, 3, K16, generator=genk, dtype=torch.float64).to(dev)
+                    vj[:, 0, :] = -4.0
+                    jd = k_driver(RowBlockJacobi)
+                    _, m1 = timed_steps(lambda: jd.forward(args.sweeps, vj, pr.g), 4, 1)
+                    vje = jd.ext_tensor(3, K16)
+                    vje.copy_(vj)
+                    _, m2 = timed_steps(lambda: jd.forward(args.sweeps, vje, pr.g), 4, 1)
+                    jac_m = gla.JacobiGNN.JacobiGNN()
+                    _, m0 = timed_steps(lambda: jac_m(args.sweeps, vj, pr.ei, pr.edge_attr, pr.g), 4, 1)
+                    rec = {"what": "the K = 16 ghost-line routes of dist.py over a one-rank RCCL communicator (neighbours = the rank "
+                                   "itself), 4096^2 rows per rank; *_ext = operands allocated with their ghost rows (drv.ext_tensor)",
+                           "jacobi_single_gpu_ms": round(median(m0), 3), "jacobi_route_ms": round(median(m1), 3),
+                           "jacobi_route_ext_ms": round(median(m2), 3)}
+                    del vj, vje, jd
+                    torch.cuda.empty_cache()
+                    bk = torch.rand(Nn * Nn, K16, generator=genk, dtype=torch.float64).to(dev)
+                    xk = torch.rand(Nn * Nn, K16, generator=genk, dtype=torch.float64).to(dev)
+                    gch = torch.tensor([-3.4, -4.0], dtype=torch.float64)
+                    cd = k_driver(RowBlockCheby)
+                    _, c1 = timed_steps(lambda: cd.forward(4, bk, xk, gch), 4, 1)
+                    bke, xke = cd.ext_tensor(K16), cd.ext_tensor(K16)
+                    bke.copy_(bk)
+                    xke.copy_(xk)
+                    _, c2 = timed_steps(lambda: cd.forward(4, bke, xke, gch), 4, 1)
+                    rec.update({"cheby_deg4_route_ms": round(median(c1), 3), "cheby_deg4_route_ext_ms": round(median(c2), 3),
+                                "cheby_deg4_single_gpu_ms": out.get("config3_k16", {}).get("cheby_deg4_ms")})
+                    out["dist_route_one_gpu_k16"] = rec
+                    del bk, xk, bke, xke, cd
+                except Exception as exc:
+                    out["dist_route_one_gpu_k16"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             del drv, plan_e
             torch.cuda.synchronize()
             from gnn_applied_linear_algebra_amd._lib import lib as _lib
