@@ -96,6 +96,7 @@ SIGNATURES = {
     "gla_spgemm": (_I, [_P, _P, _I, _I64, _P, _P, _P, ctypes.POINTER(_I64), _P]),
     "gla_pmis_split": (_I, [_P, _P, _P, _I, ctypes.POINTER(_I), _P]),
     "gla_comm_unique_id": (_I, [_P]),
+    "gla_comm_probe": (_I, []),
     "gla_comm_create": (_I, [_P, _I, _I, ctypes.POINTER(_P)]),
     "gla_comm_destroy": (_I, [_P]),
     "gla_comm_ranks": (_I, [_P, ctypes.POINTER(_I), ctypes.POINTER(_I)]),

@@ -22,7 +22,7 @@ struct TileMap {
   int tiles_per_xcd;
   int xcd_chunk;              // see map_tile
   int lds_cap = 0x7fffffff;   // tiles with more nonzeros than this are single long rows (CSR-adaptive "long" bin)
-  int vec = 0;                // CSR-adaptive "vector" bin: tiles whose rows average >= 32 nonzeros sum a row with 2 .. 64 lanes (option row_sum)
+  int vec = 0;                // CSR-adaptive "vector" bin: rows of >= GLA_WAVE_ROW nonzeros are summed by their wave (option row_sum)
 };
 
 // grid = 8 * tiles_per_xcd workgroups; with chunking the per-XCD count is rounded up to whole chunks so that the

@@ -17,6 +17,7 @@
 
 #include <dlfcn.h>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -46,6 +47,8 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 
 void load_rccl() {
+  const char* off = getenv("GLA_RCCL_DISABLE");      // test hook: this process behaves as if librccl could not be loaded
+  if (off && off[0] == '1') return;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* nm : names) {
     g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
@@ -107,22 +110,37 @@ int gla_comm_unique_id(void* id_host) {
   return GLA_OK;
 }
 
+int gla_comm_probe(void) { return rccl_ready() ? GLA_OK : GLA_ERR_UNSUPPORTED; }
+
 int gla_comm_create(const void* id_host, int rank, int nranks, gla_comm_t* out) {
   if (!id_host || !out || nranks < 1 || rank < 0 || rank >= nranks) return GLA_ERR_INVALID_ARG;
   if (!rccl_ready()) return GLA_ERR_UNSUPPORTED;
+  // Everything that can fail locally comes BEFORE the collective ncclCommInitRank (a rank that left early would leave the
+  // others blocked in it), and a failure after it releases what was created, the communicator included.
+  int device = 0;
+  GLA_HIP_CHECK(hipGetDevice(&device));
   gla_comm* c = new gla_comm();
   c->rank = rank;
   c->nranks = nranks;
-  GLA_HIP_CHECK(hipGetDevice(&c->device));
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    gla_comm_destroy(c);
+    return -(1000 + (int)e);
+  }
   UniqueId id;
   memcpy(&id, id_host, sizeof(id));
-  int rc = g_rccl.comm_init_rank(&c->comm, nranks, id, rank);
-  if (rc != 0) { delete c; return -(3000 + rc); }
-  GLA_HIP_CHECK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-  GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
-  GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
-  GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  GLA_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  const int rc = g_rccl.comm_init_rank(&c->comm, nranks, id, rank);
+  if (rc != 0) {
+    c->comm = nullptr;
+    gla_comm_destroy(c);
+    return -(3000 + rc);
+  }
   *out = c;
   return GLA_OK;
 }

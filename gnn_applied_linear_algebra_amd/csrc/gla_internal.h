@@ -21,6 +21,8 @@ constexpr int GLA_DIA_MAX = 16;
 // rows longer than this never share an LDS tile: each is a row tile of its own (CSR-adaptive "long" bin) and is summed by
 // the whole workgroup in 256 fixed chunks; shorter rows stay in stream tiles with strictly in-order sums
 constexpr int GLA_LONG_ROW = GLA_LDS_ELEMS_MAX - GLA_TILE_NNZ_MIN;
+// K = 1 CSR stream kernel: rows of this many nonzeros or more are summed by their wave (64 fixed chunks + xor tree; option row_sum)
+constexpr int GLA_WAVE_ROW = 64;
 
 struct gla_csr {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
@@ -70,9 +72,10 @@ struct gla_tuning {
   int xcd_chunk = 64;       // consecutive tiles per XCD turn (1 = identity mapping, 0 = one contiguous span per XCD)
   int col16 = 1;            // K = 1 kernels read int16 tile-relative columns when the plan could build them
   int compress = 0;         // 1: gla_csr_set_values also builds the packed stream when the matrix allows it
-  int row_sum = 1;          // K = 1 CSR stream kernel, tiles whose rows average 32 .. 3072 nonzeros: 1 = a row is summed
-                            // by 2 .. 64 lanes (contiguous chunks in edge order + a fixed xor tree: deterministic, agrees with the
-                            // in-order sum to rounding); 0 = one lane per row strictly in edge order (bit-identical to the CPU scatter-add)
+  int row_sum = 1;          // K = 1 CSR stream kernel: 1 = a row of GLA_WAVE_ROW (64) .. 3072 nonzeros is summed by its wave (64
+                            // contiguous chunks in edge order + a fixed xor tree: deterministic, a function of the row's own length --
+                            // independent of tiling and row-block partition -- and equal to the in-order sum to rounding);
+                            // 0 = one lane per row, strictly in edge order (bit-exact against the CPU scatter-add for any graph)
   int dia = 1;              // stencil matrices (<= 16 diagonals): K = 1 kernels use the diagonal layout
   int jacobi_fuse = 1;      // gla_jacobi_sweeps on 2-D stencil plans: 0 one sweep per pass, 1 several (temporal blocking; gla_jacobi_sweeps_schedule), 2 up to two
   int jacobi_lines = 0;     // grid lines a workgroup of the fused kernel marches through (0 = one resident round of workgroups)

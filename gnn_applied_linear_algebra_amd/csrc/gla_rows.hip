@@ -317,54 +317,29 @@ __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
   }
   __syncthreads();
 
+  // Row sums.  A row of fewer than GLA_WAVE_ROW (64) nonzeros is summed by ONE lane strictly in edge order (the association
+  // order of the reference's sequential CPU scatter-add: bit-exact).  A longer row -- the "vector" bin of a CSR-adaptive
+  // SpMV -- is summed by the 64 lanes of the wave its lane belongs to: lane l adds the l-th of 64 contiguous chunks of
+  // ceil(len / 64) staged products in edge order and the 64 partial sums meet in a fixed xor tree of cross-lane shuffles
+  // (option row_sum = 1, the default; row_sum = 0 keeps one lane per row for every row).  THE ORDER IS A FUNCTION OF THE
+  // ROW'S OWN LENGTH, never of the tile the row happens to share: a row-block partition (whose tiles start at the rank's
+  // first row) sums every row exactly as the single-rank plan does, so the multi-rank results stay bit-identical
+  // (tests/test_gpu_dist.py::test_two_ranks_long_rows).  Round 3 picked the lane count from the tile's population.
   T red = T(0);
-  const int nrows = r1 - r0;
-  if (tm.vec && nrows * 2 <= GLA_BLOCK && e - s >= 32 * nrows) {
-    // CSR-adaptive "vector" bin: the tile's rows average 32 nonzeros or more -- G = 2 .. 64 lanes per row, each adds a
-    // contiguous chunk of the row's products (staged in LDS like every tile) in edge order, the G partial sums meet in a
-    // fixed xor tree of cross-lane shuffles.  Deterministic for a given plan; not the association order of a sequential sum
-    // (option row_sum = 0 keeps that: one lane per row).  Measured on 200 k rows of 64 .. 1024 nonzeros (tools/bench_irregular.py):
-    // 653 -> 506 us; a wave-per-row variant straight from the streams (no LDS) was slower (756 us).
-    int G = 2;
-    while (G < 64 && nrows * G * 2 <= GLA_BLOCK) G <<= 1;
-    const int rowi = tid / G, sub = tid & (G - 1);
-    const bool live = rowi < nrows;
-    T acc = T(0);
-    if (live) {
-      int a, b;
-      row_range(r0 + rowi, a, b);
-      const int len = b - a, chunk = (len + G - 1) / G;
-      int j = a - sa + sub * chunk;
-      const int jend = min(j + chunk, b - sa);
-      for (; j + 4 <= jend; j += 4) {
-        const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
-        acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
-      }
-      for (; j < jend; ++j) acc = acc + prod[j];
-    }
-    for (int off = 1; off < G; off <<= 1) acc = acc + __shfl_xor(acc, off, 64);
-    if (live && sub == 0) {
-      const auto pre2 = epi.load((int64_t)(r0 + rowi), 0);
-      epi.apply((int64_t)(r0 + rowi), 0, acc, pre2);
-      if constexpr (Epi::NRED > 0) red = epi.redv(acc, pre2);
-    }
-  } else {
-  {
-    const bool have = r < r1;
-    if (!PF && have) {
-      row_range(r, ra, rb);
-      pre = epi.load((int64_t)r, 0);
-    }
-    // A HEAVY row (128 nonzeros or more) inside a tile of mostly short rows -- the hub rows of a power-law graph -- is not left
-    // to one lane while its wave idles: the wave's 64 lanes add contiguous 64ths of its staged products in edge order and meet
-    // in a fixed xor tree (row_sum = 1; deterministic for a plan, not the association order of a sequential sum -- row_sum = 0
-    // keeps that).  tools/bench_irregular.py, 1 M rows of 3 .. 3000 nonzeros, banded columns: 117 -> 98 us (random columns stay gather-bound at 183 us).
-    const int len = have ? rb - ra : 0;
-    const bool heavy = tm.vec && len >= 128;
+  const int lane = tid & 63;
+  for (int rbase = r0; rbase < r1; rbase += GLA_BLOCK) {         // (one round unless the tile holds more than 256 short rows)
+    const int rr = rbase + tid;
+    const bool have = rr < r1;
+    int a = 0, b = 0;
+    typename Epi::Pre pr;
+    if (PF && rbase == r0) { a = ra; b = rb; pr = pre; }
+    else if (have) { row_range(rr, a, b); pr = epi.load((int64_t)rr, 0); }
+    const int len = have ? b - a : 0;
+    const bool heavy = tm.vec && len >= GLA_WAVE_ROW;
     T acc = T(0);
     if (have && !heavy) {
-      int j = ra - sa;
-      const int jend = rb - sa;
+      int j = a - sa;
+      const int jend = b - sa;
       for (; j + 4 <= jend; j += 4) {            // LDS reads issued together, added strictly in edge order
         const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
         acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
@@ -372,14 +347,13 @@ __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
       for (; j < jend; ++j) acc = acc + prod[j];
     }
     unsigned long long hm = __ballot(heavy);
-    const int lane = tid & 63;
     while (hm) {                                  // (wave-uniform loop: every lane of the wave takes part)
       const int hl = __ffsll((long long)hm) - 1;
       hm &= hm - 1;
-      const int a = __shfl(ra, hl, 64) - sa, b = __shfl(rb, hl, 64) - sa;
-      const int chunk = (b - a + 63) >> 6;
-      int j = a + lane * chunk;
-      const int jend = min(j + chunk, b);
+      const int ha = __shfl(a, hl, 64) - sa, hb = __shfl(b, hl, 64) - sa;
+      const int chunk = (hb - ha + 63) >> 6;
+      int j = ha + lane * chunk;
+      const int jend = min(j + chunk, hb);
       T part = T(0);
       for (; j + 4 <= jend; j += 4) {
         const T p0 = prod[j], p1 = prod[j + 1], p2 = prod[j + 2], p3 = prod[j + 3];
@@ -390,21 +364,9 @@ __global__ __launch_bounds__(GLA_BLOCK, MINW) void spmv_stream_vec2_kernel(
       if (lane == hl) acc = part;
     }
     if (have) {
-      epi.apply((int64_t)r, 0, acc, pre);
-      if constexpr (Epi::NRED > 0) red = epi.redv(acc, pre);
+      epi.apply((int64_t)rr, 0, acc, pr);
+      if constexpr (Epi::NRED > 0) red = red + epi.redv(acc, pr);
     }
-  }
-  for (int r2 = r + GLA_BLOCK; r2 < r1; r2 += GLA_BLOCK) {       // tiles with more than 256 (short) rows
-    int a, b;
-    row_range(r2, a, b);
-    a -= sa;
-    b -= sa;
-    T acc = T(0);
-    for (int j = a; j < b; ++j) acc = acc + prod[j];
-    const auto pre2 = epi.load((int64_t)r2, 0);
-    epi.apply((int64_t)r2, 0, acc, pre2);
-    if constexpr (Epi::NRED > 0) red = red + epi.redv(acc, pre2);
-  }
   }
   if constexpr (Epi::NRED > 0) {                                  // fixed-order workgroup sum -> partials[tile]
     __shared__ T wred[GLA_BLOCK / 64];

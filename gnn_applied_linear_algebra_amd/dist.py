@@ -78,25 +78,44 @@ class LibComm:
             c = cls._cache[key] = cls(group)
         return c
 
+    @staticmethod
+    def _agree(flag, group):
+        """MIN of a local 0 / 1 over the ranks of `group` (tensor on the device the group's backend moves)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return int(flag)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        ok = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        return int(ok.item())
+
     @classmethod
     def try_for_group(cls, group=None):
         """for_group(group), or None ON EVERY RANK when the library's communicator cannot be set up on one of them (librccl not
         loadable through dlopen, ncclGetUniqueId / ncclCommInitRank refusing): the caller then drives torch.distributed's own
         collectives -- slower (host-ordered), never silent: the reason goes to stderr and the driver's `mode` (bench.py's
-        `config.exchange`) names the route that ran."""
+        `config.exchange`) names the route that ran.
+
+        The ranks agree in two steps.  (1) BEFORE anyone enters the collective ncclCommInitRank: every rank probes locally
+        (gla_comm_probe: dlopen + symbols, no GPU call, nothing created) and the group takes the MIN -- a rank without RCCL
+        would otherwise return from gla_comm_create at once and leave the others blocked inside the initialisation.
+        (2) After the creation (rank 0's ncclGetUniqueId status travels with the id; ncclCommInitRank itself fails or succeeds
+        as a group) a second MIN catches whatever is left."""
         import sys
-        fkey = ("unavailable", id(group), torch.cuda.current_device())
+        from ._lib import lib
+        dev_id = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        fkey = ("unavailable", id(group), dev_id)
         if fkey in cls._cache:
             return None
         c, err = None, None
-        try:
-            c = cls.for_group(group)
-        except Exception as e:                               # noqa: BLE001 -- any failure takes every rank to the fallback
-            err = e
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            ok = torch.tensor([1 if c is not None else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-            if int(ok.item()) == 0:
+        ready = int(lib().gla_comm_probe()) == 0
+        if not ready:
+            err = "librccl could not be loaded on this rank (gla_comm_probe)"
+        if cls._agree(ready, group):
+            try:
+                c = cls.for_group(group)
+            except Exception as e:                           # noqa: BLE001 -- any failure takes every rank to the fallback
+                err = e
+            if not cls._agree(c is not None, group):
                 c = None
         if c is None:
             cls._cache[fkey] = True

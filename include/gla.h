@@ -368,6 +368,11 @@ typedef struct gla_comm* gla_comm_t;
 /* Rank 0 obtains a 128-byte id (ncclGetUniqueId) and distributes it by any means; every rank then calls
  * gla_comm_create on its own device (ncclCommInitRank + a private communication stream and two events). */
 int gla_comm_unique_id(void* id128_host);
+/* GLA_OK when librccl is loadable through dlopen with every symbol the gla_comm_* entry points use, GLA_ERR_UNSUPPORTED
+ * otherwise (also when the environment sets GLA_RCCL_DISABLE=1: test hook).  Touches no GPU and creates nothing: a group of
+ * ranks agrees on the outcome of this call BEFORE any of them enters the collective ncclCommInitRank of gla_comm_create --
+ * a rank on which RCCL is missing would otherwise leave the others blocked in there (dist.py, LibComm.try_for_group). */
+int gla_comm_probe(void);
 int gla_comm_create(const void* id128_host, int rank, int nranks, gla_comm_t* out);
 int gla_comm_destroy(gla_comm_t comm);
 int gla_comm_ranks(gla_comm_t comm, int* rank_host, int* nranks_host);

@@ -126,3 +126,41 @@ def test_single_process_partition_is_identity():
     part = RowBlockPartition(ei, 25, 0, 25)
     assert part.world == 1 and part.S == 0 and part.n_cols_local == 25
     assert torch.equal(part.edge_index_local, ei)
+
+
+def _probe_worker(rank, world, port, fail_rank, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if rank == fail_rank:
+        os.environ["GLA_RCCL_DISABLE"] = "1"              # this rank behaves as if librccl could not be loaded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnn_applied_linear_algebra_amd import _lib
+        from gnn_applied_linear_algebra_amd.dist import LibComm
+        probe = int(_lib.lib().gla_comm_probe())
+        c = LibComm.try_for_group(None)
+        again = LibComm.try_for_group(None)               # remembered: no second round of collectives
+        q.put((rank, "ok", probe, c is None and again is None))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc(), 0, False))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [0, 1])
+def test_lib_comm_asymmetric_probe_failure_takes_every_rank_to_the_fallback(fail_rank):
+    """One rank without RCCL (forced by GLA_RCCL_DISABLE): the group must agree on the torch.distributed route BEFORE any
+    rank enters ncclCommInitRank -- the healthy rank must neither hang nor build a communicator of its own."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, 2, port, fail_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, probe, fell_back in res:
+        assert status == "ok", f"rank {rank}: {status}"
+        assert fell_back, f"rank {rank} did not take the fallback"
+        assert (probe != 0) == (rank == fail_rank)        # only the disabled rank fails its own probe

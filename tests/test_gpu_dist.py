@@ -138,6 +138,73 @@ def test_two_ranks_one_gpu(overlap, world):
         assert status == "ok", f"rank {rank}: {status}"
 
 
+def _long_rows_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gnn_applied_linear_algebra_amd as gla
+        from gnn_applied_linear_algebra_amd.dist import RowBlockCheby, RowBlockJacobi
+        from gnn_applied_linear_algebra_amd.dist_amg import _row_slice
+        dev = torch.device("cuda:0")
+        gen = torch.Generator().manual_seed(11)
+        n = 5000
+        # rows of 20 .. 400 nonzeros (many above GLA_WAVE_ROW = 64: summed by their wave), columns within +-1200 of the row,
+        # a few 3-nonzero rows in between so that tiles mix both kinds
+        lens = torch.randint(20, 401, (n,), generator=gen)
+        lens[::7] = 3
+        rows = torch.repeat_interleave(torch.arange(n), lens)
+        cols = (rows + torch.randint(-1200, 1201, (rows.numel(),), generator=gen)).clamp_(0, n - 1)
+        key = torch.unique(rows * n + cols)                    # sorted, duplicate-free
+        rows, cols = key // n, key % n
+        ev = (torch.rand(rows.numel(), 1, generator=gen, dtype=torch.float64) - 0.3)
+        ei = torch.stack([rows, cols]).to(dev)
+        ev = ev.to(dev)
+        diag = torch.rand(n, generator=gen, dtype=torch.float64).to(dev) + 150.0
+        b = torch.rand(n, generator=gen, dtype=torch.float64).to(dev)
+        x = torch.rand(n, generator=gen, dtype=torch.float64).to(dev)
+        g = torch.tensor([0.7], dtype=torch.float64)
+        va = torch.stack([diag, b, x], 1)
+        ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+        want = gla.JacobiGNN.JacobiGNN()(4, va, ei, ea, g)
+        gch = torch.tensor([-3.4, -150.0], dtype=torch.float64)
+        vr, _, _ = gla.ChebyGNN.ChebyRelaxGNN(3, return_edge_attr=False)(torch.stack([b, x], 1), ei, ev, gch)
+        cuts = [0, 1733, n] if world == 2 else [0, 901, 2777, n]      # blocks that start in the middle of single-rank tiles
+        lo, hi = cuts[rank], cuts[rank + 1]
+        e_l, v_l = _row_slice(ei, ev, lo, hi)
+        for overlap in (False, True):
+            jac = RowBlockJacobi(e_l, v_l.reshape(-1, 1), n, lo, hi, overlap=overlap)
+            got = jac.forward(4, va[lo:hi].contiguous(), g)
+            assert torch.equal(got, want[lo:hi]), ("jacobi, long rows", overlap, (got - want[lo:hi]).abs().max().item())
+            ch = RowBlockCheby(e_l, v_l.reshape(-1, 1), n, lo, hi, overlap=overlap)
+            xx, rr, pp, _ = ch.forward(3, b[lo:hi].contiguous(), x[lo:hi].contiguous(), gch)
+            assert torch.equal(xx, vr[lo:hi, 1]) and torch.equal(rr, vr[lo:hi, 2]) and torch.equal(pp, vr[lo:hi, 3]), "cheby, long rows"
+        torch.cuda.synchronize()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_long_rows(world):
+    """Rows of 64 nonzeros or more are summed by a wave (vector bin, option row_sum = 1): the association order must be a
+    function of the row alone, not of the tile it shares -- a row-block partition, whose tiles start at the rank's first row,
+    then reproduces the single-rank result bit for bit.  (Round 3 picked the lane count per tile: ADVICE r3.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_long_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in sorted(res):
+        assert status == "ok", f"rank {rank}: {status}"
+
+
 def test_world1_rowblock_equals_module():
     import gnn_applied_linear_algebra_amd as gla
     from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi

@@ -351,8 +351,8 @@ def test_ragged_unsorted_and_long_rows():
     va_w, ea_w, _ = rp.matvec_layer(X, ei, ev)
     eq(va, va_w)
     eq(ea, ea_w)
-    # dense 100 x 100 weight matrix (MatrixWeightedNorm.py demo): 100 nnz per row -- the CSR-adaptive VECTOR bin (rows averaging
-    # 32 nonzeros or more: 2 .. 64 lanes per row, chunked sums + a fixed xor tree): agrees with the in-order sum to rounding;
+    # dense 100 x 100 weight matrix (MatrixWeightedNorm.py demo): 100 nnz per row -- the CSR-adaptive VECTOR bin (rows of 64
+    # nonzeros or more: summed by their wave, 64 chunked sums + a fixed xor tree): agrees with the in-order sum to rounding;
     # option row_sum = 0 keeps one lane per row and is bit-exact
     W = torch.rand(100, 100, generator=gen, dtype=torch.float64)
     ei_w = torch.stack([torch.arange(100).repeat_interleave(100), torch.arange(100).repeat(100)])
@@ -1804,7 +1804,7 @@ def test_random_graphs_property():
         try:
             plan = gla.CsrPlan(d(ei), n_rows, n_cols)
             plan.set_values(d(vals))
-            # default (row_sum = 1): tiles whose rows average >= 32 nonzeros use the vector bin -- to rounding, deterministic
+            # default (row_sum = 1): rows of >= 64 nonzeros are summed by their wave (vector bin) -- to rounding, deterministic
             chk(lib().gla_set_option(b"row_sum", 1))
             y_vec = plan.spmm(d(X))
             assert torch.equal(y_vec, plan.spmm(d(X)))
