@@ -288,7 +288,21 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     if (passes[i] < 2 || passes[i] > ghost) return GLA_ERR_UNSUPPORTED;
   if (n_ext / S <= 2 * (int64_t)(2 * ghost + passes[0])) return GLA_ERR_UNSUPPORTED;
   if ((up && (up_src < 0 || up_src >= c->nranks)) || (down && (down_src < 0 || down_src >= c->nranks))) return GLA_ERR_INVALID_ARG;
+  // Everything a pass launch could decline is asked BEFORE the first enqueue: a "declined" (UNSUPPORTED / NO_VALUES) that came
+  // back from the middle of the sequence would leave an all-gather on this rank that the other ranks never match, and the
+  // side stream forked.  (What is left after this point are runtime errors; `bail` joins the streams for those.)
+  for (int i = 0; i < n_passes; ++i) {
+    const int st = gla_jacobi_parts_status(A, dtype, passes[i]);
+    if (st != GLA_OK) return st;
+  }
+  if (!rccl_ready()) return GLA_ERR_UNSUPPORTED;
   hipStream_t mn = (hipStream_t)main_stream, sd = (hipStream_t)side_stream;
+  bool forked = false;
+  auto bail = [&](int err) -> int {                 // an error after the fork: the main stream still waits for the side stream
+    if (forked && hipEventRecord(c->ev_join, sd) == hipSuccess) (void)hipStreamWaitEvent(mn, c->ev_join, 0);
+    (void)hipGetLastError();
+    return err;
+  };
   const size_t esz = dtype == GLA_F64 ? 8 : 4;
   auto at = [&](const void* p, int64_t elems) -> const void* { return (const char*)p + (size_t)elems * esz; };
   auto atw = [&](void* p, int64_t elems) -> void* { return (char*)p + (size_t)elems * esz; };
@@ -311,25 +325,26 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
         src[k] = at(va, (a - off) * ldva + col); dst[k] = atw(dst3[col], a); cnt[k] = b - a; strd[k] = ldva; ++k;
       }
     }
-    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, mn); if (rc) return rc; }
+    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, mn); if (rc) return bail(rc); }
     k = 0;                                                    // send = per column [first m own rows | last m own rows]
     for (int col = 0; col < 3; ++col) {
       src[k] = at(va, col); dst[k] = atw(send, 2 * m * col); cnt[k] = m; strd[k] = ldva; ++k;
       src[k] = at(va, (n_local - m) * ldva + col); dst[k] = atw(send, 2 * m * col + m); cnt[k] = m; strd[k] = ldva; ++k;
     }
-    rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, mn); if (rc) return rc;
-    rc = gla_comm_all_gather_begin(c, dtype, send, recv, 6 * m, mn); if (rc) return rc;
+    rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, mn); if (rc) return bail(rc);
+    rc = gla_comm_all_gather_begin(c, dtype, send, recv, 6 * m, mn); if (rc) return bail(rc);
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
-    rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, ghost, mn); if (rc) return rc;
-    rc = gla_halo_end(c, sd); if (rc) return rc;
+    forked = true;
+    rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, ghost, mn); if (rc) return bail(rc);
+    rc = gla_halo_end(c, sd); if (rc) return bail(rc);
     k = 0;
     for (int col = 0; col < 3; ++col) {                       // the neighbour above's LAST lines / below's FIRST lines
       if (up) { src[k] = at(recv, (int64_t)up_src * 6 * m + 2 * m * col + m); dst[k] = dst3[col]; cnt[k] = m; strd[k] = 1; ++k; }
       if (down) { src[k] = at(recv, (int64_t)down_src * 6 * m + 2 * m * col); dst[k] = atw(dst3[col], off + n_local); cnt[k] = m; strd[k] = 1; ++k; }
     }
-    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return rc; }
-    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 2, ghost, sd); if (rc) return rc;
+    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return bail(rc); }
+    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 2, ghost, sd); if (rc) return bail(rc);
   }
   // ---- passes 1 .. ----------------------------------------------------------------------------------------------------------
   for (int i = 1; i <= n_passes; ++i) {
@@ -338,11 +353,12 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
       const void* src[2] = {at(nxt, off), at(nxt, off + n_local - m)};
       void* dst[2] = {send, atw(send, m)};
       const int64_t cnt[2] = {m, m};
-      rc = gla_copy_batch(dtype, 2, src, dst, cnt, nullptr, sd); if (rc) return rc;
-      rc = gla_comm_all_gather_begin(c, dtype, send, recv, 2 * m, sd); if (rc) return rc;
+      rc = gla_copy_batch(dtype, 2, src, dst, cnt, nullptr, sd); if (rc) return bail(rc);
+      rc = gla_comm_all_gather_begin(c, dtype, send, recv, 2 * m, sd); if (rc) return bail(rc);
     }
     GLA_HIP_CHECK(hipEventRecord(c->ev_join, sd));
     GLA_HIP_CHECK(hipStreamWaitEvent(mn, c->ev_join, 0));
+    forked = false;
     if (i == n_passes) break;
     { void* t = cur; cur = nxt; nxt = t; }
     if (i == 1) nxt = xb == cur ? xa : xb;                    // (pass 0 wrote xb or x_last; from now on ping-pong xa / xb)
@@ -350,14 +366,15 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     const int ts = passes[i];
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
-    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 1, ghost, mn); if (rc) return rc;
-    rc = gla_halo_end(c, sd); if (rc) return rc;
+    forked = true;
+    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 1, ghost, mn); if (rc) return bail(rc);
+    rc = gla_halo_end(c, sd); if (rc) return bail(rc);
     const void* src[2]; void* dst[2]; int64_t cnt[2];
     int k = 0;
     if (up) { src[k] = at(recv, (int64_t)up_src * 2 * m + m); dst[k] = cur; cnt[k] = m; ++k; }
     if (down) { src[k] = at(recv, (int64_t)down_src * 2 * m); dst[k] = atw(cur, off + n_local); cnt[k] = m; ++k; }
-    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, nullptr, sd); if (rc) return rc; }
-    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 2, ghost, sd); if (rc) return rc;
+    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, nullptr, sd); if (rc) return bail(rc); }
+    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 2, ghost, sd); if (rc) return bail(rc);
   }
   return GLA_OK;
 }

@@ -139,6 +139,9 @@ struct gla_march5_args {
   int64_t aos_off, aos_rows;
 };
 int gla_march5_pass(const gla_march5_args& a);
+// GLA_OK iff gla_jacobi_fused_parts(_aos) would run `sweeps` sweeps on this canonical 5-point plan with these value types
+// (gla_rows.hip); otherwise the status it would return.  For callers that must know BEFORE they enqueue anything (gla_dist.hip).
+int gla_jacobi_parts_status(const gla_csr* A, int dtype, int sweeps);
 
 // jacobik.hip: `sweeps` (2 .. GLA_JACOBIK_TS_MAX) Jacobi sweeps of K right-hand sides in one temporally blocked pass
 constexpr int GLA_JACOBIK_TS_MAX = 5;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
 
   auto row_clamped = [&](int jl) -> int64_t { return min(max((J0 + jl) * dv.S + gi, (int64_t)0), dv.n_rows - 1); };
   auto live_at = [&](int jl) -> bool {             // the row (line J0 + jl, this lane's point) exists (generic path, level 0)
-    return in_i && J0 + jl >= 0 && (J0 + jl) * dv.S + gi < dv.n_rows;
+    return in_i & (J0 + jl >= 0) & ((J0 + jl) * dv.S + gi < dv.n_rows);
   };
   auto x0_load = [&](int jl) -> T {                // x^(k) at the clamped row; NOT touched until the next step
     const int64_t rc = row_clamped(jl);
@@ -185,8 +185,10 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       if (t <= nact) { nl[t - 1] = lds_row(t)[0]; nr[t - 1] = lds_row(t)[2]; }
 #pragma unroll
     for (int t = 0; t < LV; ++t) { h[t][0] = h[t][1]; h[t][1] = h[t][2]; }      // (levels only assign h[t][2]: a step is idempotent)
-    const bool whole_next = wave_in && jl + 1 >= jlo && jl + 1 < jhi;            // wave-uniform: line jl + 1 exists for every lane
-    h[0][2] = whole_next || live_at(jl + 1) ? xpre : T(0);
+    const bool whole_next = wave_in & (jl + 1 >= jlo) & (jl + 1 < jhi);          // wave-uniform: line jl + 1 exists for every lane
+    // (bitwise on purpose: hipcc 7.0 dropped the exec-masked move of `uniform || per_lane ? x : 0` in unrolled copies of
+    // jacobi_marchk_kernel's line step -- profiles/r03/marchk_miscompile.txt; a plain v_cndmask has no such region)
+    h[0][2] = (whole_next | live_at(jl + 1)) ? xpre : T(0);
     row_o[1] = h[0][2];                            // level 0, line jl + 1
     xpre = x0_load(jl + 2);
     c[(u + 1) % NC] = coef_at(jl + 1);

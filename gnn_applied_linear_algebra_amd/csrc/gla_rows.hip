@@ -1847,6 +1847,17 @@ int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* counts4
   return GLA_OK;
 }
 
+}  // extern "C"
+
+int gla_jacobi_parts_status(const gla_csr* A, int dtype, int sweeps) {
+  if (!A || (dtype != GLA_F32 && dtype != GLA_F64) || sweeps < 2 || sweeps > 8) return GLA_ERR_INVALID_ARG;
+  if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
+  if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A)) || !jacobi_canon(A)) return GLA_ERR_UNSUPPORTED;
+  return GLA_OK;
+}
+
+extern "C" {
+
 int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
                            int sweeps, int part, int ghost_lines, gla_stream_t stream) {
   if (!A || !diag || !B || !X || !Xout || X == Xout || sweeps < 2 || sweeps > 8 || part < 0 || part > 2 ||

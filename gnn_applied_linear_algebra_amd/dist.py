@@ -846,7 +846,9 @@ class RowBlockCheby(RowBlockOps):
         if temporal and col_blocks is None and self.part.world > 1 and edgeij_pair.is_cuda:
             self._setup_ghost(edgeij_pair, edge_attr, need_jacobi_passes=False)
         if self.ext is not None:
-            self.mode = "temporally blocked: one ghost-line exchange per fused pass of up to 4 Chebyshev steps"
+            self.mode = ("temporally blocked: one ghost-line exchange per fused pass of up to 4 Chebyshev steps, "
+                         + ("libgla_hip RCCL all-gather (stream-ordered)" if self.comm is not None
+                            else "torch.distributed all-gather (host-ordered)"))
 
     def _forward_ghost(self, deg, b, x0, g):
         from .ChebyGNN import _scalars, _g_out

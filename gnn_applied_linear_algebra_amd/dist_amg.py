@@ -80,8 +80,10 @@ class RowBlockAMG:
         thr = self.AGGLOMERATE_BELOW if agglomerate_below is None else int(agglomerate_below)
         n_all = len(H.A)
         # levels 0 .. n_dist - 1 are distributed; level n_dist (the coarsest at the latest) and everything below it is replicated
+        # (level 0 included: a problem that small runs replicated as a whole, n_dist = 0 -- every rank does the single-GPU cycle
+        # on gathered vectors and keeps its rows)
         n_dist = n_all - 1
-        for lv in range(1, n_all):
+        for lv in range(0, n_all):
             if H.A[lv].shape[0] < thr * self.world:
                 n_dist = lv
                 break
@@ -292,6 +294,10 @@ class RowBlockAMG:
         ops.run(buf, lambda which: launch(buf, which))
 
     def residual(self, b, x, level=0):
+        if level >= self.n_dist:                             # replicated level: the single-GPU residual on gathered vectors
+            lo, hi = self.blocks[level][self.rank]
+            r_full = self.sub.H.residual(self.gather(b, level).contiguous(), self.gather(x, level).contiguous(), self.sub.level)
+            return r_full[lo:hi].contiguous()
         ops = self.A_ops[level]
         r = torch.empty_like(b)
         self._apply(ops, x, lambda buf, which: ops.plan.residual(b, buf, out=r, which=which))
@@ -387,7 +393,11 @@ class RowBlockAMG:
             # replicated from here on: one all-gather of the right-hand side, the rest of the cycle on this GPU alone
             lo, hi = self.blocks[level][self.rank]
             b_full = self.gather(b, level).contiguous()
-            x_full = self.sub.H.cycle(b_full, self.sub.H._zero_guess(b_full), self.sub.level)
+            # a coarse level starts from the zero guess (one cached read-only buffer); at level 0 -- a hierarchy that is
+            # replicated as a whole (one level, or level 0 already below the agglomeration threshold) -- x is the CALLER's
+            # initial guess and is gathered like b, as AMGHierarchy.cycle(b, x) uses it
+            x0 = self.gather(x, level).contiguous() if level == 0 else self.sub.H._zero_guess(b_full)
+            x_full = self.sub.H.cycle(b_full, x0, self.sub.level)
             return x_full[lo:hi].contiguous()
         x, r = self.presmooth_residual(level, b, x)
         rc = self.restrict(level, r)

@@ -176,8 +176,9 @@ def _long_rows_worker(rank, world, port, q):
             got = jac.forward(4, va[lo:hi].contiguous(), g)
             assert torch.equal(got, want[lo:hi]), ("jacobi, long rows", overlap, (got - want[lo:hi]).abs().max().item())
             ch = RowBlockCheby(e_l, v_l.reshape(-1, 1), n, lo, hi, overlap=overlap)
-            xx, rr, pp, _ = ch.forward(3, b[lo:hi].contiguous(), x[lo:hi].contiguous(), gch)
-            assert torch.equal(xx, vr[lo:hi, 1]) and torch.equal(rr, vr[lo:hi, 2]) and torch.equal(pp, vr[lo:hi, 3]), "cheby, long rows"
+            xx, rr, pp, _ = ch.forward(3, b[lo:hi].reshape(-1, 1).contiguous(), x[lo:hi].reshape(-1, 1).contiguous(), gch)
+            assert (torch.equal(xx[:, 0], vr[lo:hi, 1]) and torch.equal(rr[:, 0], vr[lo:hi, 2])
+                    and torch.equal(pp[:, 0], vr[lo:hi, 3])), "cheby, long rows"
         torch.cuda.synchronize()
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
@@ -306,6 +307,16 @@ def _amg_worker(rank, world, port, q):
             rn = torch.sum(r_loc * r_loc).cpu()
             dist.all_reduce(rn)
             assert float(rn.sqrt()) < 0.5 * float(torch.norm(b))
+        # a hierarchy replicated AS A WHOLE (level 0 already below the agglomeration threshold: n_dist = 0): the caller's
+        # nonzero initial guess must reach the cycle exactly as AMGHierarchy.cycle(b, x) uses it
+        H = V.AMGHierarchy(A, levels=3, splitting=V.GridSplitting(m, m), coarse_solver="dense")
+        D = RowBlockAMG(H, overlap=True, agglomerate_below=1 << 20)
+        assert D.n_dist == 0, D.n_dist
+        gen = torch.Generator().manual_seed(6)
+        b = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
+        x0 = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
+        assert torch.equal(D.cycle(D.local(b), D.local(x0)), D.local(H.cycle(b, x0))), "n_dist = 0: initial guess dropped"
+        assert torch.equal(D.residual(D.local(b), D.local(x0)), D.local(H.residual(b, x0))), "n_dist = 0: residual"
         torch.cuda.synchronize()
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
