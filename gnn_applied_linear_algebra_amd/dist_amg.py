@@ -71,6 +71,12 @@ class _Sub:
 
 class RowBlockAMG:
     AGGLOMERATE_BELOW = 1 << 16                              # rows per rank below which a level is replicated (default)
+    # One-rank rehearsal (tools/bench_dist_vcycle_one_rank.py): with a process group of ONE rank the levels still take the
+    # ghost-line route -- extended-block plans, persistent operand buffers, one library RCCL all-gather per ghost-line exchange
+    # (of the rank's own first / last lines; it has no neighbour, so nothing is filled in) -- i.e. every kernel and every host
+    # step of a rank's cycle except the neighbours' data.  What it costs next to AMGHierarchy.cycle on the same rows is the
+    # per-rank overhead of the distributed cycle before inter-GPU latency.
+    REHEARSE_ONE_RANK = False
 
     def __init__(self, H, group=None, overlap=True, agglomerate_below=None):
         self.group = group
@@ -117,8 +123,11 @@ class RowBlockAMG:
         the temporally blocked smoothing passes of this level need one ghost-line exchange each."""
         ops = self.A_ops[lv]
         ops.ext = None
-        if self.world > 1 and e_l.is_cuda:
+        if (self.world > 1 or (self.REHEARSE_ONE_RANK and dist.is_initialized())) and e_l.is_cuda:
             ops._setup_ghost(e_l, v_l.reshape(-1, 1))
+            if self.world == 1 and ops.ext is not None:      # rehearsal: the ghost-line all-gathers run on a one-rank library communicator
+                from .dist import LibComm
+                ops.comm = LibComm.for_group(self.group)
         if ops.ext is not None:
             e = ops.ext
             dt, dev = e["dtype"], e["dev"]
@@ -327,7 +336,15 @@ class RowBlockAMG:
         own = lambda v: v[off:off + nl]                      # noqa: E731
         vecs = []
         if b is not None:
-            own(a["b"]).copy_(b.reshape(-1))
+            # b is copied into the level's extended block unless it is already there: restrict() writes a coarse level's
+            # right-hand side straight into this buffer, and the caller's level-0 b is recognised across cycles by identity and
+            # version counter (the reference to it is kept: an address alone could be a new tensor in recycled memory)
+            src = a.get("b_src")
+            if b.data_ptr() == own(a["b"]).data_ptr() and b.numel() == nl:
+                a["b_src"] = None
+            elif getattr(self, "_capturing", False) or not (src is not None and src[0] is b and src[1] == b._version):
+                own(a["b"]).copy_(b.reshape(-1))
+                a["b_src"] = (b, b._version)
             vecs.append(a["b"])
         x_full = ops._ext_of(x, (1,))                        # x allocated with its ghost rows (correct() does): used in place
         if x_full is not None:
@@ -338,7 +355,12 @@ class RowBlockAMG:
         vecs.append(x_e)
         ops._fill_ghosts(vecs, ops._ghost_exchange([own(v) for v in vecs]))
         ops._ghost_pending = None
-        return a["d"], a["b"], x_e, own
+
+        def own_marked(full):                                # own-row view of a fresh extended result, recognised by _ext_of:
+            v = full[off:off + nl]                           # the next smoothing pass (this cycle's or the next one's) reads it in place
+            v._gla_ext = full
+            return v
+        return a["d"], a["b"], x_e, own_marked
 
     def presmooth_residual(self, level, b, x):
         """n_pre sweeps and r = b - A x of the result.  Ghost-line levels: ONE exchange ([b, x] ghost lines) and ONE pass of the
@@ -367,7 +389,14 @@ class RowBlockAMG:
 
     def restrict(self, level, r):
         ops = self.Pt_ops[level]
-        rc = torch.empty((ops.part.n_local, r.shape[1]), dtype=r.dtype, device=r.device)
+        nxt = self.A_ops[level + 1] if level + 1 < self.n_dist else None
+        if nxt is not None and nxt.ext is not None and r.shape[1] == 1 and nxt.ext["dtype"] == r.dtype:
+            # the coarse level's right-hand side lands in that level's extended block (its smoothing pass reads it there)
+            e = nxt.ext
+            rc = e["amg"]["b"][e["off"]:e["off"] + nxt.part.n_local].reshape(-1, 1)
+            e["amg"]["b_src"] = None
+        else:
+            rc = torch.empty((ops.part.n_local, r.shape[1]), dtype=r.dtype, device=r.device)
         self._apply(ops, r, lambda buf, which: ops.plan.spmm(buf, out=rc, which=which))
         return rc
 
@@ -386,6 +415,41 @@ class RowBlockAMG:
         out = a_ops.ext_tensor(1, dtype=x.dtype, zero=False) if (a_ops.ext is not None and x.shape[1] == 1) else torch.empty_like(x)
         self._apply(ops, xc, lambda buf, which: ops.plan.spmm_add(x, buf, out=out, which=which))
         return out
+
+    def capture_cycle(self, dtype=torch.float64):
+        """This rank's cycle captured into a HIP graph (torch.cuda.CUDAGraph): returns run(b_local, x_local) -> x_new_local,
+        bit-identical to cycle().  A rank's share of a deep hierarchy is ~70 launches of a few microseconds each plus the
+        exchanges: driven from Python the host, not the GPU, bounds the cycle once the blocks are small (8 ranks: level 0 is
+        2.1 M rows per rank).  Needs the library's RCCL communicator (or a single rank): torch.distributed's host-ordered
+        collectives of the gloo rehearsal route cannot be captured.  Every rank must capture and replay alike."""
+        dev = self.A_ops[0].plan.device if self.A_ops else self.sub.H.plans[0].device
+        lo, hi = self.blocks[0][self.rank]
+        sb = torch.zeros((hi - lo, 1), dtype=dtype, device=dev)
+        sx = torch.zeros_like(sb)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        self._capturing = True                               # (no operand copy may be skipped on the strength of an earlier call)
+        try:
+            with torch.cuda.stream(side):                    # warm-up off the capture: lazy allocations, code loads
+                for _ in range(2):
+                    self.cycle(sb, sx)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.cycle(sb, sx)
+        finally:
+            self._capturing = False
+        for ops in self.A_ops:                               # the eager path must not trust what the capture left behind
+            if ops.ext is not None and "amg" in ops.ext:
+                ops.ext["amg"]["b_src"] = None
+
+        def run(b, x):
+            sb.copy_(b)
+            sx.copy_(x)
+            graph.replay()
+            return out.clone()
+        run.graph = graph
+        return run
 
     def cycle(self, b, x, level=0):
         """One V-cycle on this rank's rows: b, x are the LOCAL parts ([n_local, 1]) of the level vectors."""

@@ -344,6 +344,69 @@ def test_distributed_vcycle_two_ranks(world):
         assert status == "ok", f"rank {rank}: {status}"
 
 
+def _amg_one_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    keep = os.dup(1)
+    os.dup2(2, 1)                                            # (RCCL's banner goes to stderr)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        import gnn_applied_linear_algebra_amd as gla
+        from gnn_applied_linear_algebra_amd import dist as gdist
+        from gnn_applied_linear_algebra_amd.dist_amg import RowBlockAMG
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        gla._lib.check(gla._lib.lib().gla_set_option(b"jacobi_min_rows", 0))      # the ghost-line passes also on this small mesh
+        V = gla.VCycle
+        m = 127
+        n = m * m
+        ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 1.0], device=dev)
+        A = V._as_sparse(ei, ev, (n, n))
+        H = V.AMGHierarchy(A, levels=4, splitting=V.GridSplitting(m, m), coarse_solver="dense")
+        RowBlockAMG.REHEARSE_ONE_RANK = True
+        D = RowBlockAMG(H, overlap=True, agglomerate_below=2000)
+        assert D.n_dist == 2 and all(o.ext is not None and o.comm is not None for o in D.A_ops), (D.n_dist, [o.ext is None for o in D.A_ops])
+        gen = torch.Generator().manual_seed(2)
+        b = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
+        xs, xd = torch.zeros_like(b), torch.zeros_like(b)
+        for _ in range(3):
+            xs = H.cycle(b, xs)
+            e0 = gdist.EXCHANGES[0]
+            xd = D.cycle(b, xd)
+            assert torch.equal(xs, xd), "one-rank distributed cycle differs from AMGHierarchy.cycle"
+        assert gdist.EXCHANGES[0] - e0 == 2 * D.n_dist          # (one rank: the halos of r and xc are empty, the hand-over gather is local)
+        b2 = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)      # a different right-hand side: the copy cache must notice
+        assert torch.equal(D.cycle(b2, xd), H.cycle(b2, xs))
+        b2.mul_(0.5)                                                             # ... and an in-place change of the same tensor
+        assert torch.equal(D.cycle(b2, xd), H.cycle(b2, xs))
+        run = D.capture_cycle()                                                  # the rank's cycle as one HIP graph, RCCL all-gathers included
+        for rhs in (b, b2, b):
+            xg = run(rhs, xd)
+            assert torch.equal(xg, D.cycle(rhs, xd)) and torch.equal(xg, H.cycle(rhs, xs)), "captured cycle"
+        torch.cuda.synchronize()
+        q.put((0, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((0, "fail: " + traceback.format_exc()))
+    finally:
+        from gnn_applied_linear_algebra_amd.dist import LibComm
+        LibComm.release_all()
+        dist.destroy_process_group()
+        os.dup2(keep, 1)
+
+
+def test_distributed_vcycle_one_rank_rccl_and_graph_capture():
+    """A process group of ONE rank over real RCCL: every distributed level on the ghost-line route with its all-gathers on
+    libgla_hip's communicator (dist_amg.RowBlockAMG.REHEARSE_ONE_RANK), bit-identical to AMGHierarchy.cycle; the right-hand
+    side copy cache follows new tensors and in-place updates; the whole cycle replays from a HIP graph bit-identically."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_amg_one_rank_worker, args=(_free_port(), q))
+    pr.start()
+    res = q.get(timeout=300)
+    pr.join(timeout=60)
+    assert res[1] == "ok", res[1]
+
+
 def _self_halo_driver(gla, Nx, Ny, K, overlap, dev):
     """A one-rank 'row block' whose vertical couplings of the first / last two grid lines are redirected to HALO slots
     that the all-gather fills with copies of the very same rows: numerically the plain Laplacian, but every sweep goes
