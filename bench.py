@@ -698,6 +698,9 @@ def single_gpu(args, gla, dev):
         except Exception as exc:
             out["config5_vcycle"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         torch.cuda.empty_cache()
+        # ---- side: config 5 is "8 x MI355X": a rank's share of the distributed cycle rehearsed on this GPU (child process: it
+        # needs a one-rank RCCL process group of its own)
+        out["dist_vcycle_one_rank"] = side_dist_vcycle(120.0)
         # ---- side: non-stencil matrices through the CSR-adaptive kernels (stream / vector / long bins) ----------------------
         try:
             out["csr_irregular"] = side_irregular(gla, dev)
@@ -764,6 +767,35 @@ def side_config5(gla, dev, m):
         del H, x, xs
         torch.cuda.empty_cache()
     return rec
+
+
+def side_dist_vcycle(timeout_s):
+    """dist_amg.RowBlockAMG's cycle driven by ONE rank over real RCCL next to AMGHierarchy.cycle on the same rows
+    (tools/bench_dist_vcycle_one_rank.py, run as a child process with its own process group): every distributed level on the
+    ghost-line route, its all-gathers on libgla_hip's communicator, no neighbour data -- what a rank's cycle costs before
+    inter-GPU latency.  (a) 4095^2 with the agglomeration threshold of 8 ranks: a whole GPU's worth of rows; (b) 1447^2 =
+    2.1 M rows, the level-0 block of one of 8 ranks: the eager cycle is host-bound there, the HIP-graph replay is not."""
+    recs = {"what": "a rank's share of the distributed V(3,3) cycle on ONE GPU over a one-rank RCCL group vs the single-GPU "
+                    "cycle on the same rows; no multi-GPU hardware was reachable: NOT a scaling measurement"}
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 400))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    for key, argv in (("mesh4095_threshold_of_8_ranks", ["4095", "8", "524288"]), ("mesh1447_block_of_one_of_8_ranks", ["1447", "7", "65536"])):
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_dist_vcycle_one_rank.py"), *argv, "--json"]
+        try:
+            pr_ = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            try:
+                so, _ = pr_.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                pr_.kill()
+                pr_.wait()
+                recs[key] = {"error": f"timed out after {timeout_s:.0f} s"}
+                continue
+            lines = [ln for ln in so.decode(errors="replace").splitlines() if ln.startswith("{")]
+            recs[key] = json.loads(lines[-1]) if pr_.returncode == 0 and lines else {"error": f"child exited with {pr_.returncode}"}
+        except Exception as exc:                             # (a side record: never the reason a bench run fails)
+            recs[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    return recs
 
 
 def side_irregular(gla, dev):

@@ -16,9 +16,11 @@ import gnn_applied_linear_algebra_amd as gla          # noqa: E402
 from gnn_applied_linear_algebra_amd import dist as gdist          # noqa: E402
 from gnn_applied_linear_algebra_amd.dist_amg import RowBlockAMG   # noqa: E402
 
-m = int(sys.argv[1]) if len(sys.argv) > 1 else 4095
-levels = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-agg = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 16
+as_json = "--json" in sys.argv
+argv = [a for a in sys.argv if not a.startswith("--")]
+m = int(argv[1]) if len(argv) > 1 else 4095
+levels = int(argv[2]) if len(argv) > 2 else 8
+agg = int(argv[3]) if len(argv) > 3 else 1 << 16
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29517")
 keep = os.dup(1)
@@ -75,6 +77,17 @@ for _ in range(3):
     same_g = same_g and bool(torch.equal(xg, xe))
 _, ms_g, mn_g = timed(run, torch.zeros_like(b))
 os.dup2(keep, 1)
+if as_json:
+    import json
+    med = sorted(res)[len(res) // 2]
+    print(json.dumps({"mesh": f"{m}^2 Q1 FEM", "rows": n, "level_rows": [int(a.shape[0]) for a in H.A], "distributed_levels": D.n_dist,
+                      "ghost_line_levels": ghost_lv, "agglomerate_below_rows_per_rank": agg, "collectives_per_cycle_this_rank": n_ex,
+                      "bit_identical_to_single_gpu_cycle": same, "single_gpu_ms_per_cycle": round(med[0], 3),
+                      "one_rank_distributed_ms_per_cycle": round(med[1], 3), "ratio": round(med[1] / med[0], 3),
+                      "hip_graph_replay_ms_per_cycle": round(ms_g, 3), "hip_graph_bit_identical": same_g}))
+    gdist.LibComm.release_all()
+    dist.destroy_process_group()
+    sys.exit(0)
 print(f"m={m} n={n} levels={[int(a.shape[0]) for a in H.A]}")
 print(f"distributed levels {D.n_dist} (ghost-line route on {ghost_lv}), replicated from level {D.n_dist} on; "
       f"collectives per cycle on this rank: {n_ex}; iterates bit-identical to AMGHierarchy.cycle: {same}")
