@@ -75,6 +75,8 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
   constexpr int LV = TS, NC = LV + PF, U = NC;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   double* buf = reinterpret_cast<double*>(smem_raw);
+  double* const obuf = buf + TS * 2 * LW;            // ST >= 8: [ST][BW] output lines awaiting their burst
+  (void)obuf;
   int blk;
   {
     const int bid = blockIdx.x, C = xcd_chunk, xcd = bid % 8, j = bid / 8;
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
           if (t == TS) {
             if constexpr (ST == 0) { if (owner) xo[(J0 + jl - (TS - 1)) * p.S + gi] = xn; }
             else if constexpr (ST == 1) { if (owner) __builtin_nontemporal_store(xn, xo + (J0 + jl - (TS - 1)) * p.S + gi); }
+            else if constexpr (ST >= 8) { obuf[((jl - (TS - 1)) & (ST - 1)) * BW + tid] = xn; }      // (flushed ST lines at a time, below)
             else { if (owner && xn == 1.2345e300) xo[gi] = xn; }
           }
         }
@@ -246,7 +249,22 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
           double xn = h[t - 1][1] + (w * (cc.b - acc)) / cc.dg;
           xn = lv ? xn : 0.0;
           if (t < LV) { h[t][2] = xn; row[2 * LW + 1] = xn; }
-          if (t == TS) { if (lv && owner) xo[(J0 + line) * p.S + gi] = xn; }
+          if (t == TS) {
+            if constexpr (ST >= 8) { if (line >= 0) obuf[(line & (ST - 1)) * BW + tid] = lv ? xn : __builtin_nan(""); }
+            else { if (lv && owner) xo[(J0 + line) * p.S + gi] = xn; }
+          }
+        }
+      }
+    }
+    if constexpr (ST >= 8) {                        // burst stores: every lane writes its own column of the last ST output lines
+      const int lo_ = jl - (TS - 1);
+      if (nact == LV && lo_ >= 0 && (((lo_ & (ST - 1)) == ST - 1) || jl == j_last)) {
+        const int first = lo_ & ~(ST - 1);
+        if (owner) {
+          for (int q = first; q <= lo_; ++q) {
+            const double v = obuf[(q & (ST - 1)) * BW + tid];
+            if (v == v) xo[(J0 + q) * p.S + gi] = v;          // (NaN marks a row that does not exist; this experiment's data has no NaN results)
+          }
         }
       }
     }
@@ -613,9 +631,9 @@ void run_kernel(Ctx& c, const std::string& name, int TS, K kern, int threads, si
 template <int TS, int HD, int PRIO, int PF = 1, int ST = 0, int AL = 0>
 void run_v2(Ctx& c, const char* name, int lines_override = 0, int per_cu = 2) {
   char nm[100];
-  snprintf(nm, sizeof nm, "v2 hd%d prio%d pf%d wg/cu=%d%s%s", HD, PRIO, PF, per_cu, ST == 1 ? " nt-store" : ST == 2 ? " NO-STORE" : "", AL ? " aligned-own" : "");
+  snprintf(nm, sizeof nm, "v2 hd%d prio%d pf%d wg/cu=%d%s%s", HD, PRIO, PF, per_cu, ST == 1 ? " nt-store" : ST == 2 ? " NO-STORE" : ST == 8 ? " burst8" : ST == 16 ? " burst16" : ST == 32 ? " burst32" : "", AL ? " aligned-own" : "");
   (void)name;
-  run_kernel(c, nm, TS, march5v2<TS, HD, PRIO, PF, ST, AL>, BW, (size_t)TS * 2 * (BW + 2) * 8, per_cu, 2 * (TS - 1), lines_override, AL);
+  run_kernel(c, nm, TS, march5v2<TS, HD, PRIO, PF, ST, AL>, BW, (size_t)TS * 2 * (BW + 2) * 8 + (ST >= 8 ? (size_t)ST * BW * 8 : 0), per_cu, 2 * (TS - 1), lines_override, AL);
 }
 template <int LA, int LB, int HOIST, int PRIO, int PFA, int PFB, int DIAG = 0>
 void run_g(Ctx& c, const char* name, int lines_override = 0) {
@@ -698,11 +716,12 @@ int main(int argc, char** argv) {
       continue;
     }
     run_v2<7, 2, 2>(c, "");
-    run_v2<7, 2, 2, 1, 0, 1>(c, "");
-    run_v2<7, 2, 2, 1, 1, 1>(c, "");
+    run_v2<7, 2, 2, 1, 8>(c, "");
+    run_v2<7, 2, 2, 1, 16>(c, "");
     run_v2<4, 2, 2, 1, 0>(c, "");
-    run_v2<4, 2, 2, 1, 0, 1>(c, "");
-    run_v2<4, 2, 2, 1, 2, 1>(c, "");
+    run_v2<4, 2, 2, 1, 8>(c, "");
+    run_v2<4, 2, 2, 1, 16>(c, "");
+    run_v2<4, 2, 2, 1, 32>(c, "");
   }
   for (auto& kv : c.samples) {
     auto& v = kv.second;
