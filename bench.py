@@ -404,8 +404,14 @@ def single_gpu(args, gla, dev):
              ("spmv_dia_kernel<double,EpiJacobi>" if int(info.dia) > 0 and not bool(info.packed) else
               "spmv_stream_vec2_kernel<double,EpiJacobi>"))
     # bytes one launch has to move with this plan's layout (one pass over the matrix whatever the sweeps it carries)
+    # (symmetric value sets, option "sym": the march kernel reads the lower diagonals from their upper partners -- 3 of a 5-point
+    # matrix's 5 diagonals cross HBM)
+    n_sym = bin(int(info.dia_sym)).count("1") if (march and int(info.dia_canon5) == 1) else 0
+    row_bytes = 8 * (int(info.dia) - n_sym) + 2 + 32
     if int(info.dia) > 0 and not bool(info.packed):
-        layout_name, Bl = f"dia{int(info.dia)}" + (f", {spl} sweeps per pass" if fused else ""), (8 * int(info.dia) + 2 + 32) * pr.n_local
+        layout_name = (f"dia{int(info.dia)}" + (f", symmetric: {int(info.dia) - n_sym} diagonals read" if n_sym else "")
+                       + (f", {spl} sweeps per pass" if fused else ""))
+        Bl = row_bytes * pr.n_local
     elif args.compress and bool(info.packed):
         layout_name, Bl = "packed stream", 3 * pr.nnz + 2 * (pr.n_local + int(info.n_tiles)) + 32 * pr.n_local
         kname = "spmv_packed_kernel<double,EpiJacobi>"
@@ -426,7 +432,7 @@ def single_gpu(args, gla, dev):
     tp = os.path.join(ROOT, "profiles", "traffic_jacobi.json")
     if traffic is None and os.path.exists(tp):
         tj = json.load(open(tp))
-        if tj.get("n") == args.n and int(tj.get("dia", 0)) == int(info.dia) and not bool(info.packed) \
+        if tj.get("n") == args.n and int(tj.get("dia", 0)) == int(info.dia) and int(tj.get("dia_sym", 0)) == n_sym and not bool(info.packed) \
                 and int(tj.get("sweeps_per_launch", 1)) == spl and (fused or int(tj.get("col16", 0)) == int(info.col16)):
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = "profiles/traffic_jacobi.json: PMC passes of an EARLIER run of this kernel and layout, not re-measured now"
@@ -508,10 +514,40 @@ def single_gpu(args, gla, dev):
                 "what": "same step with option jacobi_fuse=0: spmv_dia_kernel<double,EpiJacobi>, one launch per sweep",
                 "value": round(total_sweeps / el, 2), "unit": "sweeps/s", "launch_us": round(tl * 1e6, 2),
                 "achieved": round(Bl / tl / 1e9, 1), "frac": round(Bl / tl / HBM_PEAK, 4),
-                "bytes_moved_is": "layout bytes of one pass (74 B per row)", "layout_bytes_per_launch": Bl,
+                "bytes_moved_is": f"layout bytes of one pass ({8 * int(info.dia) + 34} B per row)", "layout_bytes_per_launch": Bl,
                 "pass_model_frac": round(pr.B / tl / HBM_PEAK, 4), "bit_identical_to_default": same}
         finally:
             check(L.gla_set_option(b"jacobi_fuse", 1))
+
+    # ---- side: the same step on ALL FIVE diagonals (option sym = 0): what a matrix whose value set is not symmetric gets --------
+    if side and n_sym:
+        try:
+            check(L.gla_set_option(b"sym", 0))
+            ref_out = step()                                  # (sym is read at launch: this is the five-diagonal kernel)
+            check(L.gla_set_option(b"sym", 1))
+            same = bool(torch.equal(step(), ref_out))
+            check(L.gla_set_option(b"sym", 0))
+            el, _ = timed_steps(step, args.steps, 1)
+            ts = []
+            for it in range(8):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(L.gla_jacobi_fused(plan._h, dtype_code(torch.float64), ptr(diag1), ptr(pr.b), ptr(pr.x0), ptr(xo_buf), 0.7, spl,
+                                         0, stream_ptr(dev)))
+                e1.record()
+                torch.cuda.synchronize()
+                if it >= 2:
+                    ts.append(e0.elapsed_time(e1) * 1e-3)
+            tl = median(ts)
+            Bg = (8 * int(info.dia) + 2 + 32) * pr.n_local
+            out["unsymmetric_layout"] = {
+                "what": "same step with option sym=0: every diagonal is read (what a plan whose VALUES are not symmetric bit for "
+                        "bit runs on; the default recognises A_ij == A_ji at gla_csr_set_values and reads 3 of the 5 diagonals)",
+                "value": round(total_sweeps / el, 2), "unit": "sweeps/s", "launch_us": round(tl * 1e6, 2),
+                "layout_bytes_per_launch": Bg, "achieved": round(Bg / tl / 1e9, 1), "frac": round(Bg / tl / HBM_PEAK, 4),
+                "bytes_moved_is": f"layout bytes of one pass ({8 * int(info.dia) + 34} B per row)", "bit_identical_to_default": same}
+        finally:
+            check(L.gla_set_option(b"sym", 1))
 
     # ---- side: the general CSR-stream kernel (what every non-stencil matrix gets): same step with dia = 0 -----------
     if side:

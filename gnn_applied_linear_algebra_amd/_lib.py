@@ -27,7 +27,8 @@ class CsrInfo(ctypes.Structure):
                 ("long_rows", ctypes.c_int32), ("val_dtype", ctypes.c_int32), ("packed", ctypes.c_int32),
                 ("col16", ctypes.c_int32), ("col16_wide_tiles", ctypes.c_int32), ("dia", ctypes.c_int32),
                 ("dia_stride", ctypes.c_int32), ("dia_row_lo", ctypes.c_int64), ("dia_row_hi", ctypes.c_int64),
-                ("dia_A", ctypes.c_int32), ("dia_B", ctypes.c_int32), ("dia_canon5", ctypes.c_int32)]
+                ("dia_A", ctypes.c_int32), ("dia_B", ctypes.c_int32), ("dia_canon5", ctypes.c_int32),
+                ("dia_sym", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p

@@ -53,6 +53,8 @@ struct gla_csr {
   int32_t dia_off[16] = {0};     // ascending offsets (host copy; passed to the kernels by value)
   uint16_t* dia_mask = nullptr;  // [n_rows] bit d set: row has an entry on diagonal d
   void* dia_val = nullptr;       // [dia_D][n_rows] values, diagonal-major (0 where the row has no entry)
+  int32_t dia_sym = 0;           // bit d set: diagonal d (offset < 0) repeats its partner of offset -off bit for bit, A[r][r + off] ==
+                                 // A[r + off][r] for every row (0 where r + off < 0): the kernels need not read it (option "sym")
   int32_t dia_const = 0;         // 1 (option "compress"): every diagonal holds ONE value -> no value stream either
   double dia_cval[16] = {0};     // that value per diagonal
   int64_t dia_row_lo = 0, dia_row_hi = 0;   // rows [lo, hi) fit the diagonal set (halo rows of a row block do not)
@@ -81,6 +83,8 @@ struct gla_tuning {
   int jacobi_lines = 0;     // grid lines a workgroup of the fused kernel marches through (0 = one resident round of workgroups)
   int jacobi_ts_max = 8;    // canonical 5-point plans: most sweeps per pass (2 .. 8)
   int jacobi_ts_max9 = 5;   // canonical 9-point plans: most sweeps per pass (2 .. 6)
+  int sym = 1;              // stencil plans whose value set is symmetric (checked bit for bit at gla_csr_set_values): the K = 1 march
+                            // kernels read the lower diagonals from their upper partners (24 instead of 40 bytes of values per 5-point row)
   int jacobi_march = 1;     // canonical 5-point plans: 1 = the register-history march kernel, 0 = the generic LDS-ring kernel
   int64_t jacobi_min_rows = 1 << 19;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
                                        // is faster: 512^2 takes 4.5 us per sweep single vs 5.9 fused, 768^2 8.4 vs 6.0)
@@ -138,6 +142,8 @@ struct gla_march5_args {
   int ghost;                   // ghost lines either end (parts 1 / 2)
   int64_t aos_off, aos_rows;
 };
+// every lower diagonal of the canonical 5-point plan repeats its upper partner (and the option allows using that)
+inline bool gla_dia_sym5(const gla_csr* A) { return g_tuning.sym && gla_dia_canon5(A) && (A->dia_sym & 3) == 3; }
 int gla_march5_pass(const gla_march5_args& a);
 // GLA_OK iff gla_jacobi_fused_parts(_aos) would run `sweeps` sweeps on this canonical 5-point plan with these value types
 // (gla_rows.hip); otherwise the status it would return.  For callers that must know BEFORE they enqueue anything (gla_dist.hip).

@@ -29,6 +29,12 @@
 // Per row the arithmetic is that of spmv_dia_kernel + EpiJacobi (in-order masked sum over the diagonals, then
 // x + (w * (b - sum)) / A_ii, product and sum rounded separately): bit-identical to TS single sweeps.
 //
+// Round 4, SYM: on a plan whose value set is symmetric (A_ij == A_ji bit for bit along both diagonal pairs, checked at
+// gla_csr_set_values; option "sym") only the centre, east and south diagonals are read: a row's west coefficient is the east
+// coefficient of the point before it (same cache lines as the east load), its north coefficient the south coefficient of the
+// line above (the lane's own previous set).  24 instead of 40 bytes of values per row; the pass is bound by its bytes
+// (profiles/r04/march5v2_what_bounds_the_pass.txt), so it takes a fifth less time.  Same values, same order: bit-identical.
+//
 // MODE 1 (first pass of gla_jacobi_sweeps_aos): A_ii, b and x^(k) are columns 0, 1, 2 of the reference's row-major vertex
 // attribute tensor (JacobiGNN.py:104-106); the lane that owns a row leaves contiguous copies of its A_ii and b in diag_out /
 // b_out for the later passes.  MODE 2 (gla_jacobi_fused_residual): one more level forms r = b - A x^(k+TS) (-> b_out).
@@ -79,7 +85,7 @@ struct M5Coef {               // one row's matrix data
 
 constexpr int M5_PLAIN = 0, M5_AOS = 1, M5_RES = 2;
 
-template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX>
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM>
 __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, const T* __restrict__ diag,
                                                                      const T* __restrict__ bvec, const T* __restrict__ x,
                                                                      T* __restrict__ xo, T w, int lines, int nstrips, TileMap tm,
@@ -133,8 +139,17 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
   auto coef_at = [&](int jl) -> M5Coef<T> {
     const int64_t rc = row_clamped(jl);
     M5Coef<T> c;
+    if constexpr (SYM) {
+      c.v[2] = val[2 * dv.n_rows + rc];
+      c.v[3] = val[3 * dv.n_rows + rc];
+      c.v[4] = val[4 * dv.n_rows + rc];
+      const T wv = val[3 * dv.n_rows + max(rc - 1, (int64_t)0)];      // west(r) = east(r - 1); a line's first point has none
+      c.v[1] = gi == 0 ? T(0) : wv;
+      c.v[0] = T(0);                                                  // north: filled in at the set's first use (below)
+    } else {
 #pragma unroll
-    for (int d = 0; d < 5; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
+      for (int d = 0; d < 5; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
+    }
     if constexpr (AOS) {
       const int64_t ra = min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1);
       c.dg = x[ra * ldva];
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
   c[0] = coef_at(j_first);
 #pragma unroll
   for (int s = 1; s < NC; ++s) c[s] = c[0];
+  if constexpr (SYM) c[NC - 1].v[4] = val[4 * dv.n_rows + row_clamped(j_first - 1)];    // (the set "before" the first: its south)
 #pragma unroll
   for (int s = 0; s < NC; ++s) { crc[s] = T(1); cfast[s] = false; }
 
@@ -192,6 +208,8 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
     row_o[1] = h[0][2];                            // level 0, line jl + 1
     xpre = x0_load(jl + 2);
     c[(u + 1) % NC] = coef_at(jl + 1);
+    if constexpr (SYM)                             // north(line jl) = south(line jl - 1); the grid's first line has none
+      c[u % NC].v[0] = J0 + jl <= 0 ? T(0) : c[(u + NC - 1) % NC].v[4];
     {                                              // first use of the set of line jl (loaded a step ago)
       const M5Coef<T>& cu = c[u % NC];
       const int64_t gj = J0 + jl;
@@ -335,16 +353,16 @@ template <typename T, int LV, int MODE> struct M5Cfg {
   static constexpr int hd = sizeof(T) == 4 ? 2 : (LV >= 8 || (MODE == M5_AOS && LV == 6) ? 0 : 2);
   static constexpr bool static_idx = sizeof(T) == 4 || LV >= 8;
 };
-#define M5_KERNEL(T, TS, MODE, LV) jacobi_march5_kernel<T, TS, MODE, M5Cfg<T, LV, MODE>::rcp, M5Cfg<T, LV, MODE>::hd, M5Cfg<T, LV, MODE>::static_idx>
+#define M5_KERNEL(T, TS, MODE, LV, SYM) jacobi_march5_kernel<T, TS, MODE, M5Cfg<T, LV, MODE>::rcp, M5Cfg<T, LV, MODE>::hd, M5Cfg<T, LV, MODE>::static_idx, SYM>
 
-template <typename T, int TS, int MODE>
+template <typename T, int TS, int MODE, bool SYM>
 int m5_blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     constexpr int LV = TS + (MODE == M5_RES ? 1 : 0);
     int nb = 0;
     const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, M5_KERNEL(T, TS, MODE, LV), GLA_BLOCK, lds) != hipSuccess || nb < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, M5_KERNEL(T, TS, MODE, LV, SYM), GLA_BLOCK, lds) != hipSuccess || nb < 1) {
       (void)hipGetLastError();
       nb = 2;
     }
@@ -353,8 +371,8 @@ int m5_blocks_per_cu() {
   return cached;
 }
 
-template <typename T, int TS, int MODE>
-int m5_launch(const gla_march5_args& a) {
+template <typename T, int TS, int MODE, bool SYM>
+int m5_launch_sym(const gla_march5_args& a) {
   gla_csr* A = a.A;
   constexpr int LV = TS + (MODE == M5_RES ? 1 : 0);
   M5View dv;
@@ -390,7 +408,7 @@ int m5_launch(const gla_march5_args& a) {
     // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (LV - 1) coefficient
     // lines) for which all workgroups are resident at once.  Measured (tools/ab_jacobi_march.py): two workgroups per CU beat
     // three or four even where the registers allow more -- fewer, longer streams; one per CU cannot hide a line step
-    int per_cu = m5_blocks_per_cu<T, TS, MODE>();
+    int per_cu = m5_blocks_per_cu<T, TS, MODE, SYM>();
     if (per_cu > 2) per_cu = 2;
     // Interior / boundary split: the interior launch leaves 2 x nstrips workgroup slots FREE for the two edge line blocks that
     // a second stream launches once the ghost lines are in.  A march workgroup takes half a CU's registers, so on a chip full
@@ -418,11 +436,16 @@ int m5_launch(const gla_march5_args& a) {
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
-  hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV)), grid, block, lds, a.st, dv,
+  hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV, SYM)), grid, block, lds, a.st, dv,
                      (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1,
                      a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out);
   GLA_LAUNCH_CHECK();
   return GLA_OK;
+}
+
+template <typename T, int TS, int MODE>
+int m5_launch(const gla_march5_args& a) {
+  return gla_dia_sym5(a.A) ? m5_launch_sym<T, TS, MODE, true>(a) : m5_launch_sym<T, TS, MODE, false>(a);
 }
 
 template <typename T, int MODE>

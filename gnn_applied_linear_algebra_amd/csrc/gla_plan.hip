@@ -568,6 +568,56 @@ int detect_dia_const(gla_csr* p, hipStream_t st) {
   return GLA_OK;
 }
 
+// Symmetric value sets (option "sym"): diagonal d of offset off < 0 with a partner q of offset -off is REDUNDANT when
+// val[d][r] == val[q][r + off] bit for bit for every row r with r + off >= 0, and == +0 above (A_ij == A_ji along the pair,
+// absent entries being stored zeros on both sides).  The K = 1 march kernels then read the partner instead: the negative
+// Laplacian of UtilsGNN.py:53-67, the Q1 stiffness matrix of heateqnfem2dfun.m and every Galerkin operator P^T A P of theirs
+// qualify; a convection term, a one-sided hole or a -0.0 against a +0.0 does not, and such a plan keeps all its diagonals.
+template <typename T, typename U>
+__global__ __launch_bounds__(GLA_BLOCK) void dia_sym_kernel(const T* __restrict__ dia_val, int64_t n_rows, int D, DiaOffsets off,
+                                                            int* __restrict__ broken) {      // bit d: pair (d, partner) differs
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK) {
+    int bad = 0;
+    for (int d = 0; d < D; ++d) {
+      const int64_t o = off.off[d];
+      if (o >= 0) break;                                      // (offsets ascend)
+      int q = -1;
+      for (int e = d + 1; e < D; ++e) if ((int64_t)off.off[e] == -o) q = e;
+      if (q < 0) { bad |= 1 << d; continue; }
+      const U mine = __builtin_bit_cast(U, dia_val[(int64_t)d * n_rows + r]);
+      const U want = r + o >= 0 ? __builtin_bit_cast(U, dia_val[(int64_t)q * n_rows + r + o]) : (U)0;
+      if (mine != want) bad |= 1 << d;
+    }
+    if (bad) atomicOr(broken, bad);
+  }
+}
+
+template <typename T, typename U>
+int detect_dia_sym(gla_csr* p, hipStream_t st) {
+  p->dia_sym = 0;
+  if (p->dia_state != 1 || !p->dia_val || p->dia_row_lo != 0 || p->dia_row_hi != p->n_rows || p->n_rows != p->n_cols ||
+      p->dia_S <= 0 || !p->dia_nowrap)
+    return GLA_OK;
+  int n_neg = 0;
+  for (int d = 0; d < p->dia_D; ++d) n_neg += p->dia_off[d] < 0;
+  if (n_neg == 0) return GLA_OK;
+  int* d_broken = nullptr;
+  int h_broken = 0;
+  hipError_t e = hipMalloc(&d_broken, sizeof(int));
+  if (e != hipSuccess) return -(1000 + (int)e);
+  e = hipMemsetAsync(d_broken, 0, sizeof(int), st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL((dia_sym_kernel<T, U>), dim3(grid_for(p->n_rows)), dim3(GLA_BLOCK), 0, st, (const T*)p->dia_val, p->n_rows,
+                       p->dia_D, dia_offsets_of(p), d_broken);
+    e = hipMemcpyAsync(&h_broken, d_broken, sizeof(int), hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_broken);
+  if (e != hipSuccess) return -(1000 + (int)e);
+  p->dia_sym = ((1 << n_neg) - 1) & ~h_broken;
+  return GLA_OK;
+}
+
 // Value side, at gla_csr_set_values: scatter the CSR values onto their diagonals (absent entries stay 0)
 template <typename T>
 int fill_dia(gla_csr* p, hipStream_t st) {
@@ -733,6 +783,7 @@ int gla_set_option(const char* name, int64_t value) {
   if (!strcmp(name, "xcd_chunk")) { if (value < 0) return GLA_ERR_INVALID_ARG; g_tuning.xcd_chunk = (int)value; return GLA_OK; }
   if (!strcmp(name, "col16")) { g_tuning.col16 = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "dia")) { g_tuning.dia = value ? 1 : 0; return GLA_OK; }
+  if (!strcmp(name, "sym")) { g_tuning.sym = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "row_sum")) { g_tuning.row_sum = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "jacobi_fuse")) { if (value < 0 || value > 2) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_fuse = (int)value; return GLA_OK; }
   if (!strcmp(name, "jacobi_min_rows")) { if (value < 0) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_min_rows = value; return GLA_OK; }
@@ -963,6 +1014,11 @@ int gla_csr_set_values(gla_csr_t p, const void* edge_val, int64_t stride, int dt
     if (rc) return rc;
   }
   p->dia_const = 0;
+  p->dia_sym = 0;
+  if (g_tuning.sym) {                                 // (one pass over the diagonals + a host wait, once per value set)
+    const int rc = dtype == GLA_F64 ? detect_dia_sym<double, uint64_t>(p, st) : detect_dia_sym<float, uint32_t>(p, st);
+    if (rc) return rc;
+  }
   if (g_tuning.compress) {
     const int rc = dtype == GLA_F64 ? detect_dia_const<double, uint64_t>(p, st) : detect_dia_const<float, uint32_t>(p, st);
     if (rc) return rc;
@@ -986,6 +1042,7 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->dia_A = info->dia ? p->dia_A : 0;
   info->dia_B = info->dia ? p->dia_B : 0;
   info->dia_canon5 = info->dia && gla_dia_canon5(p) ? 1 : (info->dia && gla_dia_canon9(p) ? 9 : 0);
+  info->dia_sym = info->dia && g_tuning.sym ? p->dia_sym : 0;
   return GLA_OK;
 }
 

@@ -495,7 +495,8 @@ struct DiaView {
   int64_t row_lo, row_hi;     // rows handled by this launch
   double cval[GLA_DIA_MAX];   // CONSTV kernels: the one value of each diagonal (option "compress")
   int64_t part_off;           // reducing epilogues: this launch's row blocks write partials[part_off + block]
-};
+  int32_t partner[GLA_DIA_MAX];   // >= 0: diagonal d (offset < 0) is read from this diagonal at row r + off[d] (symmetric value
+};                                // sets, option "sym": A_ij == A_ji bit for bit, checked at gla_csr_set_values); -1: from itself
 
 template <typename T, class Epi, int DMAX, bool CONSTV = false>
 __global__ __launch_bounds__(GLA_BLOCK) void spmv_dia_kernel(DiaView dv, const T* __restrict__ x, TileMap tm, Epi epi) {
@@ -515,9 +516,16 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmv_dia_kernel(DiaView dv, const T
 #pragma unroll
   for (int d = 0; d < DMAX; ++d) {               // every lane issues every load (absent diagonals: clamped, unused)
     const int dd = min(d, dv.D - 1);
+    const int64_t c_raw = r + (int64_t)dv.off[dd];
+    const int64_t c = min(max(c_raw, (int64_t)0), dv.n_cols - 1);
     if constexpr (CONSTV) v[d] = (T)dv.cval[dd];            // constant diagonals: the stencil is matrix-free
-    else v[d] = val[(int64_t)dd * dv.n_rows + r];
-    const int64_t c = min(max(r + (int64_t)dv.off[dd], (int64_t)0), dv.n_cols - 1);
+    else {
+      // (a lower diagonal of a symmetric value set: its value is the partner's at the row this entry points to -- bytes some
+      // other lane streams anyway, so only the upper diagonals cross HBM)
+      const int sp = dv.partner[dd];
+      const T vv = val[sp >= 0 ? (int64_t)sp * dv.n_rows + c : (int64_t)dd * dv.n_rows + r];
+      v[d] = sp >= 0 && c_raw < 0 ? T(0) : vv;
+    }
     xv[d] = epi.gx(x[c], gxs);
   }
   T acc = T(0);
@@ -1190,7 +1198,11 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_fused_dia2d_kernel(Dia2D dv,
 // level underneath produces in the same line step: three lines per level in LDS (slot = line mod 3), one barrier per level
 // and line step, three ds_read2 per update.  Same arithmetic as spmv_dia_kernel + EpiJacobi: bit-identical.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int TS, bool AOS = false, bool RES = false>
+// SYM (round 4): a symmetric value set (gla_csr_set_values found A_ij == A_ji bit for bit along all four diagonal pairs; option
+// "sym") streams only the centre, E, SW, S and SE diagonals: W = E of the point before, NW / NE = SE / SW of the line above at
+// the points before / after (cache hits: those lines were streamed a line step ago), N = S of the line above (the lane's own
+// previous set).  40 instead of 72 bytes of values per row.
+template <typename T, int TS, bool AOS = false, bool RES = false, bool SYM = false>
 __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, const T* __restrict__ diag,
                                                                   const T* __restrict__ bvec, const T* __restrict__ x,
                                                                   T* __restrict__ xo, T w, int lines, int nstrips,
@@ -1229,8 +1241,21 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
     const bool live = in_i && gj >= 0 && gj < nlines && r < dv.n_rows;
     const int64_t rc = live ? r : 0;
     DiaCoef<T, 9> c;
+    if constexpr (SYM) {
 #pragma unroll
-    for (int d = 0; d < 9; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
+      for (int d = 4; d < 9; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
+      const int64_t rw_ = rc - 1, rnw = rc - dv.S - 1, rne = rc - dv.S + 1;
+      const T vw = val[5 * dv.n_rows + max(rw_, (int64_t)0)];
+      const T vnw = val[8 * dv.n_rows + max(rnw, (int64_t)0)];
+      const T vne = val[6 * dv.n_rows + max(rne, (int64_t)0)];
+      c.v[3] = rw_ >= 0 ? vw : T(0);
+      c.v[0] = rnw >= 0 ? vnw : T(0);
+      c.v[2] = rne >= 0 ? vne : T(0);
+      c.v[1] = T(0);                               // north: filled in at the set's first use
+    } else {
+#pragma unroll
+      for (int d = 0; d < 9; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
+    }
     if constexpr (AOS) {
       const int64_t ra = min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1);
       c.dg = x[ra * ldva];
@@ -1276,6 +1301,10 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
   for (int s = 1; s < NC; ++s) c[s] = c[0];
 #pragma unroll
   for (int s = 0; s < NC; ++s) cfull[s] = false;
+  if constexpr (SYM) {                             // (the set "before" the first one: its south coefficient)
+    const int64_t rp = (J0 + j_first - 1) * dv.S + gi;
+    c[NC - 1].v[7] = val[7 * dv.n_rows + min(max(rp, (int64_t)0), dv.n_rows - 1)];
+  }
 
   auto do_step = [&](const int jl, const int u, const int nact) {
     if ((jl & 1) ^ (((int)blockIdx.x / GLA_XCDS) >> 5 & 1)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);   // (priority alternation between a CU's two workgroups: gla_march5.hip)
@@ -1287,6 +1316,8 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
     rw[0][1] = xpre;                               // level 0, line jl + 1
     xpre = x0_at(jl + 2);                          // clamped / dead beyond the block: harmless, never used
     c[(u + 1) % NC] = coef_at(jl + 1);
+    if constexpr (SYM)                             // north(line jl) = south(line jl - 1); the grid's first line has none
+      c[u % NC].v[1] = J0 + jl <= 0 ? T(0) : c[(u + NC - 1) % NC].v[7];
     cfull[u % NC] = __all(c[u % NC].lv && (c[u % NC].m & 0x1ff) == 0x1ff) != 0;   // (at first use: loaded a step ago)
     if constexpr (AOS) {
       const DiaCoef<T, 9>& c0 = c[u % NC];
@@ -1345,6 +1376,11 @@ inline bool jacobi_canon(const gla_csr* A) { return g_tuning.jacobi_march && gla
 // ... and the canonical 9-point pattern of jacobi_march9_kernel (2 .. 6 sweeps per pass)
 inline bool jacobi_canon9(const gla_csr* A) { return g_tuning.jacobi_march && gla_dia_canon9(A); }
 constexpr int JACOBI_TS_MAX9 = 6;
+
+inline bool jacobi_sym9(const gla_csr* A) { return g_tuning.sym && gla_dia_canon9(A) && (A->dia_sym & 15) == 15; }
+// the SYM instances that keep two waves per SIMD (256 registers; the others are not built: those passes read all nine diagonals)
+template <typename T, int TS, bool AOS, bool RES>
+constexpr bool march9_sym_fits() { return sizeof(T) == 4 || (AOS || RES ? TS <= 4 : TS <= 5); }
 
 template <typename T, int TS, bool AOS>
 int jacobi_march9_blocks_per_cu() {
@@ -1431,7 +1467,24 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   if constexpr (TS <= JACOBI_TS_MAX9) {
     if (canon9) {                                   // the same march for the canonical 9-point pattern
       const size_t lds9 = (size_t)TS * 3 * (GLA_BLOCK + 2) * sizeof(T);
-      if (ldva > 0)
+      const bool sym9 = jacobi_sym9(A);
+      bool done = false;
+      if constexpr (march9_sym_fits<T, TS, true, false>()) {
+        if (ldva > 0 && sym9) {
+          hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, true, false, true>), grid, block, lds9, st, dv, diag, b, x, xo, w, lines,
+                             nstrips, nlines, tm, base0, split, base1, ldva, diag_out, b_out);
+          done = true;
+        }
+      }
+      if constexpr (march9_sym_fits<T, TS, false, false>()) {
+        if (!done && ldva <= 0 && sym9) {
+          hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, false, false, true>), grid, block, lds9, st, dv, diag, b, x, xo, w, lines,
+                             nstrips, nlines, tm, base0, split, base1);
+          done = true;
+        }
+      }
+      if (done) {}
+      else if (ldva > 0)
         hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, true>), grid, block, lds9, st, dv, diag, b, x, xo, w, lines, nstrips,
                            nlines, tm, base0, split, base1, ldva, diag_out, b_out);
       else
@@ -1498,9 +1551,19 @@ int launch_jacobi_fused_res(gla_csr* A, const T* diag, const T* b, const T* x, T
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   {
-    if constexpr (TS + 1 <= JACOBI_TS_MAX9)
-      hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, false, true>), grid, block, (size_t)LV * 3 * (GLA_BLOCK + 2) * sizeof(T), st, dv,
-                         diag, b, x, xo, w, lines, nstrips, nlines, tm, 0, tm.n_tiles, 0, (int64_t)1, (T*)nullptr, ro);
+    if constexpr (TS + 1 <= JACOBI_TS_MAX9) {
+      bool done = false;
+      if constexpr (march9_sym_fits<T, TS, false, true>()) {
+        if (jacobi_sym9(A)) {
+          hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, false, true, true>), grid, block, (size_t)LV * 3 * (GLA_BLOCK + 2) * sizeof(T),
+                             st, dv, diag, b, x, xo, w, lines, nstrips, nlines, tm, 0, tm.n_tiles, 0, (int64_t)1, (T*)nullptr, ro);
+          done = true;
+        }
+      }
+      if (!done)
+        hipLaunchKernelGGL((jacobi_march9_kernel<T, TS, false, true>), grid, block, (size_t)LV * 3 * (GLA_BLOCK + 2) * sizeof(T), st, dv,
+                           diag, b, x, xo, w, lines, nstrips, nlines, tm, 0, tm.n_tiles, 0, (int64_t)1, (T*)nullptr, ro);
+    }
   }
   GLA_LAUNCH_CHECK();
   return GLA_OK;
@@ -1580,6 +1643,12 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
       set_tile_mapping(bm);
       const dim3 dgrid((unsigned)(bm.tiles_per_xcd * GLA_XCDS)), dblock(GLA_BLOCK);
       for (int i = 0; i < GLA_DIA_MAX; ++i) dv.cval[i] = A->dia_cval[i];
+      for (int i = 0; i < GLA_DIA_MAX; ++i) dv.partner[i] = -1;
+      if (g_tuning.sym && d_lo == 0 && d_hi == A->n_rows && A->n_rows == A->n_cols)
+        for (int i = 0; i < A->dia_D; ++i)
+          if (A->dia_off[i] < 0 && ((A->dia_sym >> i) & 1))
+            for (int q = i + 1; q < A->dia_D; ++q)
+              if (A->dia_off[q] == -A->dia_off[i]) dv.partner[i] = q;
       if (constv && which == 0 && A->dia_D <= 5)
         hipLaunchKernelGGL((spmv_dia_kernel<T, Epi, 5, true>), dgrid, dblock, 0, st, dv, X, bm, epi);
       else if (constv && which == 0 && A->dia_D <= 9)

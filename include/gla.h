@@ -102,6 +102,9 @@ typedef struct {
   int32_t dia_A, dia_B;     /* max |a| (grid lines) and max |b| (points) of the 2-D reading */
   int32_t dia_canon5;       /* 1: the reading is the canonical 5-point pattern -S, -1, 0, +1, +S (march kernel, 2 .. 8 sweeps per
                              * pass); 9: the canonical 9-point pattern (a, b) in {-1, 0, 1}^2 (march kernel, 2 .. 6); 0: neither */
+  int32_t dia_sym;          /* bit d set: diagonal d (negative offset) repeats its partner of the opposite offset bit for bit
+                             * (A_ij == A_ji along it, checked at gla_csr_set_values) and option "sym" is on: kernels that say so
+                             * read it from the partner -- a symmetric 5-point matrix streams 3 diagonals instead of 5 */
 } gla_csr_info_t;
 int gla_csr_info(gla_csr_t plan, gla_csr_info_t* info_host);
 

@@ -34,7 +34,7 @@ def default_layout_only():
     also run as `GLA_OPTIONS=dia=0 pytest ...` etc., where they are skipped (the numerical tests all still run)."""
     import os
     opts = os.environ.get("GLA_OPTIONS", "")
-    if any(k in opts for k in ("dia=0", "col16=0", "compress=1", "jacobi_fuse=", "jacobi_march=", "jacobi_ts_max")):
+    if any(k in opts for k in ("dia=0", "col16=0", "compress=1", "jacobi_fuse=", "jacobi_march=", "jacobi_ts_max", "sym=0")):
         pytest.skip(f"layout-specific expectations; GLA_OPTIONS={opts}")
 
 
@@ -1115,6 +1115,131 @@ def test_dia_layout_bit_identical():
                             eq(a, b_)
                         else:
                             np.testing.assert_allclose(a.cpu().numpy(), b_.cpu().numpy(), rtol=1e-12, atol=1e-13)
+
+
+def _symmetric_values(ei, n, seed):
+    """Values with A_ij == A_ji bit for bit on any symmetric pattern: a deterministic function of the unordered pair (i, j)."""
+    lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+    key = (lo * n + hi + seed) % 1000003
+    return ((key * 7919) % 1000003).to(torch.float64).reshape(-1, 1) / 1000003.0 + 0.25
+
+
+def test_symmetric_value_sets_read_three_diagonals_bit_identical():
+    """Option "sym" (default on): a 5-point plan whose VALUES are symmetric (A_ij == A_ji bit for bit, checked at
+    gla_csr_set_values) is run by march kernels that read only the centre, east and south diagonals -- the west / north
+    coefficients are the east / south ones of the neighbouring rows.  Same values in the same order: bit-identical to the
+    general kernels (sym = 0), to single sweeps and to the oracle, for every pass size, with the residual level, through the
+    AoS module path, on ragged grids, in fp64 and fp32.  A value set that is not symmetric -- random values, ONE perturbed
+    entry, a -0.0 facing a +0.0, a one-sided hole -- is detected and keeps all five diagonals."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+
+    def opt(name, v):
+        check(lib().gla_set_option(name, v))
+    gen = torch.Generator().manual_seed(77)
+    for Nx, Ny in ((300, 300), (257, 41), (64, 200), (1000, 9), (50, 33)):
+        n = Nx * Ny
+        ei, _ = rp.laplacianfun_torch(Nx, Ny)
+        ev = _symmetric_values(ei, n, Nx)
+        for dtype in (torch.float64, torch.float32):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            assert plan.info.dia_canon5 == 1 and plan.info.dia_sym == 3, (Nx, Ny, plan.info.dia_sym)
+            b = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            x = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            diag = d((torch.rand(n, generator=gen, dtype=torch.float64) + 3.0).to(dtype))
+            for its in (1, 2, 3, 5, 7, 8, 13, 20):
+                got = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                xr = plan.jacobi_sweeps_residual(diag, b, x, 0.7, its) if its <= 7 else None
+                try:
+                    opt(b"sym", 0)                           # (read at launch: the general kernels from here on)
+                    want = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                    opt(b"jacobi_fuse", 0)
+                    single = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                finally:
+                    opt(b"sym", 1)
+                    opt(b"jacobi_fuse", 1)
+                eq(got, want)
+                eq(got, single)
+                if xr is not None:
+                    eq(xr[0], want)
+                    eq(xr[1], plan.residual(b, want))
+            if dtype == torch.float64 and n <= 20000:            # the module surface (AoS first pass) against the oracle
+                va = torch.cat([diag.reshape(-1, 1), b, x], 1)
+                ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+                g = torch.tensor([0.7], dtype=torch.float64)
+                eq(gla.JacobiGNN.JacobiGNN()(9, va, d(ei), d(ea), d(g)), rp.jacobi_forward(9, va.cpu(), ei, ea, g))
+    # the 9-point Q1 stiffness matrix (symmetric): march9 reads 5 of its 9 diagonals; every K = 1 stencil entry point
+    # (spmv_dia_kernel: lower diagonals from their partners) against the same plan with sym = 0
+    for cells, hs in (([71, 59], [1.0, 4.0]), ([300, 260], [1.0, 1.0])):
+        ei, ev = rp.heateqnfem2dfun(cells, hs)
+        n = (cells[0] - 1) * (cells[1] - 1)
+        for dtype in (torch.float64, torch.float32):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            assert plan.info.dia_canon5 == 9 and plan.info.dia_sym == 15, plan.info.dia_sym
+            b = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            x = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            diag = d((torch.rand(n, generator=gen, dtype=torch.float64) + 3.0).to(dtype))
+            got = {its: plan.jacobi_sweeps(diag, b, x, 0.7, its) for its in (1, 2, 3, 5, 6, 11)}
+            xr = plan.jacobi_sweeps_residual(diag, b, x, 0.7, 3)
+            y, r = plan.spmm(x), plan.residual(b, x)
+            try:
+                opt(b"sym", 0)
+                for its, g_ in got.items():
+                    eq(g_, plan.jacobi_sweeps(diag, b, x, 0.7, its))
+                if xr is not None:
+                    want3 = plan.jacobi_sweeps(diag, b, x, 0.7, 3)
+                    eq(xr[0], want3)
+                    eq(xr[1], plan.residual(b, want3))
+                eq(y, plan.spmm(x))
+                eq(r, plan.residual(b, x))
+            finally:
+                opt(b"sym", 1)
+    # value sets that are NOT symmetric keep every diagonal (and stay correct)
+    Nx = Ny = 96
+    n = Nx * Ny
+    ei, _ = rp.laplacianfun_torch(Nx, Ny)
+    sym = _symmetric_values(ei, n, 5)
+    west = ((ei[1] == ei[0] - 1).nonzero().reshape(-1))
+    north = ((ei[1] == ei[0] - Nx).nonzero().reshape(-1))
+    cases = {"random": torch.rand(ei.shape[1], 1, generator=gen, dtype=torch.float64) + 0.1}
+    one = sym.clone()
+    one[west[1234]] = one[west[1234]] * (1 + 2.0 ** -52)                 # ONE west entry, one ulp off its east partner
+    cases["one west entry off by an ulp"] = one
+    one = sym.clone()
+    one[north[77]] += 1.0
+    cases["one north entry"] = one
+    z = sym.clone()
+    e = int(west[500])
+    partner = int(((ei[0] == ei[1][e]) & (ei[1] == ei[0][e])).nonzero()[0])
+    z[e], z[partner] = -0.0, 0.0                                          # equal as numbers, not as bits
+    cases["-0.0 facing +0.0"] = z
+    expect = {"random": 0, "one west entry off by an ulp": 1, "one north entry": 2, "-0.0 facing +0.0": 1}
+    b = d(torch.rand(n, 1, generator=gen, dtype=torch.float64))
+    x = d(torch.rand(n, 1, generator=gen, dtype=torch.float64))
+    diag = d(torch.rand(n, generator=gen, dtype=torch.float64) + 3.0)
+    for name, ev in cases.items():
+        plan = gla.CsrPlan(d(ei), n)
+        plan.set_values(d(ev))
+        assert plan.info.dia_sym == expect[name], (name, plan.info.dia_sym)
+        got = plan.jacobi_sweeps(diag, b, x, 0.7, 7)
+        try:
+            opt(b"jacobi_fuse", 0)
+            eq(got, plan.jacobi_sweeps(diag, b, x, 0.7, 7))
+        finally:
+            opt(b"jacobi_fuse", 1)
+    keep = torch.ones(ei.shape[1], dtype=torch.bool)                      # a one-sided hole: (r, r - 1) present, (r - 1, r) absent
+    keep[partner] = False
+    plan = gla.CsrPlan(d(ei[:, keep]), n)
+    plan.set_values(d(sym[keep]))
+    assert plan.info.dia == 5 and (plan.info.dia_sym & 2) == 0, plan.info.dia_sym
+    got = plan.jacobi_sweeps(diag, b, x, 0.7, 6)
+    try:
+        opt(b"jacobi_fuse", 0)
+        eq(got, plan.jacobi_sweeps(diag, b, x, 0.7, 6))
+    finally:
+        opt(b"jacobi_fuse", 1)
 
 
 def test_jacobi_temporal_blocking_bit_identical():

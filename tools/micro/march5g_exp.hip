@@ -67,7 +67,7 @@ struct Coef2 {
 // strips: BW lanes wide, interior strips own the middle BW - 2 TS points (iterate t is valid t points inside the strip edge);
 // the first strip starts AT the grid's first point and the last one ends AT its last point (nothing lies beyond, so nothing
 // is invalid there): no lane is ever outside the grid when S >= BW.
-template <int TS, int HD, int PRIO = 0, int PF = 1, int ST = 0, int AL = 0>    // ST: 0 plain stores, 1 non-temporal stores, 2 no stores (diagnostic); AL: strips own 128-byte aligned ranges
+template <int TS, int HD, int PRIO = 0, int PF = 1, int ST = 0, int AL = 0, int SYM = 0>     // SYM: symmetric matrix, only the centre / east / south diagonals are read    // ST: 0 plain stores, 1 non-temporal stores, 2 no stores (diagnostic); AL: strips own 128-byte aligned ranges
 __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict__ x, double* __restrict__ xo, double w, int lines,
                                                int nstrips, int nblocks, int xcd_chunk, int tiles_per_xcd,
                                                unsigned long long* __restrict__ stamps = nullptr) {
@@ -128,8 +128,17 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
   auto coef_at = [&](int jl) -> Coef2 {
     const int64_t rc = row_clamped(jl);
     Coef2 c;
+    if constexpr (SYM) {                            // A_ij == A_ji: west = the east coefficient of the point before (the same cache
+      c.v[2] = p.val[2 * p.ldv + rc];               // lines as the east load), north = the south coefficient of the line above (this
+      c.v[3] = p.val[3 * p.ldv + rc];               // lane's previous set: filled in at first use)
+      c.v[4] = p.val[4 * p.ldv + rc];
+      const double wv = p.val[3 * p.ldv + max(rc - 1, (int64_t)0)];
+      c.v[1] = gi == 0 ? 0.0 : wv;
+      c.v[0] = 0.0;
+    } else {
 #pragma unroll
     for (int d = 0; d < 5; ++d) c.v[d] = p.val[(int64_t)d * p.ldv + rc];
+    }
     c.b = p.b[rc];
     c.dg = p.diag[rc];
     c.m = (int)p.mask[rc];
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
   for (int s = 0; s < PF; ++s) c[s] = coef_at(j_first + s);
 #pragma unroll
   for (int s = PF; s < NC; ++s) c[s] = c[0];
+  if constexpr (SYM) c[NC - 1].v[4] = p.val[4 * p.ldv + row_clamped(j_first - 1)];     // (the set "before" the first one: its south)
 #pragma unroll
   for (int s = 0; s < NC; ++s) { crc[s] = 1.0; cfast[s] = false; }
 
@@ -179,6 +189,9 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
     row_o[1] = h[0][2];
     if constexpr (PF == 1) xpre = x[row_clamped(jl + 2)];
     c[(u + PF) % NC] = coef_at(jl + PF);
+    if constexpr (SYM) {                            // north(line jl) = south(line jl - 1); the grid's first line has none
+      c[u % NC].v[0] = J0 + jl <= 0 ? 0.0 : c[(u + NC - 1) % NC].v[4];
+    }
     {
       const Coef2& cu = c[u % NC];
       const double ad = __builtin_fabs(cu.dg);
@@ -628,12 +641,12 @@ void run_kernel(Ctx& c, const std::string& name, int TS, K kern, int threads, si
   CK(hipEventDestroy(e1));
 }
 
-template <int TS, int HD, int PRIO, int PF = 1, int ST = 0, int AL = 0>
+template <int TS, int HD, int PRIO, int PF = 1, int ST = 0, int AL = 0, int SYM = 0>
 void run_v2(Ctx& c, const char* name, int lines_override = 0, int per_cu = 2) {
   char nm[100];
-  snprintf(nm, sizeof nm, "v2 hd%d prio%d pf%d wg/cu=%d%s%s", HD, PRIO, PF, per_cu, ST == 1 ? " nt-store" : ST == 2 ? " NO-STORE" : ST == 8 ? " burst8" : ST == 16 ? " burst16" : ST == 32 ? " burst32" : "", AL ? " aligned-own" : "");
+  snprintf(nm, sizeof nm, "v2 hd%d prio%d pf%d wg/cu=%d%s%s", HD, PRIO, PF, per_cu, ST == 1 ? " nt-store" : ST == 2 ? " NO-STORE" : ST == 8 ? " burst8" : ST == 16 ? " burst16" : ST == 32 ? " burst32" : "", AL ? " aligned-own" : SYM ? " SYM" : "");
   (void)name;
-  run_kernel(c, nm, TS, march5v2<TS, HD, PRIO, PF, ST, AL>, BW, (size_t)TS * 2 * (BW + 2) * 8 + (ST >= 8 ? (size_t)ST * BW * 8 : 0), per_cu, 2 * (TS - 1), lines_override, AL);
+  run_kernel(c, nm, TS, march5v2<TS, HD, PRIO, PF, ST, AL, SYM>, BW, (size_t)TS * 2 * (BW + 2) * 8 + (ST >= 8 ? (size_t)ST * BW * 8 : 0), per_cu, 2 * (TS - 1), lines_override, AL);
 }
 template <int LA, int LB, int HOIST, int PRIO, int PFA, int PFB, int DIAG = 0>
 void run_g(Ctx& c, const char* name, int lines_override = 0) {
@@ -688,6 +701,16 @@ int main(int argc, char** argv) {
     }
   }
   if (special) for (int64_t r = n / 2; r < std::min(n, n / 2 + 40 * N); ++r) { b[r] = 0.0; x[r] = (r & 1) ? -0.0 : 0.0; }
+  const int symmetric = argc > 6 ? atoi(argv[6]) : 1;   // the matrix is made symmetric: west = east of the point before, north = south of the line above
+  if (symmetric) {
+    for (int64_t r = 0; r < n; ++r) {
+      val[1 * ldv + r] = r >= 1 ? val[3 * ldv + r - 1] : 0.0;
+      val[0 * ldv + r] = r >= N ? val[4 * ldv + r - N] : 0.0;
+    }
+    for (int64_t r = 0; r < n; ++r) {                  // holes must be symmetric too: a masked-out west entry clears the partner's east
+      if (!(mask[r] & 2) && r >= 1 && r % N != 0) { val[3 * ldv + r - 1] = 0.0; mask[r - 1] &= ~8; val[1 * ldv + r] = 0.0; }
+    }
+  }
   double *d_val, *d_diag, *d_b;
   uint16_t* d_mask;
   CK(hipMalloc(&d_val, 5 * ldv * 8));
@@ -716,12 +739,11 @@ int main(int argc, char** argv) {
       continue;
     }
     run_v2<7, 2, 2>(c, "");
-    run_v2<7, 2, 2, 1, 8>(c, "");
-    run_v2<7, 2, 2, 1, 16>(c, "");
+    run_v2<7, 2, 2, 1, 0, 0, 1>(c, "");
+    run_v2<8, 0, 2, 1, 0, 0, 1>(c, "");
+    run_v2<6, 2, 2, 1, 0, 0, 1>(c, "");
     run_v2<4, 2, 2, 1, 0>(c, "");
-    run_v2<4, 2, 2, 1, 8>(c, "");
-    run_v2<4, 2, 2, 1, 16>(c, "");
-    run_v2<4, 2, 2, 1, 32>(c, "");
+    run_v2<4, 2, 2, 1, 0, 0, 1>(c, "");
   }
   for (auto& kv : c.samples) {
     auto& v = kv.second;
