@@ -805,6 +805,16 @@ def side_config5(gla, dev, m):
     return rec
 
 
+def _row_bytes(drv, blocked):
+    """Bytes a 5-point row moves per pass of a row-block driver: 8 per diagonal read (3 of the 5 where the block's value set is
+    symmetric and its passes are the temporally blocked ones: option "sym"), 2 of mask, b, A_ii, x in, x out."""
+    n_sym = 0
+    ext = getattr(drv, "ext", None)
+    if blocked and ext is not None and ext.get("plan") is not None:
+        n_sym = bin(int(ext["plan"].info.dia_sym)).count("1")
+    return 8 * (5 - n_sym) + 2 + 32
+
+
 def side_dist_vcycle(timeout_s):
     """dist_amg.RowBlockAMG's cycle driven by ONE rank over real RCCL next to AMGHierarchy.cycle on the same rows
     (tools/bench_dist_vcycle_one_rank.py, run as a child process with its own process group): every distributed level on the
@@ -930,10 +940,11 @@ def multi_gpu(args, gla, dev, world, rank):
     # bytes a rank moves per step: one pass over its block (74 B per row: values, mask, b, A_ii, x in, x out) per launch
     sched_fn = getattr(drv, "_sched", None)
     passes = len(sched_fn(args.sweeps)) if sched_fn is not None and drv.mode.startswith("temporally blocked") else args.sweeps
-    moved_sweep = (8 * 5 + 2 + 32) * pr.n_local * passes / args.sweeps
+    row_b = _row_bytes(drv, passes < args.sweeps)
+    moved_sweep = row_b * pr.n_local * passes / args.sweeps
     roof = {"bound": "hbm", "achieved": round(moved_sweep / t_sweep / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(moved_sweep / t_sweep / HBM_PEAK, 4), "traffic": None,
-            "bytes_moved_is": f"layout bytes per rank: {passes} passes of 74 B per row per {args.sweeps} sweeps",
+            "bytes_moved_is": f"layout bytes per rank: {passes} passes of {row_b} B per row per {args.sweeps} sweeps",
             "kernel": "per-rank step incl. halo exchange (interior + boundary launches), per sweep",
             "passes_per_step": passes, "algorithmic_bytes_per_sweep": pr.B,
             "model_ratio": round(pr.B / t_sweep / HBM_PEAK, 4), "avg_launch_us": round(t_sweep * 1e6 * args.sweeps / passes, 2)}
@@ -972,7 +983,7 @@ def multi_gpu(args, gla, dev, world, rank):
                "aggregate_model_equivalent_GBps": round(B4_global / t4 / 1e9, 1)}
         sf4 = getattr(d4, "_sched", None)
         ps4 = len(sf4(args.sweeps)) if sf4 is not None and d4.mode.startswith("temporally blocked") else args.sweeps
-        m4 = (8 * 5 + 2 + 32) * p4.n_local * ps4 / args.sweeps
+        m4 = _row_bytes(d4, ps4 < args.sweeps) * p4.n_local * ps4 / args.sweeps
         rec.update({"bytes_moved_GBps_per_gpu": round(m4 / t4 / 1e9, 1), "frac_per_gpu": round(m4 / t4 / HBM_PEAK, 4),
                     "passes_per_step": ps4})
         del p4, d4

@@ -401,7 +401,12 @@ class RowBlockOps:
             return
         lo, hi, n = p.row_lo, p.row_hi, p.n_global
         elo, ehi = max(0, lo - T * S), min(n, hi + T * S)                  # extended x domain
-        glo, ghi = max(0, lo - (T - 1) * S), min(n, hi + (T - 1) * S)      # rows whose matrix entries are needed
+        # Matrix rows of EVERY ghost line are fetched.  The outermost one is needed only for its x values (a pass carries at most T
+        # sweeps), but with its true rows -- cut off where they point out of the extended block, exactly like the first / last
+        # line of a grid -- the extended block is a proper stencil matrix: in particular a symmetric one where the global matrix
+        # is, so that the block's passes read the lower diagonals from their upper partners as the single-GPU plan does (option
+        # "sym"; until round 4 the outermost ghost line had no rows and the extended plan could never qualify)
+        glo, ghi = elo, ehi
         dev = edgeij_pair.device
         want = torch.cat([torch.arange(glo, lo), torch.arange(hi, ghi)])
         ev = edge_attr[:, 0] if edge_attr.dim() == 2 else edge_attr
@@ -410,7 +415,11 @@ class RowBlockOps:
         all_ei = torch.cat([g_ei[:, g_ei[0] < lo], edgeij_pair, g_ei[:, g_ei[0] >= hi]], 1)
         all_ev = torch.cat([g_ev[g_ei[0] < lo], ev.reshape(-1), g_ev[g_ei[0] >= hi]])
         inside = (all_ei[1] >= elo) & (all_ei[1] < ehi)
-        good = int(bool(inside.all()))
+        # only the outermost ghost lines may point out of the extended block; anything else is not a stencil this route handles
+        outer = (all_ei[0] < elo + S) | (all_ei[0] >= ehi - S)
+        good = int(bool((inside | outer).all()))
+        if good and not bool(inside.all()):
+            all_ei, all_ev = all_ei[:, inside], all_ev[inside]
         plan = None
         if good:
             plan = CsrPlan(all_ei - elo, ehi - elo, ehi - elo)

@@ -60,6 +60,10 @@ def _worker(rank, world, port, overlap, q):
         default_layout = not any(k in os.environ.get("GLA_OPTIONS", "") for k in ("dia=0", "compress=1", "jacobi_fuse="))
         if default_layout:                                     # (which route a block takes is a statement about the default layout)
             assert (jac.ext is not None) == (world == 2), (world, jac.ext is None)
+            if jac.ext is not None and "sym=0" not in os.environ.get("GLA_OPTIONS", ""):
+                # the extended block (own lines + ghost lines with their true rows) is a symmetric stencil matrix of its own:
+                # its passes read 3 of the 5 diagonals like the single-GPU plan
+                assert jac.ext["plan"].info.dia_sym == 3, jac.ext["plan"].info.dia_sym
         va1, va1_loc = torch.stack([diag[:, 0], B[:, 0], X[:, 0]], 1), torch.stack([diag[lo:hi, 0], B[lo:hi, 0], X[lo:hi, 0]], 1)
         for its in (1, 2, 4, 5, 7, 11):                        # 1, 2, 4, 5, 5 + 2 and 5 + 4 + 2 sweeps
             assert torch.equal(jac.forward(its, va1_loc, g), gla.JacobiGNN.JacobiGNN()(its, va1, ei, ea, g)[lo:hi]), its
@@ -79,6 +83,8 @@ def _worker(rank, world, port, overlap, q):
         jac9 = RowBlockJacobi(e9_l, v9_l.reshape(-1, 1), n9, lo9, hi9, overlap=overlap)
         if default_layout:
             assert jac9.ext is not None, "FEM blocks of >= 8 lines take the temporally blocked route"
+            if "sym=0" not in os.environ.get("GLA_OPTIONS", ""):
+                assert jac9.ext["plan"].info.dia_sym == 15, jac9.ext["plan"].info.dia_sym
         for its in (3, 5, 9):
             assert torch.equal(jac9.forward(its, va9[lo9:hi9].contiguous(), g),
                                gla.JacobiGNN.JacobiGNN()(its, va9, ei9, ea9, g)[lo9:hi9]), ("fem", its)
