@@ -49,7 +49,8 @@ enum {
 
 /* 100 * major + minor; entry points are only ever added within a major version (110: + gla_edge_attr,
  * gla_segment_stats, gla_edge_dot, gla_mlp_relu3 / gla_mlp_work_bytes; 120: + gla_comm_*, gla_halo_*, gla_dist_jacobi_sweeps,
- * gla_pmis_split). */
+ * gla_pmis_split; 130: round 3 (power / Chebyshev / dist entry points); 140: + gla_comm_probe, option "sym",
+ * gla_csr_info_t.dia_sym appended at the end of the struct). */
 int gla_version(void);
 /* Tuning knobs (process-wide): "spmv_variant" (kernel flavour for K = 1), "tile_nnz" (target nnz per row
  * tile for plans created afterwards; 0 = automatic), "compress" (1: value-dependent compression at gla_csr_set_values:
@@ -62,7 +63,13 @@ int gla_version(void);
  * partition -- are read as int32; results are bit-identical), "dia" (1, the default: when every nonzero of a
  * row-sorted matrix lies on one of <= 16 diagonals col - row -- 5-point, 9-point stencils -- the values are also kept
  * diagonal-major and the K = 1 kernels stream them with NO index stream at all, x[row + offset] being a coalesced
- * load; same products, same summation order: bit-identical), "xcd_chunk",
+ * load; same products, same summation order: bit-identical), "sym" (1, the default: gla_csr_set_values checks a full
+ * stencil plan's diagonal pairs for A_ij == A_ji BIT FOR BIT; a lower diagonal that repeats its upper partner is then not
+ * streamed by the K = 1 stencil kernels -- they read the partner's value at the row the entry points to, or keep it from the
+ * line above in registers: 3 of a symmetric 5-point matrix's 5 diagonals cross HBM; per pair, bit-identical, any other
+ * matrix keeps its diagonals; gla_csr_info_t.dia_sym), "row_sum" (1, the default: K = 1 CSR kernel, a row of 64 nonzeros or
+ * more is summed by its wave -- 64 chunks in edge order + a fixed cross-lane tree, a function of the row's own length; 0: one
+ * lane per row strictly in edge order), "xcd_chunk",
  * "spmm_variant" (A/B knobs).  The environment variable GLA_OPTIONS="name=value,name=value" sets initial values when
  * the library is loaded. */
 int gla_set_option(const char* name, int64_t value);

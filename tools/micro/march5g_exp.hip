@@ -235,6 +235,10 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
           if (t == TS) {
             if constexpr (ST == 0) { if (owner) xo[(J0 + jl - (TS - 1)) * p.S + gi] = xn; }
             else if constexpr (ST == 1) { if (owner) __builtin_nontemporal_store(xn, xo + (J0 + jl - (TS - 1)) * p.S + gi); }
+            else if constexpr (ST == 4) { if (owner) { double* q_ = xo + (J0 + jl - (TS - 1)) * p.S + gi; asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(q_), "v"(xn) : "memory"); } }
+            else if constexpr (ST == 5) { if (owner) { double* q_ = xo + (J0 + jl - (TS - 1)) * p.S + gi; asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(q_), "v"(xn) : "memory"); } }
+            else if constexpr (ST == 6) { if (owner) { double* q_ = xo + (J0 + jl - (TS - 1)) * p.S + gi; asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" :: "v"(q_), "v"(xn) : "memory"); } }
+            else if constexpr (ST == 7) { if (owner) { double* q_ = xo + (J0 + jl - (TS - 1)) * p.S + gi; asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(q_), "v"(xn) : "memory"); } }
             else if constexpr (ST >= 8) { obuf[((jl - (TS - 1)) & (ST - 1)) * BW + tid] = xn; }      // (flushed ST lines at a time, below)
             else { if (owner && xn == 1.2345e300) xo[gi] = xn; }
           }
@@ -644,7 +648,7 @@ void run_kernel(Ctx& c, const std::string& name, int TS, K kern, int threads, si
 template <int TS, int HD, int PRIO, int PF = 1, int ST = 0, int AL = 0, int SYM = 0>
 void run_v2(Ctx& c, const char* name, int lines_override = 0, int per_cu = 2) {
   char nm[100];
-  snprintf(nm, sizeof nm, "v2 hd%d prio%d pf%d wg/cu=%d%s%s", HD, PRIO, PF, per_cu, ST == 1 ? " nt-store" : ST == 2 ? " NO-STORE" : ST == 8 ? " burst8" : ST == 16 ? " burst16" : ST == 32 ? " burst32" : "", AL ? " aligned-own" : SYM ? " SYM" : "");
+  snprintf(nm, sizeof nm, "v2 hd%d prio%d pf%d wg/cu=%d%s%s", HD, PRIO, PF, per_cu, ST == 1 ? " nt-store" : ST == 2 ? " NO-STORE" : ST == 4 ? " store-sc1" : ST == 5 ? " store-sc0sc1" : ST == 6 ? " store-sc0sc1nt" : ST == 7 ? " store-sc0" : ST == 8 ? " burst8" : ST == 16 ? " burst16" : ST == 32 ? " burst32" : "", AL ? " aligned-own" : SYM ? " SYM" : "");
   (void)name;
   run_kernel(c, nm, TS, march5v2<TS, HD, PRIO, PF, ST, AL, SYM>, BW, (size_t)TS * 2 * (BW + 2) * 8 + (ST >= 8 ? (size_t)ST * BW * 8 : 0), per_cu, 2 * (TS - 1), lines_override, AL);
 }
@@ -738,12 +742,13 @@ int main(int argc, char** argv) {
       run_g<4, 3, 1, 0, 2, 1>(c, "");
       continue;
     }
-    run_v2<7, 2, 2>(c, "");
-    run_v2<7, 2, 2, 1, 0, 0, 1>(c, "");
-    run_v2<8, 0, 2, 1, 0, 0, 1>(c, "");
-    run_v2<6, 2, 2, 1, 0, 0, 1>(c, "");
-    run_v2<4, 2, 2, 1, 0>(c, "");
     run_v2<4, 2, 2, 1, 0, 0, 1>(c, "");
+    run_v2<4, 2, 2, 1, 1, 0, 1>(c, "");
+    run_v2<4, 2, 2, 1, 4, 0, 1>(c, "");
+    run_v2<4, 2, 2, 1, 5, 0, 1>(c, "");
+    run_v2<4, 2, 2, 1, 6, 0, 1>(c, "");
+    run_v2<4, 2, 2, 1, 7, 0, 1>(c, "");
+    run_v2<4, 2, 2, 1, 2, 0, 1>(c, "");
   }
   for (auto& kv : c.samples) {
     auto& v = kv.second;
