@@ -85,6 +85,8 @@ struct gla_tuning {
   int jacobi_ts_max9 = 5;   // canonical 9-point plans: most sweeps per pass (2 .. 6)
   int sym = 1;              // stencil plans whose value set is symmetric (checked bit for bit at gla_csr_set_values): the K = 1 march
                             // kernels read the lower diagonals from their upper partners (24 instead of 40 bytes of values per 5-point row)
+  int jacobi_diag_flag = 1; // gla_jacobi_sweeps_aos on 5-point march plans: 1 = no A_ii copy; the first pass flags whether A_ii repeats the matrix
+                            // diagonal, the later passes skip the A_ii stream if so (else read the AoS column); 0 = contiguous copies as before
   int jacobi_march = 1;     // canonical 5-point plans: 1 = the register-history march kernel, 0 = the generic LDS-ring kernel
   int64_t jacobi_min_rows = 1 << 19;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
                                        // is faster: 512^2 takes 4.5 us per sweep single vs 5.9 fused, 768^2 8.4 vs 6.0)
@@ -141,7 +143,9 @@ struct gla_march5_args {
   void *diag_out, *b_out;      // AoS pass: contiguous copies of A_ii and b; res: the residual
   int ghost;                   // ghost lines either end (parts 1 / 2)
   int64_t aos_off, aos_rows;
-};
+  int64_t ldd = 1;             // stride of `diag` (plain / residual passes): 1, or an AoS row stride
+  int* dg_flag = nullptr;      // AoS pass: raised where A_ii differs from the centre diagonal; plain passes: A_ii is `diag` if raised,
+};                             // the centre diagonal otherwise.  diag == nullptr (plain passes, no flag): A_ii = the centre diagonal
 // every lower diagonal of the canonical 5-point plan repeats its upper partner (and the option allows using that)
 inline bool gla_dia_sym5(const gla_csr* A) { return g_tuning.sym && gla_dia_canon5(A) && (A->dia_sym & 3) == 3; }
 int gla_march5_pass(const gla_march5_args& a);

@@ -35,11 +35,20 @@
 // line above (the lane's own previous set).  24 instead of 40 bytes of values per row; the pass is bound by its bytes
 // (profiles/r04/march5v2_what_bounds_the_pass.txt), so it takes a fifth less time.  Same values, same order: bit-identical.
 //
+// Round 4, the A_ii stream: JacobiGNN divides by the vertex attribute A_ii (JacobiGNN.py:104-119), which in every use the
+// reference makes of it IS the matrix diagonal.  dv.dg_mode says where a pass takes it from: 0 = the array `diag` (stride
+// dv.ldd: contiguous, or column 0 of the AoS vertex attributes), 1 = the plan's own centre diagonal (callers that pass
+// diag == NULL), 2 = whichever the device flag dv.dg_flag says: the AoS first pass of gla_jacobi_sweeps_aos compares the two bit
+// for bit, row by row, and raises the flag on the first difference; its later passes then either skip the A_ii stream
+// (8 of their 58 bytes per row) or read column 0 of the AoS rows.  Branch-free: the load's ADDRESS is selected (the centre
+// value is in the L1 from the row's own coefficient load), so the prefetch pattern is the same either way.
+//
 // MODE 1 (first pass of gla_jacobi_sweeps_aos): A_ii, b and x^(k) are columns 0, 1, 2 of the reference's row-major vertex
 // attribute tensor (JacobiGNN.py:104-106); the lane that owns a row leaves contiguous copies of its A_ii and b in diag_out /
 // b_out for the later passes.  MODE 2 (gla_jacobi_fused_residual): one more level forms r = b - A x^(k+TS) (-> b_out).
 #include "gla_device.h"
 
+#include <type_traits>
 #include <utility>
 
 namespace {
@@ -55,6 +64,9 @@ struct M5View {
   int32_t edge, nlb;          // multi-GPU interior / boundary split: height of the first / last line block (0: uniform), line blocks
   int64_t aos_off, aos_rows;  // MODE 1: plan row r is row r - aos_off of an AoS tensor of aos_rows rows
   int64_t aos_wlo, aos_whi;   // MODE 1: grid lines [aos_wlo, aos_whi) get their contiguous copies of A_ii and b written by this launch
+  int64_t ldd;                // MODE 0 / 2: stride of `diag` (1, or the row stride of the AoS tensor whose column 0 it points at)
+  int32_t dg_mode;            // MODE 0 / 2: A_ii from 0 `diag`, 1 the centre diagonal, 2 `diag` or the centre diagonal as *dg_flag says
+  int* dg_flag;               // MODE 1: raised when an owned row's A_ii differs from its centre coefficient; dg_mode 2: read
 };
 
 // line block lb: lines [J0, J0 + L) of the grid
@@ -114,6 +126,11 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
   m5_block(lb, lines, dv.edge, dv.nlb, dv.nlines, J0, L);
   const int tid = threadIdx.x;
   const T* __restrict__ val = static_cast<const T*>(dv.val);
+  bool dg_center = false;                          // (kernel-uniform)
+  if constexpr (!AOS) dg_center = dv.dg_mode == 1 || (dv.dg_mode == 2 && __builtin_amdgcn_readfirstlane(*dv.dg_flag) == 0);
+  // A_ii = dg_base[row * dg_ld]: the caller's array, or the plan's centre diagonal (the row's own v[2]: an L1 hit, no HBM bytes)
+  const T* const dg_base = dg_center || !diag ? val + 2 * dv.n_rows : diag;
+  const uint32_t dg_ld = dg_center || !diag ? 1u : (uint32_t)dv.ldd;
   const int64_t gi = P0 + tid;
   const bool in_i = gi < dv.S;                     // (false only on grids narrower than a strip)
   const bool owner = gi >= own_lo && gi < own_hi;
@@ -154,7 +171,10 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       const int64_t ra = min(max(rc - dv.aos_off, (int64_t)0), dv.aos_rows - 1);
       c.dg = x[ra * ldva];
       c.b = x[ra * ldva + 1];
-    } else { c.b = bvec[rc]; c.dg = diag[rc]; }
+    } else {
+      c.b = bvec[rc];
+      c.dg = dg_base[(int64_t)((uint32_t)rc * (uint64_t)dg_ld)];      // (base and stride chosen ONCE, below: see header)
+    }
     c.m = (int)dv.mask[rc];
     return c;
   };
@@ -226,8 +246,12 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       if constexpr (AOS) {                         // the row's owner leaves contiguous copies of A_ii and b
         if (jl >= 0 && jl < L && owner && live_at(jl) && gj >= dv.aos_wlo && gj < dv.aos_whi) {
           const int64_t r = gj * dv.S + gi;
-          diag_out[r] = cu.dg;
+          if (diag_out) diag_out[r] = cu.dg;
           b_out[r] = cu.b;
+          if (dv.dg_flag) {                          // does A_ii repeat the matrix diagonal?  (bit for bit; the later passes ask)
+            typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned>::type U;
+            if (__builtin_bit_cast(U, cu.dg) != __builtin_bit_cast(U, cu.v[2])) atomicOr(dv.dg_flag, 1);
+          }
         }
       }
     }
@@ -348,12 +372,14 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
 
 // Markstein division and LDS prefetch depth per level count: what fits two waves per SIMD (256 registers; the build log of
 // csrc/build.sh shows the allocation of every instance)
-template <typename T, int LV, int MODE> struct M5Cfg {
-  static constexpr bool rcp = sizeof(T) == 4 || LV <= 7;
+template <typename T, int LV, int MODE, bool SYM = false> struct M5Cfg {
+  // (the symmetric AoS pass of six sweeps is the one instance the Markstein division does not fit in 256 registers: IEEE division;
+  //  that pass is bound by its 16-24 bytes per row of writes anyway)
+  static constexpr bool rcp = sizeof(T) == 4 || (LV <= 7 && !(SYM && MODE == M5_AOS && LV == 6));
   static constexpr int hd = sizeof(T) == 4 ? 2 : (LV >= 8 || (MODE == M5_AOS && LV == 6) ? 0 : 2);
   static constexpr bool static_idx = sizeof(T) == 4 || LV >= 8;
 };
-#define M5_KERNEL(T, TS, MODE, LV, SYM) jacobi_march5_kernel<T, TS, MODE, M5Cfg<T, LV, MODE>::rcp, M5Cfg<T, LV, MODE>::hd, M5Cfg<T, LV, MODE>::static_idx, SYM>
+#define M5_KERNEL(T, TS, MODE, LV, SYM) jacobi_march5_kernel<T, TS, MODE, M5Cfg<T, LV, MODE, SYM>::rcp, M5Cfg<T, LV, MODE, SYM>::hd, M5Cfg<T, LV, MODE, SYM>::static_idx, SYM>
 
 template <typename T, int TS, int MODE, bool SYM>
 int m5_blocks_per_cu() {
@@ -382,6 +408,9 @@ int m5_launch_sym(const gla_march5_args& a) {
   dv.nlines = (A->n_rows + A->dia_S - 1) / A->dia_S;
   dv.aos_off = a.aos_off;
   dv.aos_rows = a.aos_rows >= 0 ? a.aos_rows : A->n_rows;
+  dv.ldd = a.ldd > 0 ? a.ldd : 1;
+  dv.dg_flag = a.dg_flag;
+  dv.dg_mode = MODE == M5_AOS ? 0 : (a.dg_flag ? 2 : (a.diag ? 0 : 1));
   const int64_t nlines = dv.nlines;
   // Height of the first / last line block of the multi-GPU split: ghost + LV lines keep the interior blocks off the ghost
   // lines (an interior block reads x from LV lines above its first line); at least 2 x ghost, so that the edge launch alone

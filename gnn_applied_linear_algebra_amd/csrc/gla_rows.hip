@@ -1400,7 +1400,7 @@ int jacobi_march9_blocks_per_cu() {
 template <typename T, int TS>
 int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
                         int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = TS, int64_t aos_off = 0,
-                        int64_t aos_rows = -1) {
+                        int64_t aos_rows = -1, int64_t ldd = 1, int* dg_flag = nullptr) {
   constexpr bool generic_ts = TS == 2 || TS == 4 || TS == 5;      // what jacobi_fused_dia2d_kernel is instantiated for
   const bool canon = jacobi_canon(A);
   const bool canon9 = TS <= JACOBI_TS_MAX9 && jacobi_canon9(A);
@@ -1409,9 +1409,12 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     a.A = A; a.dtype = sizeof(T) == 8 ? GLA_F64 : GLA_F32; a.ts = TS; a.res = false;
     a.diag = diag; a.b = b; a.x = x; a.xo = xo; a.w = (double)w; a.st = st; a.part = part;
     a.ldva = ldva; a.diag_out = diag_out; a.b_out = b_out; a.ghost = ghost; a.aos_off = aos_off; a.aos_rows = aos_rows;
+    a.ldd = ldd; a.dg_flag = dg_flag;
     if (part < 0 || part > 2 || ghost < TS) return GLA_ERR_INVALID_ARG;
     return gla_march5_pass(a);
   }
+  // (A_ii from the centre diagonal / a strided array / by a device flag: the 5-point march kernel only)
+  if (ldd != 1 || dg_flag || (ldva <= 0 && !diag)) return GLA_ERR_UNSUPPORTED;
   if (!canon && !canon9 && !generic_ts) return GLA_ERR_UNSUPPORTED;
   if (part < 0 || part > 2 || ghost < TS) return GLA_ERR_INVALID_ARG;
   Dia2D dv;
@@ -1587,8 +1590,20 @@ int launch_jacobi_fused_res_ts(int ts, gla_csr* A, const T* diag, const T* b, co
 template <typename T>
 int launch_jacobi_fused_ts(int ts, gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
                            int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = -1, int64_t aos_off = 0,
-                           int64_t aos_rows = -1) {
+                           int64_t aos_rows = -1, int64_t ldd = 1, int* dg_flag = nullptr) {
   if (ghost < 0) ghost = ts;
+  if (ldd != 1 || dg_flag) {                       // (rare argument combination: not threaded through the switch below)
+    switch (ts) {
+      case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
+      case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
+      case 4: return launch_jacobi_fused<T, 4>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
+      case 5: return launch_jacobi_fused<T, 5>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
+      case 6: return launch_jacobi_fused<T, 6>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
+      case 7: return launch_jacobi_fused<T, 7>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
+      case 8: return launch_jacobi_fused<T, 8>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
+      default: return GLA_ERR_UNSUPPORTED;
+    }
+  }
   switch (ts) {
     case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
     case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows);
@@ -1803,11 +1818,23 @@ int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T
                       const JacobiPlan& plan, hipStream_t st) {
   const int n_launch = jacobi_plan_launches(plan);
   const T* src = va;
+  // Canonical 5-point plans whose passes are all march passes: no contiguous copy of A_ii is made.  The first pass compares
+  // A_ii with the matrix diagonal row by row and raises a flag (the first word of diag_work) on a difference; the later passes
+  // take A_ii from the centre coefficient they load anyway -- 8 bytes per row less to read, 8 less for the first pass to write --
+  // or, flag raised, from column 0 of the AoS rows.  (The reference always passes the diagonal: JacobiGNN.py:104, VCycle.py:164.)
+  bool flagged = g_tuning.jacobi_diag_flag && jacobi_canon(A) && n_launch >= 2;
+  for (int i = 0; i < n_launch && flagged; ++i) flagged = jacobi_plan_ts(plan, i) >= 2;
+  int* const flag = reinterpret_cast<int*>(dwork);
+  if (flagged) GLA_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
   for (int i = 1; i <= n_launch; ++i) {
     T* dst = ((n_launch - i) % 2 == 0) ? Xout : Xtmp;
     const int ts = jacobi_plan_ts(plan, i - 1);
     int rc;
-    if (i == 1)                                     // reads the AoS rows, writes the contiguous A_ii / b copies
+    if (flagged && i == 1)
+      rc = launch_jacobi_fused_ts<T>(ts, A, nullptr, nullptr, va, dst, w, st, 0, ld, nullptr, bwork, -1, 0, -1, 1, flag);
+    else if (flagged)
+      rc = launch_jacobi_fused_ts<T>(ts, A, va, bwork, src, dst, w, st, 0, 0, nullptr, nullptr, -1, 0, -1, ld, flag);
+    else if (i == 1)                                // reads the AoS rows, writes the contiguous A_ii / b copies
       rc = launch_jacobi_fused_ts<T>(ts, A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
     else if (ts > 1)
       rc = launch_jacobi_fused_ts<T>(ts, A, dwork, bwork, src, dst, w, st, 0);
@@ -1929,12 +1956,13 @@ extern "C" {
 
 int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
                            int sweeps, int part, int ghost_lines, gla_stream_t stream) {
-  if (!A || !diag || !B || !X || !Xout || X == Xout || sweeps < 2 || sweeps > 8 || part < 0 || part > 2 ||
+  if (!A || !B || !X || !Xout || X == Xout || sweeps < 2 || sweeps > 8 || part < 0 || part > 2 ||
       ghost_lines < sweeps || (dtype != GLA_F32 && dtype != GLA_F64))
     return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
   if (A->n_rows == 0) return GLA_OK;
   if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A))) return GLA_ERR_UNSUPPORTED;
+  if (!diag && !jacobi_canon(A)) return GLA_ERR_INVALID_ARG;        // diag == NULL: A_ii is the plan's own centre diagonal (5-point march)
   hipStream_t st = (hipStream_t)stream;
   if (dtype == GLA_F64)
     return launch_jacobi_fused_ts<double>(sweeps, A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout,

@@ -15,12 +15,19 @@ ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=dev)
 n = N * N
 plan = gla.CsrPlan(ei, n)
 plan.set_values(ev)
-del ei
 gen = torch.Generator().manual_seed(1)
 b = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
 x = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
 diag = torch.full((n,), -4.0, dtype=torch.float64, device=dev)
-out = plan.jacobi_sweeps(diag, b, x, 0.7, 20)
+# the bench's step: JacobiGNN.forward through the module surface (AoS vertex attributes: gla_jacobi_sweeps_aos) -- the kernels and
+# operand sources (A_ii from the matrix diagonal where vertex_attr[:, 0] repeats it) of the timed steps, three steps
+va = torch.cat([diag.reshape(-1, 1), b, x], 1)
+ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+g = torch.tensor([0.7], dtype=torch.float64, device=dev)
+jac = gla.JacobiGNN.JacobiGNN()
+ei2, _ = gla.UtilsGNN.laplacianfun_torch(N, device=dev)
+for _ in range(3):
+    out = jac(20, va, ei2, ea, g)
 torch.cuda.synchronize()
 # calibration: elementwise add of two 512 MiB fp64 vectors (reads 1 GiB, writes 512 MiB, 16 B per lane)
 a = torch.rand(64 * 1024 * 1024, dtype=torch.float64, device=dev)
