@@ -168,7 +168,11 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
  * A_ii and b in diag_work / b_work [n] for the later passes (16 B per row of extra writes instead of a 48 B per row
  * split pass).  The iterate after n_iters sweeps lands in Xout; Xtmp as in gla_jacobi_sweeps.  Returns
  * GLA_ERR_UNSUPPORTED when the first launch of the schedule would not be a fused pass (plan without a 2-D stencil
- * reading, n_iters = 1, option jacobi_fuse = 0): split and use gla_jacobi_sweeps then. */
+ * reading, n_iters = 1, option jacobi_fuse = 0): split and use gla_jacobi_sweeps then.
+ * Canonical 5-point plans whose passes are all fused (option "jacobi_diag_flag", default 1): no copy of A_ii is made.  The first
+ * pass compares vertex_attr[r, 0] with the row's centre coefficient bit for bit and raises a flag (the first word of diag_work) on a
+ * difference; the later passes take A_ii from the centre coefficient they load anyway, or -- flag raised -- from column 0 of the
+ * AoS rows.  Same division either way: bit-identical.  diag_work must still hold n elements (other plans use all of it). */
 int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, void* diag_work, void* b_work,
                           void* Xout, void* Xtmp, double w, int n_iters, gla_stream_t stream);
 /* On 2-D stencil plans (diagonal layout whose offsets read as a * S + b on a grid of line length S) with one
@@ -190,7 +194,9 @@ int gla_jacobi_sweeps_schedule(gla_csr_t A, int dtype, int n_iters, int* counts4
  * grid lines of X (>= sweeps) may still be in flight while part 1 runs -- part 1 is every line block that reads none of them,
  * part 2 the first and the last line block (ghost_lines + sweeps lines high each, so that they are short; on grids of
  * fewer than 2 (ghost_lines + sweeps) + 1 lines part 1 is empty and part 2 everything).  Part 1 + part 2 write exactly what
- * part 0 writes.  gla_jacobi_fused(.., part, ..) is gla_jacobi_fused_parts with ghost_lines = sweeps. */
+ * part 0 writes.  gla_jacobi_fused(.., part, ..) is gla_jacobi_fused_parts with ghost_lines = sweeps.
+ * diag == NULL (canonical 5-point plans; GLA_ERR_INVALID_ARG elsewhere): A_ii is the plan's own centre diagonal -- what the
+ * reference always passes (JacobiGNN.py:160-170) -- and the pass streams no A_ii array. */
 int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
                            int sweeps, int part, int ghost_lines, gla_stream_t stream);
 int gla_jacobi_fused(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, double w,
