@@ -22,4 +22,8 @@ $HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $OUT
 echo "built $(realpath $OUT)"
 # Scan the code objects for the hipcc miscompile signature of profiles/r03/marchk_miscompile.txt (an exec-masked region with
 # nothing in it; 12 s).  Part of every build -- a hit fails it; GLA_ISA_CHECK=0 skips the scan.
-if [ "${GLA_ISA_CHECK:-1}" != "0" ]; then ../../tools/check_isa.sh; fi
+if [ "${GLA_ISA_CHECK:-1}" != "0" ]; then
+  ../../tools/check_isa.sh
+  # ... and the headline kernel's line steps for a wait / branch inside their load sequence (tools/check_prefetch_isa.py, 12 s)
+  python3 ../../tools/check_prefetch_isa.py gla_march5.o
+fi

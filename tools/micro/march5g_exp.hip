@@ -67,7 +67,7 @@ struct Coef2 {
 // strips: BW lanes wide, interior strips own the middle BW - 2 TS points (iterate t is valid t points inside the strip edge);
 // the first strip starts AT the grid's first point and the last one ends AT its last point (nothing lies beyond, so nothing
 // is invalid there): no lane is ever outside the grid when S >= BW.
-template <int TS, int HD, int PRIO = 0, int PF = 1, int ST = 0, int AL = 0, int SYM = 0>     // SYM: symmetric matrix, only the centre / east / south diagonals are read    // ST: 0 plain stores, 1 non-temporal stores, 2 no stores (diagnostic); AL: strips own 128-byte aligned ranges
+template <int TS, int HD, int PRIO = 0, int PF = 1, int ST = 0, int AL = 0, int SYM = 0, int ROT = 0>     // ROT: loop rotated (back edge between a step's loads and its levels); SYM: symmetric matrix, only the centre / east / south diagonals are read    // ST: 0 plain stores, 1 non-temporal stores, 2 no stores (diagnostic); AL: strips own 128-byte aligned ranges
 __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict__ x, double* __restrict__ xo, double w, int lines,
                                                int nstrips, int nblocks, int xcd_chunk, int tiles_per_xcd,
                                                unsigned long long* __restrict__ stamps = nullptr) {
@@ -169,15 +169,17 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
 #pragma unroll
   for (int s = 0; s < NC; ++s) { crc[s] = 1.0; cfast[s] = false; }
 
-  auto do_step = [&](const int jl, const int u, const int nact) {
-    __syncthreads();
+  double nl[LV], nr[LV];
+  auto do_step = [&](const int jl, const int u, const int nact, const int phase = 2) {      // phase 0: up to the set's first use; 1: the levels; 2: both
     const int pj = (jl + 64) & 1;
-    if constexpr (PRIO == 2) { if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-    if constexpr (PRIO == 3) { if (((jl + 64) >> 2 & 1) ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     double* const row_e = buf + pj * LW + tid;
     double* const row_o = buf + (1 - pj) * LW + tid;
     auto lds_row = [&](int t) -> double* { return ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LW; };   // level t - 1, line of level t
-    double nl[LV], nr[LV];
+    if (phase != 1) {
+    __syncthreads();
+    if constexpr (PRIO == 2) { if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    if constexpr (PRIO == 3) { if (((jl + 64) >> 2 & 1) ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+
 #pragma unroll
     for (int t = 1; t <= LV && t <= HD; ++t)
       if (t <= nact) { nl[t - 1] = lds_row(t)[0]; nr[t - 1] = lds_row(t)[2]; }
@@ -201,6 +203,8 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
       cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all((cu.m & 0x1f) == em && dok) != 0;
       crc[u % NC] = 1.0 / (dok ? cu.dg : 1.0);
     }
+    }
+    if (phase == 0) return;
     bool fast = true;
 #pragma unroll
     for (int t = 1; t <= LV; ++t)
@@ -289,6 +293,22 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
 #pragma unroll
   for (int s = 0; s < 2 * (LV - 1); ++s) do_step(j_first + s, s % U, (s + 2) / 2);
   constexpr int u0 = (2 * (LV - 1)) % U;
+  if constexpr (ROT) {
+    // rotated: the loop's back edge lies between a step's first use (where the load counters are in a known state on both
+    // incoming edges) and its levels -- not in front of the load sequence, where hipcc's counter merge at the loop header puts a
+    // near-complete `s_waitcnt vmcnt` into every U-th line step
+    if (LV - 1 > j_last) return;
+    do_step(LV - 1, u0, LV, 0);
+#pragma unroll 1
+    for (int jl0 = LV - 1;; jl0 += U) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        do_step(jl0 + q, (u0 + q) % U, LV, 1);
+        if (jl0 + q + 1 > j_last) return;
+        do_step(jl0 + q + 1, (u0 + q + 1) % U, LV, 0);
+      }
+    }
+  } else {
 #pragma unroll 1
   for (int jl0 = LV - 1;; jl0 += U) {
 #pragma unroll
@@ -296,6 +316,7 @@ __global__ __launch_bounds__(BW) void march5v2(Prob p, const double* __restrict_
       if (jl0 + q > j_last) return;
       do_step(jl0 + q, (u0 + q) % U, LV);
     }
+  }
   }
 }
 
@@ -645,12 +666,12 @@ void run_kernel(Ctx& c, const std::string& name, int TS, K kern, int threads, si
   CK(hipEventDestroy(e1));
 }
 
-template <int TS, int HD, int PRIO, int PF = 1, int ST = 0, int AL = 0, int SYM = 0>
+template <int TS, int HD, int PRIO, int PF = 1, int ST = 0, int AL = 0, int SYM = 0, int ROT = 0>
 void run_v2(Ctx& c, const char* name, int lines_override = 0, int per_cu = 2) {
   char nm[100];
-  snprintf(nm, sizeof nm, "v2 hd%d prio%d pf%d wg/cu=%d%s%s", HD, PRIO, PF, per_cu, ST == 1 ? " nt-store" : ST == 2 ? " NO-STORE" : ST == 4 ? " store-sc1" : ST == 5 ? " store-sc0sc1" : ST == 6 ? " store-sc0sc1nt" : ST == 7 ? " store-sc0" : ST == 8 ? " burst8" : ST == 16 ? " burst16" : ST == 32 ? " burst32" : "", AL ? " aligned-own" : SYM ? " SYM" : "");
+  snprintf(nm, sizeof nm, "v2 hd%d prio%d pf%d wg/cu=%d%s%s", HD, PRIO, PF, per_cu, ST == 1 ? " nt-store" : ST == 2 ? " NO-STORE" : ST == 4 ? " store-sc1" : ST == 5 ? " store-sc0sc1" : ST == 6 ? " store-sc0sc1nt" : ST == 7 ? " store-sc0" : ST == 8 ? " burst8" : ST == 16 ? " burst16" : ST == 32 ? " burst32" : "", AL ? " aligned-own" : SYM ? (ROT ? " SYM rotated" : " SYM") : "");
   (void)name;
-  run_kernel(c, nm, TS, march5v2<TS, HD, PRIO, PF, ST, AL, SYM>, BW, (size_t)TS * 2 * (BW + 2) * 8 + (ST >= 8 ? (size_t)ST * BW * 8 : 0), per_cu, 2 * (TS - 1), lines_override, AL);
+  run_kernel(c, nm, TS, march5v2<TS, HD, PRIO, PF, ST, AL, SYM, ROT>, BW, (size_t)TS * 2 * (BW + 2) * 8 + (ST >= 8 ? (size_t)ST * BW * 8 : 0), per_cu, 2 * (TS - 1), lines_override, AL);
 }
 template <int LA, int LB, int HOIST, int PRIO, int PFA, int PFB, int DIAG = 0>
 void run_g(Ctx& c, const char* name, int lines_override = 0) {
@@ -748,9 +769,11 @@ int main(int argc, char** argv) {
       continue;
     }
     run_v2<6, 2, 2, 1, 0, 0, 1>(c, "");
+    run_v2<6, 2, 2, 1, 0, 0, 1, 1>(c, "");
     run_v2<4, 2, 2, 1, 0, 0, 1>(c, "");
-    run_v2<7, 2, 2>(c, "");
-    run_v2<4, 2, 2, 1, 2, 0, 1>(c, "");
+    run_v2<4, 2, 2, 1, 0, 0, 1, 1>(c, "");
+    run_v2<5, 2, 2, 1, 0, 0, 1>(c, "");
+    run_v2<5, 2, 2, 1, 0, 0, 1, 1>(c, "");
   }
   for (auto& kv : c.samples) {
     auto& v = kv.second;
