@@ -23,6 +23,7 @@ constexpr int GLA_DIA_MAX = 16;
 constexpr int GLA_LONG_ROW = GLA_LDS_ELEMS_MAX - GLA_TILE_NNZ_MIN;
 // K = 1 CSR stream kernel: rows of this many nonzeros or more are summed by their wave (64 fixed chunks + xor tree; option row_sum)
 constexpr int GLA_WAVE_ROW = 64;
+constexpr int GLA_DG_SLOTS = 64;        // calls of gla_jacobi_sweeps_aos that may be in flight on ONE plan at a time (on different streams)
 
 struct gla_csr {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
@@ -53,6 +54,8 @@ struct gla_csr {
   int32_t dia_off[16] = {0};     // ascending offsets (host copy; passed to the kernels by value)
   uint16_t* dia_mask = nullptr;  // [n_rows] bit d set: row has an entry on diagonal d
   void* dia_val = nullptr;       // [dia_D][n_rows] values, diagonal-major (0 where the row has no entry)
+  int* dg_flags = nullptr;       // [GLA_DG_SLOTS] device words of gla_jacobi_sweeps_aos' "A_ii is not the matrix diagonal" flags: call k uses
+  uint32_t dg_calls = 0;         // word k mod GLA_DG_SLOTS and stores k there to raise it (never reset; guarded by dg_mutex)
   int32_t dia_sym = 0;           // bit d set: diagonal d (offset < 0) repeats its partner of offset -off bit for bit, A[r][r + off] ==
                                  // A[r + off][r] for every row (0 where r + off < 0): the kernels need not read it (option "sym")
   int32_t dia_const = 0;         // 1 (option "compress"): every diagonal holds ONE value -> no value stream either
@@ -144,6 +147,7 @@ struct gla_march5_args {
   int ghost;                   // ghost lines either end (parts 1 / 2)
   int64_t aos_off, aos_rows;
   int64_t ldd = 1;             // stride of `diag` (plain / residual passes): 1, or an AoS row stride
+  int dg_epoch = 0;            // the call's number: `*dg_flag == dg_epoch` means raised in this call
   int* dg_flag = nullptr;      // AoS pass: raised where A_ii differs from the centre diagonal; plain passes: A_ii is `diag` if raised,
 };                             // the centre diagonal otherwise.  diag == nullptr (plain passes, no flag): A_ii = the centre diagonal
 // every lower diagonal of the canonical 5-point plan repeats its upper partner (and the option allows using that)

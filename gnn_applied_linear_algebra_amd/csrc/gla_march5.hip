@@ -39,7 +39,7 @@
 // reference makes of it IS the matrix diagonal.  dv.dg_mode says where a pass takes it from: 0 = the array `diag` (stride
 // dv.ldd: contiguous, or column 0 of the AoS vertex attributes), 1 = the plan's own centre diagonal (callers that pass
 // diag == NULL), 2 = whichever the device flag dv.dg_flag says: the AoS first pass of gla_jacobi_sweeps_aos compares the two bit
-// for bit, row by row, and raises the flag on the first difference; its later passes then either skip the A_ii stream
+// for bit, row by row, and raises the flag on a difference (it stores the call's number: flags are never reset); its later passes then either skip the A_ii stream
 // (8 of their 58 bytes per row) or read column 0 of the AoS rows.  Branch-free: the load's ADDRESS is selected (the centre
 // value is in the L1 from the row's own coefficient load), so the prefetch pattern is the same either way.
 //
@@ -66,7 +66,8 @@ struct M5View {
   int64_t aos_wlo, aos_whi;   // MODE 1: grid lines [aos_wlo, aos_whi) get their contiguous copies of A_ii and b written by this launch
   int64_t ldd;                // MODE 0 / 2: stride of `diag` (1, or the row stride of the AoS tensor whose column 0 it points at)
   int32_t dg_mode;            // MODE 0 / 2: A_ii from 0 `diag`, 1 the centre diagonal, 2 `diag` or the centre diagonal as *dg_flag says
-  int* dg_flag;               // MODE 1: raised when an owned row's A_ii differs from its centre coefficient; dg_mode 2: read
+  int* dg_flag;               // MODE 1: set to dg_epoch when an owned row's A_ii differs from its centre coefficient; dg_mode 2: read
+  int32_t dg_epoch;           // this call's number (> 0): a flag word equal to it means "raised in THIS call" -- nobody has to reset it
 };
 
 // line block lb: lines [J0, J0 + L) of the grid
@@ -126,8 +127,9 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
   m5_block(lb, lines, dv.edge, dv.nlb, dv.nlines, J0, L);
   const int tid = threadIdx.x;
   const T* __restrict__ val = static_cast<const T*>(dv.val);
+  bool dg_raised = false;                          // (wave-uniform: this wave has raised the A_ii flag already)
   bool dg_center = false;                          // (kernel-uniform)
-  if constexpr (!AOS) dg_center = dv.dg_mode == 1 || (dv.dg_mode == 2 && __builtin_amdgcn_readfirstlane(*dv.dg_flag) == 0);
+  if constexpr (!AOS) dg_center = dv.dg_mode == 1 || (dv.dg_mode == 2 && __builtin_amdgcn_readfirstlane(*dv.dg_flag) != dv.dg_epoch);
   // A_ii = dg_base[row * dg_ld]: the caller's array, or the plan's centre diagonal (the row's own v[2]: an L1 hit, no HBM bytes)
   const T* const dg_base = dg_center || !diag ? val + 2 * dv.n_rows : diag;
   const uint32_t dg_ld = dg_center || !diag ? 1u : (uint32_t)dv.ldd;
@@ -244,14 +246,19 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       }
       cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all((cu.m & 0x1f) == em && dok) != 0;
       if constexpr (AOS) {                         // the row's owner leaves contiguous copies of A_ii and b
+        bool dg_mis = false;
         if (jl >= 0 && jl < L && owner && live_at(jl) && gj >= dv.aos_wlo && gj < dv.aos_whi) {
           const int64_t r = gj * dv.S + gi;
           if (diag_out) diag_out[r] = cu.dg;
           b_out[r] = cu.b;
           if (dv.dg_flag) {                          // does A_ii repeat the matrix diagonal?  (bit for bit; the later passes ask)
             typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned>::type U;
-            if (__builtin_bit_cast(U, cu.dg) != __builtin_bit_cast(U, cu.v[2])) atomicOr(dv.dg_flag, 1);
+            dg_mis = __builtin_bit_cast(U, cu.dg) != __builtin_bit_cast(U, cu.v[2]);
           }
+        }
+        if (!dg_raised && __any(dg_mis)) {           // (one atomic per WAVE and launch at most, whatever the number of rows that differ)
+          if ((tid & 63) == 0) atomicExch(dv.dg_flag, dv.dg_epoch);
+          dg_raised = true;
         }
       }
     }
@@ -410,6 +417,7 @@ int m5_launch_sym(const gla_march5_args& a) {
   dv.aos_rows = a.aos_rows >= 0 ? a.aos_rows : A->n_rows;
   dv.ldd = a.ldd > 0 ? a.ldd : 1;
   dv.dg_flag = a.dg_flag;
+  dv.dg_epoch = a.dg_epoch;
   dv.dg_mode = MODE == M5_AOS ? 0 : (a.dg_flag ? 2 : (a.diag ? 0 : 1));
   const int64_t nlines = dv.nlines;
   // Height of the first / last line block of the multi-GPU split: ghost + LV lines keep the interior blocks off the ghost

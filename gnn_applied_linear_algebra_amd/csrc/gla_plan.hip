@@ -857,6 +857,7 @@ int gla_csr_destroy(gla_csr_t p) {
   if (p->rowoff16) (void)hipFree(p->rowoff16);
   if (p->dia_mask) (void)hipFree(p->dia_mask);
   if (p->dia_val) (void)hipFree(p->dia_val);
+  if (p->dg_flags) (void)hipFree(p->dg_flags);
   if (p->vcode) (void)hipFree(p->vcode);
   if (p->vdict) (void)hipFree(p->vdict);
   delete p;

@@ -21,6 +21,8 @@
 // are (row, rhs) pairs so that every gather reads K contiguous values of one X row.
 #include "gla_device.h"
 
+#include <mutex>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -1400,7 +1402,7 @@ int jacobi_march9_blocks_per_cu() {
 template <typename T, int TS>
 int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
                         int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = TS, int64_t aos_off = 0,
-                        int64_t aos_rows = -1, int64_t ldd = 1, int* dg_flag = nullptr) {
+                        int64_t aos_rows = -1, int64_t ldd = 1, int* dg_flag = nullptr, int dg_epoch = 0) {
   constexpr bool generic_ts = TS == 2 || TS == 4 || TS == 5;      // what jacobi_fused_dia2d_kernel is instantiated for
   const bool canon = jacobi_canon(A);
   const bool canon9 = TS <= JACOBI_TS_MAX9 && jacobi_canon9(A);
@@ -1409,7 +1411,7 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     a.A = A; a.dtype = sizeof(T) == 8 ? GLA_F64 : GLA_F32; a.ts = TS; a.res = false;
     a.diag = diag; a.b = b; a.x = x; a.xo = xo; a.w = (double)w; a.st = st; a.part = part;
     a.ldva = ldva; a.diag_out = diag_out; a.b_out = b_out; a.ghost = ghost; a.aos_off = aos_off; a.aos_rows = aos_rows;
-    a.ldd = ldd; a.dg_flag = dg_flag;
+    a.ldd = ldd; a.dg_flag = dg_flag; a.dg_epoch = dg_epoch;
     if (part < 0 || part > 2 || ghost < TS) return GLA_ERR_INVALID_ARG;
     return gla_march5_pass(a);
   }
@@ -1590,17 +1592,17 @@ int launch_jacobi_fused_res_ts(int ts, gla_csr* A, const T* diag, const T* b, co
 template <typename T>
 int launch_jacobi_fused_ts(int ts, gla_csr* A, const T* diag, const T* b, const T* x, T* xo, T w, hipStream_t st, int part = 0,
                            int64_t ldva = 0, T* diag_out = nullptr, T* b_out = nullptr, int ghost = -1, int64_t aos_off = 0,
-                           int64_t aos_rows = -1, int64_t ldd = 1, int* dg_flag = nullptr) {
+                           int64_t aos_rows = -1, int64_t ldd = 1, int* dg_flag = nullptr, int dg_epoch = 0) {
   if (ghost < 0) ghost = ts;
   if (ldd != 1 || dg_flag) {                       // (rare argument combination: not threaded through the switch below)
     switch (ts) {
-      case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
-      case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
-      case 4: return launch_jacobi_fused<T, 4>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
-      case 5: return launch_jacobi_fused<T, 5>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
-      case 6: return launch_jacobi_fused<T, 6>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
-      case 7: return launch_jacobi_fused<T, 7>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
-      case 8: return launch_jacobi_fused<T, 8>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag);
+      case 2: return launch_jacobi_fused<T, 2>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag, dg_epoch);
+      case 3: return launch_jacobi_fused<T, 3>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag, dg_epoch);
+      case 4: return launch_jacobi_fused<T, 4>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag, dg_epoch);
+      case 5: return launch_jacobi_fused<T, 5>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag, dg_epoch);
+      case 6: return launch_jacobi_fused<T, 6>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag, dg_epoch);
+      case 7: return launch_jacobi_fused<T, 7>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag, dg_epoch);
+      case 8: return launch_jacobi_fused<T, 8>(A, diag, b, x, xo, w, st, part, ldva, diag_out, b_out, ghost, aos_off, aos_rows, ldd, dg_flag, dg_epoch);
       default: return GLA_ERR_UNSUPPORTED;
     }
   }
@@ -1821,19 +1823,37 @@ int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T
   // Canonical 5-point plans whose passes are all march passes: no contiguous copy of A_ii is made.  The first pass compares
   // A_ii with the matrix diagonal row by row and raises a flag (the first word of diag_work) on a difference; the later passes
   // take A_ii from the centre coefficient they load anyway -- 8 bytes per row less to read, 8 less for the first pass to write --
-  // or, flag raised, from column 0 of the AoS rows.  (The reference always passes the diagonal: JacobiGNN.py:104, VCycle.py:164.)
+  // or, flag raised, from column 0 of the AoS rows.  (diag_work is not touched in this flow.)  (The reference always passes the diagonal: JacobiGNN.py:104, VCycle.py:164.)
   bool flagged = g_tuning.jacobi_diag_flag && jacobi_canon(A) && n_launch >= 2;
   for (int i = 0; i < n_launch && flagged; ++i) flagged = jacobi_plan_ts(plan, i) >= 2;
-  int* const flag = reinterpret_cast<int*>(dwork);
-  if (flagged) GLA_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
+  int* flag = nullptr;
+  int epoch = 0;
+  if (flagged) {
+    // The flag lives in the plan (GLA_DG_SLOTS words, zero when allocated): call number k uses word k mod GLA_DG_SLOTS and stores
+    // k into it to raise it, so no word ever has to be reset -- a memset in front of every call was 15-19 us of launch gap per step
+    static std::mutex dg_mutex;
+    std::lock_guard<std::mutex> lock(dg_mutex);
+    if (!A->dg_flags) {
+      GLA_HIP_CHECK(hipMalloc(&A->dg_flags, GLA_DG_SLOTS * sizeof(int)));
+      GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, GLA_DG_SLOTS * sizeof(int)));
+    }
+    if (++A->dg_calls >= 0x7fffff00u) {               // (wrap-around after 2^31 calls: start over with clean words)
+      GLA_HIP_CHECK(hipDeviceSynchronize());
+      GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, GLA_DG_SLOTS * sizeof(int)));
+      A->dg_calls = 1;
+    }
+    epoch = (int)A->dg_calls;
+    flag = A->dg_flags + (A->dg_calls % GLA_DG_SLOTS);
+  }
+  (void)dwork;
   for (int i = 1; i <= n_launch; ++i) {
     T* dst = ((n_launch - i) % 2 == 0) ? Xout : Xtmp;
     const int ts = jacobi_plan_ts(plan, i - 1);
     int rc;
     if (flagged && i == 1)
-      rc = launch_jacobi_fused_ts<T>(ts, A, nullptr, nullptr, va, dst, w, st, 0, ld, nullptr, bwork, -1, 0, -1, 1, flag);
+      rc = launch_jacobi_fused_ts<T>(ts, A, nullptr, nullptr, va, dst, w, st, 0, ld, nullptr, bwork, -1, 0, -1, 1, flag, epoch);
     else if (flagged)
-      rc = launch_jacobi_fused_ts<T>(ts, A, va, bwork, src, dst, w, st, 0, 0, nullptr, nullptr, -1, 0, -1, ld, flag);
+      rc = launch_jacobi_fused_ts<T>(ts, A, va, bwork, src, dst, w, st, 0, 0, nullptr, nullptr, -1, 0, -1, ld, flag, epoch);
     else if (i == 1)                                // reads the AoS rows, writes the contiguous A_ii / b copies
       rc = launch_jacobi_fused_ts<T>(ts, A, nullptr, nullptr, va, dst, w, st, 0, ld, dwork, bwork);
     else if (ts > 1)

@@ -170,9 +170,10 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
  * GLA_ERR_UNSUPPORTED when the first launch of the schedule would not be a fused pass (plan without a 2-D stencil
  * reading, n_iters = 1, option jacobi_fuse = 0): split and use gla_jacobi_sweeps then.
  * Canonical 5-point plans whose passes are all fused (option "jacobi_diag_flag", default 1): no copy of A_ii is made.  The first
- * pass compares vertex_attr[r, 0] with the row's centre coefficient bit for bit and raises a flag (the first word of diag_work) on a
- * difference; the later passes take A_ii from the centre coefficient they load anyway, or -- flag raised -- from column 0 of the
- * AoS rows.  Same division either way: bit-identical.  diag_work must still hold n elements (other plans use all of it). */
+ * pass compares vertex_attr[r, 0] with the row's centre coefficient bit for bit and raises a plan-owned flag on a difference; the
+ * later passes take A_ii from the centre coefficient they load anyway, or -- flag raised -- from column 0 of the AoS rows.  Same
+ * division either way: bit-identical.  diag_work must still hold n elements (other plans use all of it).  Up to 64 calls may be
+ * in flight on ONE plan at a time on different streams (calls on one stream are ordered anyway). */
 int gla_jacobi_sweeps_aos(gla_csr_t A, int dtype, const void* vertex_attr, int64_t ld, void* diag_work, void* b_work,
                           void* Xout, void* Xtmp, double w, int n_iters, gla_stream_t stream);
 /* On 2-D stencil plans (diagonal layout whose offsets read as a * S + b on a grid of line length S) with one
