@@ -1815,6 +1815,8 @@ inline int jacobi_plan_ts(const JacobiPlan& p, int i) {      // sweeps of launch
   return 1;
 }
 
+std::mutex g_dg_mutex;                               // guards every plan's dg_flags / dg_calls (taken once per gla_jacobi_sweeps_aos call)
+
 template <typename T>
 int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T* Xout, T* Xtmp, T w,
                       const JacobiPlan& plan, hipStream_t st) {
@@ -1831,8 +1833,7 @@ int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T
   if (flagged) {
     // The flag lives in the plan (GLA_DG_SLOTS words, zero when allocated): call number k uses word k mod GLA_DG_SLOTS and stores
     // k into it to raise it, so no word ever has to be reset -- a memset in front of every call was 15-19 us of launch gap per step
-    static std::mutex dg_mutex;
-    std::lock_guard<std::mutex> lock(dg_mutex);
+    std::lock_guard<std::mutex> lock(g_dg_mutex);
     if (!A->dg_flags) {
       GLA_HIP_CHECK(hipMalloc(&A->dg_flags, GLA_DG_SLOTS * sizeof(int)));
       GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, GLA_DG_SLOTS * sizeof(int)));
