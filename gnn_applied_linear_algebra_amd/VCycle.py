@@ -225,6 +225,11 @@ class AMGHierarchy:
     lambda from the power-method GNN, or coarse_solver="dense" (the coarsest operator factored once and its inverse applied
     per cycle, for hierarchies deep enough that it is small).  splitting: None (every other vertex), "pmis" (pmis_splitting) or a callable."""
 
+    # The smoothers' A_ii is the diagonal this class extracts from each level's matrix (`diags`): the march passes are told so
+    # and take it from the centre coefficient they load anyway (plan.jacobi_sweeps(..., diag_is_matrix_diagonal=True)).
+    # False: stream the extracted vector like any caller's (A/B, tests).
+    _diag_from_matrix = True
+
     def __init__(self, A, levels=3, theta_=0.25, cheb_deg_=4, splitting=None, w=0.7, n_pre=3, n_post=3,
                  coarse_bounds=None, coarse_sweeps=1, min_coarse=0, coarse_deg=None,
                  coarse_kappa=100.0, coarse_solver="cheby"):
@@ -338,7 +343,9 @@ class AMGHierarchy:
     def _smooth(self, level, n_it, b, x):
         """n_it weighted-Jacobi sweeps (JacobiGNN on the level's plan; w is cast to the operand dtype like g[0])."""
         w = float(torch.tensor(self.w, dtype=b.dtype))
-        return self.plans[level].jacobi_sweeps(self.diags[level], b.contiguous(), x.contiguous(), w, n_it)
+        # (self.diags[level] was extracted from the level's matrix: the march passes are told so and stream no A_ii)
+        return self.plans[level].jacobi_sweeps(self.diags[level], b.contiguous(), x.contiguous(), w, n_it,
+                                               diag_is_matrix_diagonal=self._diag_from_matrix)
 
     def capture_cycle(self, n_rhs=1, dtype=torch.float64):
         """Capture one V-cycle into a HIP graph (torch.cuda.CUDAGraph) and return run(b, x) -> x_new.
@@ -383,7 +390,8 @@ class AMGHierarchy:
         # pre-smoothing and the residual of its result: one pass over the level's matrix where the plan qualifies
         # (gla_jacobi_fused_residual; same arithmetic as the two calls, bit for bit)
         w = float(torch.tensor(self.w, dtype=b.dtype))
-        xr = self.plans[level].jacobi_sweeps_residual(self.diags[level], b.contiguous(), x.contiguous(), w, self.n_pre) \
+        xr = self.plans[level].jacobi_sweeps_residual(self.diags[level], b.contiguous(), x.contiguous(), w, self.n_pre,
+                                                      diag_is_matrix_diagonal=self._diag_from_matrix) \
             if (b.dim() == 2 and b.shape[1] == 1) else None
         if xr is not None:
             x, r = xr

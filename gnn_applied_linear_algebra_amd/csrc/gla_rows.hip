@@ -1228,6 +1228,9 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
   march_block(lb, lines, dv.nbi, dv.nbj, nlines, J0, L);
   const int tid = threadIdx.x;
   const T* __restrict__ val = static_cast<const T*>(dv.val);
+  // A_ii: the caller's array, or (diag == NULL: "A_ii is the matrix diagonal", as in every use the reference makes of JacobiGNN)
+  // the plan's own centre diagonal -- the row's v[4], an L1 hit: no A_ii stream
+  const T* const dg_base = diag ? diag : val + 4 * dv.n_rows;
   const int64_t gi = P0 + tid;
   const bool in_i = gi >= 0 && gi < dv.S;
   const bool owner = tid >= halo && tid < BW - halo;
@@ -1263,7 +1266,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void jacobi_march9_kernel(Dia2D dv, cons
       c.dg = x[ra * ldva];
       c.b = x[ra * ldva + 1];
     }
-    else { c.b = bvec[rc]; c.dg = diag[rc]; }
+    else { c.b = bvec[rc]; c.dg = dg_base[rc]; }
     c.m = (int)dv.mask[rc];
     c.lv = live;
     return c;
@@ -1416,7 +1419,7 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     return gla_march5_pass(a);
   }
   // (A_ii from the centre diagonal / a strided array / by a device flag: the 5-point march kernel only)
-  if (ldd != 1 || dg_flag || (ldva <= 0 && !diag)) return GLA_ERR_UNSUPPORTED;
+  if (ldd != 1 || dg_flag || (ldva <= 0 && !diag && !canon9)) return GLA_ERR_UNSUPPORTED;
   if (!canon && !canon9 && !generic_ts) return GLA_ERR_UNSUPPORTED;
   if (part < 0 || part > 2 || ghost < TS) return GLA_ERR_INVALID_ARG;
   Dia2D dv;
@@ -1983,7 +1986,8 @@ int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void*
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
   if (A->n_rows == 0) return GLA_OK;
   if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A))) return GLA_ERR_UNSUPPORTED;
-  if (!diag && !jacobi_canon(A)) return GLA_ERR_INVALID_ARG;        // diag == NULL: A_ii is the plan's own centre diagonal (5-point march)
+  // diag == NULL: A_ii is the plan's own centre diagonal (the 5- / 9-point march kernels)
+  if (!diag && !jacobi_canon(A) && !(jacobi_canon9(A) && sweeps <= JACOBI_TS_MAX9)) return GLA_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == GLA_F64)
     return launch_jacobi_fused_ts<double>(sweeps, A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout,
@@ -1994,7 +1998,7 @@ int gla_jacobi_fused_parts(gla_csr_t A, int dtype, const void* diag, const void*
 
 int gla_jacobi_fused_residual(gla_csr_t A, int dtype, const void* diag, const void* B, const void* X, void* Xout, void* Rout,
                               double w, int sweeps, gla_stream_t stream) {
-  if (!A || !diag || !B || !X || !Xout || !Rout || X == Xout || Xout == Rout || X == Rout || sweeps < 1 ||
+  if (!A || !B || !X || !Xout || !Rout || X == Xout || Xout == Rout || X == Rout || sweeps < 1 ||
       (dtype != GLA_F32 && dtype != GLA_F64))
     return GLA_ERR_INVALID_ARG;
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
@@ -2002,6 +2006,7 @@ int gla_jacobi_fused_residual(gla_csr_t A, int dtype, const void* diag, const vo
   if (A->n_rows < g_tuning.jacobi_min_rows || g_tuning.jacobi_fuse != 1 ||
       !(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A)))
     return GLA_ERR_UNSUPPORTED;
+  if (!diag && !jacobi_canon(A) && !jacobi_canon9(A)) return GLA_ERR_INVALID_ARG;      // (diag == NULL: the march kernels only)
   hipStream_t st = (hipStream_t)stream;
   if (dtype == GLA_F64)
     return launch_jacobi_fused_res_ts<double>(sweeps, A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout,
@@ -2067,7 +2072,14 @@ int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const voi
   // blocked kernels (the intermediate iterates stay on chip; jacobi_schedule); what is left over runs as an ordinary sweep.
   // Same arithmetic per row: bit-identical.  Option "jacobi_fuse": 0 off, 1 (default), 2 at most two per pass.
   JacobiPlan plan;
-  jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && diag && B && X0, n_iters, plan);
+  // diag == NULL ("A_ii is the matrix diagonal": the march kernels then take it from the centre coefficient, no A_ii stream):
+  // single right-hand side on canonical 5- / 9-point plans whose schedule is march passes only
+  const bool dg_null_ok = !diag && K == 1 && A->n_rows > 0 && (jacobi_canon(A) || jacobi_canon9(A));
+  if (!diag && A->n_rows > 0 && !dg_null_ok) return GLA_ERR_INVALID_ARG;
+  jacobi_schedule(A, dtype, K == 1 && ldb == 1 && ldx0 == 1 && ldw == 1 && (diag || dg_null_ok) && B && X0, n_iters, plan);
+  if (!diag && A->n_rows > 0)
+    for (int i = 0; i < jacobi_plan_launches(plan); ++i)
+      if (jacobi_plan_ts(plan, i) < 2) return GLA_ERR_INVALID_ARG;
   // K right-hand sides on canonical 5- / 9-point plans: passes of up to GLA_JACOBIK_TS_MAX sweeps (jacobi_marchk_kernel,
   // gla_jacobik.hip), ceil(n / 4) (9-point: n / 3) passes of equal size +- 1; anything it declines keeps one sweep per launch
   if (K > 1 && n_iters >= 2) {

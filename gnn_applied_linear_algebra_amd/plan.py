@@ -195,8 +195,17 @@ class CsrPlan:
                                      ptr(Xout), ldxo, float(w), which, stream_ptr(self.device)))
         return Xout
 
+    def _diag_from_matrix(self, K, n_iters, dtype, contiguous):
+        """The caller vouches that its `diag` IS this plan's matrix diagonal (an AMG hierarchy extracts it from the matrix): on
+        canonical 5- / 9-point plans whose schedule for n_iters is march passes only the library is then told diag = NULL and the
+        passes take A_ii from the centre coefficient they load anyway (no A_ii stream; same division, bit-identical)."""
+        if K != 1 or not contiguous or int(self.info.dia_canon5) not in (1, 9):
+            return False
+        sched = self.jacobi_schedule(int(n_iters), dtype)
+        return len(sched) > 0 and min(sched) >= 2
+
     @_on_device
-    def jacobi_sweeps(self, diag, B, X0, w, n_iters):
+    def jacobi_sweeps(self, diag, B, X0, w, n_iters, diag_is_matrix_diagonal=False):
         """n_iters fused sweeps; returns a new [n, K] tensor, X0 untouched (JacobiGNN.py:138-148)."""
         assert self.n_rows == self.n_cols
         X0, K, ldx0 = _dense(X0, self.n_cols, "X0")
@@ -208,7 +217,8 @@ class CsrPlan:
             return X0.clone()
         Xout = torch.empty((self.n_rows, K), dtype=X0.dtype, device=self.device)
         Xtmp = torch.empty_like(Xout) if n_iters > 1 else None
-        check(lib().gla_jacobi_sweeps(self._h, dtype_code(X0.dtype), K, ptr(diag), ptr(B), ldb, ptr(X0), ldx0,
+        no_stream = diag_is_matrix_diagonal and self._diag_from_matrix(K, n_iters, X0.dtype, ldb == 1 and ldx0 == 1)
+        check(lib().gla_jacobi_sweeps(self._h, dtype_code(X0.dtype), K, None if no_stream else ptr(diag), ptr(B), ldb, ptr(X0), ldx0,
                                       ptr(Xout), ptr(Xtmp), K, float(w), int(n_iters), stream_ptr(self.device)))
         return Xout
 
@@ -232,7 +242,7 @@ class CsrPlan:
         return Xout
 
     @_on_device
-    def jacobi_sweeps_residual(self, diag, B, X0, w, n_iters):
+    def jacobi_sweeps_residual(self, diag, B, X0, w, n_iters, diag_is_matrix_diagonal=False):
         """(x after n_iters sweeps, r = B - A x) with the residual formed inside the last temporally blocked pass
         (gla_jacobi_fused_residual), or None when the plan / count does not qualify (the caller runs jacobi_sweeps and
         residual).  Single contiguous rhs."""
@@ -253,12 +263,12 @@ class CsrPlan:
             return None
         x = X0
         if n_iters > last:                                   # the earlier passes of the schedule as usual
-            x = self.jacobi_sweeps(diag, B, X0, w, n_iters - last)
+            x = self.jacobi_sweeps(diag, B, X0, w, n_iters - last, diag_is_matrix_diagonal=diag_is_matrix_diagonal)
         Xout = torch.empty((self.n_rows, 1), dtype=X0.dtype, device=self.device)
         R = torch.empty_like(Xout)
         try:
-            check(lib().gla_jacobi_fused_residual(self._h, dtype_code(X0.dtype), ptr(diag), ptr(B), ptr(x), ptr(Xout), ptr(R),
-                                                  float(w), last, stream_ptr(self.device)))
+            check(lib().gla_jacobi_fused_residual(self._h, dtype_code(X0.dtype), None if diag_is_matrix_diagonal else ptr(diag),
+                                                  ptr(B), ptr(x), ptr(Xout), ptr(R), float(w), last, stream_ptr(self.device)))
         except GlaError as err:
             if err.code == -5:                               # GLA_ERR_UNSUPPORTED (small matrix, options)
                 return None

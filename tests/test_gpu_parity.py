@@ -1301,6 +1301,52 @@ def test_jacobi_module_path_takes_a_ii_from_the_matrix_diagonal_when_it_is_the_d
         eq(out, plan.jacobi_sweeps(d(centre), b, x, 0.7, ts))
 
 
+def test_vcycle_smoothers_take_a_ii_from_the_matrix_diagonal():
+    """AMGHierarchy extracts each level's A_ii from the level's matrix, so its march passes are told diag = NULL ("A_ii is the
+    matrix diagonal": no A_ii stream, 5- and 9-point march kernels, with and without the residual level).  Bit-identical to the
+    same cycle with the extracted vector streamed (AMGHierarchy._diag_from_matrix = False), on the FEM mesh (9-point) and the
+    Laplacian (5-point), and through the plan entry points for every pass size."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+    V = gla.VCycle
+    gen = torch.Generator().manual_seed(17)
+    check(lib().gla_set_option(b"jacobi_min_rows", 0))        # (the session fixture may already have: march passes on small levels)
+    try:
+        for kind in ("fem", "laplacian"):
+            m = 95
+            if kind == "fem":
+                ei, ev = gla.UtilsGNN.heateqnfem2dfun([m + 1, m + 1], [1.0, 2.0], device=DEV)
+            else:
+                ei, ev = gla.UtilsGNN.laplacianfun_torch(m, device=DEV)
+                ev = -ev
+            n = m * m
+            A = V._as_sparse(ei, ev, (n, n))
+            H = V.AMGHierarchy(A, levels=3, splitting=V.GridSplitting(m, m), coarse_solver="dense")
+            b = d(torch.rand(n, 1, generator=gen, dtype=torch.float64))
+            x1, x0 = torch.zeros_like(b), torch.zeros_like(b)
+            for _ in range(3):
+                x1 = H.cycle(b, x1)
+                try:
+                    V.AMGHierarchy._diag_from_matrix = False
+                    x0 = H.cycle(b, x0)
+                finally:
+                    V.AMGHierarchy._diag_from_matrix = True
+                eq(x1, x0)
+            plan, dg = H.plans[0], H.diags[0]
+            x = d(torch.rand(n, 1, generator=gen, dtype=torch.float64))
+            for its in (2, 3, 5, 6, 7, 11):
+                eq(plan.jacobi_sweeps(dg, b, x, 0.7, its, diag_is_matrix_diagonal=True), plan.jacobi_sweeps(dg, b, x, 0.7, its))
+            for its in (1, 2, 3, 4):
+                a_ = plan.jacobi_sweeps_residual(dg, b, x, 0.7, its, diag_is_matrix_diagonal=True)
+                b_ = plan.jacobi_sweeps_residual(dg, b, x, 0.7, its)
+                assert (a_ is None) == (b_ is None)
+                if a_ is not None:
+                    eq(a_[0], b_[0])
+                    eq(a_[1], b_[1])
+    finally:
+        check(lib().gla_set_option(b"jacobi_min_rows", 0))
+
+
 def test_jacobi_temporal_blocking_bit_identical():
     """gla_jacobi_sweeps on 2-D stencil plans takes several sweeps per pass (temporal blocking: the intermediate iterates
     stay on chip, the matrix is read once per pass): 2 .. 8 on the canonical 5-point pattern (jacobi_march5_kernel), 5 / 4 /
