@@ -438,10 +438,12 @@ def single_gpu(args, gla, dev):
     # (symmetric value sets, option "sym": the march kernel reads the lower diagonals from their upper partners -- 3 of a 5-point
     # matrix's 5 diagonals cross HBM)
     n_sym = bin(int(info.dia_sym)).count("1") if (march and int(info.dia_canon5) == 1) else 0
-    row_bytes = 8 * (int(info.dia) - n_sym) + 2 + 32 - (8 if dg_center else 0)
+    no_mask = bool(n_sym and int(getattr(info, "dia_full", 0)))          # (every row has the mask of its grid position: not read)
+    row_bytes = 8 * (int(info.dia) - n_sym) + (0 if no_mask else 2) + 32 - (8 if dg_center else 0)
     if int(info.dia) > 0 and not bool(info.packed):
         layout_name = (f"dia{int(info.dia)}" + (f", symmetric: {int(info.dia) - n_sym} diagonals read" if n_sym else "")
                        + (", A_ii = the centre coefficient (no A_ii stream)" if dg_center else "")
+                       + (", no row masks (every row has its grid neighbours)" if no_mask else "")
                        + (f", {spl} sweeps per pass" if fused else ""))
         Bl = row_bytes * pr.n_local
     elif args.compress and bool(info.packed):
@@ -464,7 +466,7 @@ def single_gpu(args, gla, dev):
     tp = os.path.join(ROOT, "profiles", "traffic_jacobi.json")
     if traffic is None and os.path.exists(tp):
         tj = json.load(open(tp))
-        if tj.get("n") == args.n and int(tj.get("dia", 0)) == int(info.dia) and int(tj.get("dia_sym", 0)) == n_sym and bool(tj.get("a_ii_from_centre", False)) == dg_center and not bool(info.packed) \
+        if tj.get("n") == args.n and int(tj.get("dia", 0)) == int(info.dia) and int(tj.get("dia_sym", 0)) == n_sym and bool(tj.get("a_ii_from_centre", False)) == dg_center and bool(tj.get("no_mask", False)) == no_mask and not bool(info.packed) \
                 and int(tj.get("sweeps_per_launch", 1)) == spl and (fused or int(tj.get("col16", 0)) == int(info.col16)):
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = "profiles/traffic_jacobi.json: PMC passes of an EARLIER run of this kernel and layout, not re-measured now"
@@ -857,11 +859,13 @@ def side_config5(gla, dev, m):
 def _row_bytes(drv, blocked):
     """Bytes a 5-point row moves per pass of a row-block driver: 8 per diagonal read (3 of the 5 where the block's value set is
     symmetric and its passes are the temporally blocked ones: option "sym"), 2 of mask, b, A_ii, x in, x out."""
-    n_sym = 0
+    n_sym, mask_b = 0, 2
     ext = getattr(drv, "ext", None)
     if blocked and ext is not None and ext.get("plan") is not None:
         n_sym = bin(int(ext["plan"].info.dia_sym)).count("1")
-    return 8 * (5 - n_sym) + 2 + 32
+        if n_sym and int(getattr(ext["plan"].info, "dia_full", 0)):
+            mask_b = 0
+    return 8 * (5 - n_sym) + mask_b + 32
 
 
 def side_dist_vcycle(timeout_s):

@@ -28,7 +28,7 @@ class CsrInfo(ctypes.Structure):
                 ("col16", ctypes.c_int32), ("col16_wide_tiles", ctypes.c_int32), ("dia", ctypes.c_int32),
                 ("dia_stride", ctypes.c_int32), ("dia_row_lo", ctypes.c_int64), ("dia_row_hi", ctypes.c_int64),
                 ("dia_A", ctypes.c_int32), ("dia_B", ctypes.c_int32), ("dia_canon5", ctypes.c_int32),
-                ("dia_sym", ctypes.c_int32)]
+                ("dia_sym", ctypes.c_int32), ("dia_full", ctypes.c_int32)]
 
 
 _P = ctypes.c_void_p

@@ -8,9 +8,9 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-result"
 OUT=../libgla_hip.so
 pids=()
-SRCS="gla_rows gla_march5 gla_powerk gla_edges gla_plan gla_sparse gla_mlp gla_dist gla_cheby gla_jacobik"
+SRCS="gla_rows gla_march5 gla_march5_f32 gla_powerk gla_edges gla_plan gla_sparse gla_mlp gla_dist gla_cheby gla_jacobik"
 for f in $SRCS; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gla_internal.h -nt $f.o ] || [ gla_device.h -nt $f.o ] || [ ../../include/gla.h -nt $f.o ]; then
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || { [ $f = gla_march5_f32 ] && [ gla_march5.hip -nt $f.o ]; } || [ gla_internal.h -nt $f.o ] || [ gla_device.h -nt $f.o ] || [ ../../include/gla.h -nt $f.o ]; then
     rm -f $f.o                                   # a failed compile must not leave a stale object behind
     $HIPCC $FLAGS -c $f.hip -o $f.o &
     pids+=($!)

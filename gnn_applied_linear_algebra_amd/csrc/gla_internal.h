@@ -58,6 +58,8 @@ struct gla_csr {
   uint32_t dg_calls = 0;         // word k mod GLA_DG_SLOTS and stores k there to raise it (never reset; guarded by dg_mutex)
   int32_t dia_sym = 0;           // bit d set: diagonal d (offset < 0) repeats its partner of offset -off bit for bit, A[r][r + off] ==
                                  // A[r + off][r] for every row (0 where r + off < 0): the kernels need not read it (option "sym")
+  int32_t dia_full = 0;          // canonical 5-point plans: 1 = EVERY row couples to every grid neighbour it has (its mask is the one its
+                                 // position implies): structure only, checked at plan creation; the march kernel then reads no masks
   int32_t dia_const = 0;         // 1 (option "compress"): every diagonal holds ONE value -> no value stream either
   double dia_cval[16] = {0};     // that value per diagonal
   int64_t dia_row_lo = 0, dia_row_hi = 0;   // rows [lo, hi) fit the diagonal set (halo rows of a row block do not)
@@ -88,6 +90,8 @@ struct gla_tuning {
   int jacobi_ts_max9 = 5;   // canonical 9-point plans: most sweeps per pass (2 .. 6)
   int sym = 1;              // stencil plans whose value set is symmetric (checked bit for bit at gla_csr_set_values): the K = 1 march
                             // kernels read the lower diagonals from their upper partners (24 instead of 40 bytes of values per 5-point row)
+  int full_mask = 1;        // canonical 5-point plans whose every row has the mask of its grid position (dia_full): the symmetric march passes
+                            // do not read the 2-byte row masks (0: they do)
   int jacobi_diag_flag = 1; // gla_jacobi_sweeps_aos on 5-point march plans: 1 = no A_ii copy; the first pass flags whether A_ii repeats the matrix
                             // diagonal, the later passes skip the A_ii stream if so (else read the AoS column); 0 = contiguous copies as before
   int jacobi_march = 1;     // canonical 5-point plans: 1 = the register-history march kernel, 0 = the generic LDS-ring kernel
@@ -152,6 +156,8 @@ struct gla_march5_args {
 };                             // the centre diagonal otherwise.  diag == nullptr (plain passes, no flag): A_ii = the centre diagonal
 // every lower diagonal of the canonical 5-point plan repeats its upper partner (and the option allows using that)
 inline bool gla_dia_sym5(const gla_csr* A) { return g_tuning.sym && gla_dia_canon5(A) && (A->dia_sym & 3) == 3; }
+// ... and no row lacks a neighbour its grid position has (and the option allows using that): no mask stream
+inline bool gla_dia_full5(const gla_csr* A) { return g_tuning.full_mask && gla_dia_canon5(A) && A->dia_full == 1; }
 int gla_march5_pass(const gla_march5_args& a);
 // GLA_OK iff gla_jacobi_fused_parts(_aos) would run `sweeps` sweeps on this canonical 5-point plan with these value types
 // (gla_rows.hip); otherwise the status it would return.  For callers that must know BEFORE they enqueue anything (gla_dist.hip).

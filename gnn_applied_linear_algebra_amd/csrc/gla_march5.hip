@@ -98,7 +98,7 @@ struct M5Coef {               // one row's matrix data
 
 constexpr int M5_PLAIN = 0, M5_AOS = 1, M5_RES = 2;
 
-template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM>
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM>
 __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, const T* __restrict__ diag,
                                                                      const T* __restrict__ bvec, const T* __restrict__ x,
                                                                      T* __restrict__ xo, T w, int lines, int nstrips, TileMap tm,
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       c.b = bvec[rc];
       c.dg = dg_base[(int64_t)((uint32_t)rc * (uint64_t)dg_ld)];      // (base and stride chosen ONCE, below: see header)
     }
-    c.m = (int)dv.mask[rc];
+    if constexpr (FM) c.m = 0;                      // (every row has the mask of its position: gla_csr.dia_full; not read)
+    else c.m = (int)dv.mask[rc];
     return c;
   };
 
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
         dok = ad >= Lim::dlo && ad <= Lim::dhi && !Lim::all_ones(cu.dg);
         crc[u % NC] = T(1) / (dok ? cu.dg : T(1));
       }
-      cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all((cu.m & 0x1f) == em && dok) != 0;
+      if constexpr (FM) { (void)em; cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all(dok) != 0; }
+      else cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all((cu.m & 0x1f) == em && dok) != 0;
       if constexpr (AOS) {                         // the row's owner leaves contiguous copies of A_ii and b
         bool dg_mis = false;
         if (jl >= 0 && jl < L && owner && live_at(jl) && gj >= dv.aos_wlo && gj < dv.aos_whi) {
@@ -386,16 +388,16 @@ template <typename T, int LV, int MODE, bool SYM = false> struct M5Cfg {
   static constexpr int hd = sizeof(T) == 4 ? 2 : (LV >= 8 || (MODE == M5_AOS && LV == 6) ? 0 : 2);
   static constexpr bool static_idx = sizeof(T) == 4 || LV >= 8;
 };
-#define M5_KERNEL(T, TS, MODE, LV, SYM) jacobi_march5_kernel<T, TS, MODE, M5Cfg<T, LV, MODE, SYM>::rcp, M5Cfg<T, LV, MODE, SYM>::hd, M5Cfg<T, LV, MODE, SYM>::static_idx, SYM>
+#define M5_KERNEL(T, TS, MODE, LV, SYM, FM) jacobi_march5_kernel<T, TS, MODE, M5Cfg<T, LV, MODE, SYM>::rcp, M5Cfg<T, LV, MODE, SYM>::hd, M5Cfg<T, LV, MODE, SYM>::static_idx, SYM, FM>
 
-template <typename T, int TS, int MODE, bool SYM>
+template <typename T, int TS, int MODE, bool SYM, bool FM>
 int m5_blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     constexpr int LV = TS + (MODE == M5_RES ? 1 : 0);
     int nb = 0;
     const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, M5_KERNEL(T, TS, MODE, LV, SYM), GLA_BLOCK, lds) != hipSuccess || nb < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, M5_KERNEL(T, TS, MODE, LV, SYM, FM), GLA_BLOCK, lds) != hipSuccess || nb < 1) {
       (void)hipGetLastError();
       nb = 2;
     }
@@ -404,7 +406,7 @@ int m5_blocks_per_cu() {
   return cached;
 }
 
-template <typename T, int TS, int MODE, bool SYM>
+template <typename T, int TS, int MODE, bool SYM, bool FM>
 int m5_launch_sym(const gla_march5_args& a) {
   gla_csr* A = a.A;
   constexpr int LV = TS + (MODE == M5_RES ? 1 : 0);
@@ -445,7 +447,7 @@ int m5_launch_sym(const gla_march5_args& a) {
     // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (LV - 1) coefficient
     // lines) for which all workgroups are resident at once.  Measured (tools/ab_jacobi_march.py): two workgroups per CU beat
     // three or four even where the registers allow more -- fewer, longer streams; one per CU cannot hide a line step
-    int per_cu = m5_blocks_per_cu<T, TS, MODE, SYM>();
+    int per_cu = m5_blocks_per_cu<T, TS, MODE, SYM, FM>();
     if (per_cu > 2) per_cu = 2;
     // Interior / boundary split: the interior launch leaves 2 x nstrips workgroup slots FREE for the two edge line blocks that
     // a second stream launches once the ghost lines are in.  A march workgroup takes half a CU's registers, so on a chip full
@@ -473,7 +475,7 @@ int m5_launch_sym(const gla_march5_args& a) {
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
-  hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV, SYM)), grid, block, lds, a.st, dv,
+  hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV, SYM, FM)), grid, block, lds, a.st, dv,
                      (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1,
                      a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out);
   GLA_LAUNCH_CHECK();
@@ -482,7 +484,12 @@ int m5_launch_sym(const gla_march5_args& a) {
 
 template <typename T, int TS, int MODE>
 int m5_launch(const gla_march5_args& a) {
-  return gla_dia_sym5(a.A) ? m5_launch_sym<T, TS, MODE, true>(a) : m5_launch_sym<T, TS, MODE, false>(a);
+  if (!gla_dia_sym5(a.A)) return m5_launch_sym<T, TS, MODE, false, false>(a);
+  // (the no-mask instances exist for the symmetric layout only: a plan whose values are not symmetric keeps its masks as well)
+  // (... and for up to seven levels: hipcc spills the eight-level no-mask instance, 205 registers of it)
+  constexpr bool fm_fits = TS + (MODE == M5_RES ? 1 : 0) <= 7;
+  if constexpr (fm_fits) { if (gla_dia_full5(a.A)) return m5_launch_sym<T, TS, MODE, true, true>(a); }
+  return m5_launch_sym<T, TS, MODE, true, false>(a);
 }
 
 template <typename T, int MODE>
@@ -504,14 +511,24 @@ int m5_dispatch_ts(const gla_march5_args& a) {
 
 // `ts` sweeps (2 .. 8; with res: 1 .. 7 sweeps + the residual) of the canonical 5-point plan A in one pass.  The caller
 // (gla_rows.hip) has checked the plan (jacobi_fused_ok + gla_dia_canon5) and the operands.
+// Two translation units (the instances take minutes to compile): this file holds the fp64 instances and the entry point,
+// gla_march5_f32.hip includes it with GLA_M5_F32_TU defined and holds the fp32 ones.
+#ifdef GLA_M5_F32_TU
+int gla_march5_pass_f32(const gla_march5_args& a) {
+  if (a.res) return m5_dispatch_ts<float, M5_RES>(a);
+  if (a.ldva > 0) return m5_dispatch_ts<float, M5_AOS>(a);
+  return m5_dispatch_ts<float, M5_PLAIN>(a);
+}
+#else
+int gla_march5_pass_f32(const gla_march5_args& a);
 int gla_march5_pass(const gla_march5_args& a) {
   if (!a.A || !gla_dia_canon5(a.A) || a.part < 0 || a.part > 2) return GLA_ERR_UNSUPPORTED;
   const int lv = a.ts + (a.res ? 1 : 0);
   if (a.ghost < lv && a.part != 0) return GLA_ERR_INVALID_ARG;
-  if (a.res) {
-    if (a.ldva > 0 || a.part != 0) return GLA_ERR_UNSUPPORTED;
-    return a.dtype == GLA_F64 ? m5_dispatch_ts<double, M5_RES>(a) : m5_dispatch_ts<float, M5_RES>(a);
-  }
-  if (a.ldva > 0) return a.dtype == GLA_F64 ? m5_dispatch_ts<double, M5_AOS>(a) : m5_dispatch_ts<float, M5_AOS>(a);
-  return a.dtype == GLA_F64 ? m5_dispatch_ts<double, M5_PLAIN>(a) : m5_dispatch_ts<float, M5_PLAIN>(a);
+  if (a.res && (a.ldva > 0 || a.part != 0)) return GLA_ERR_UNSUPPORTED;
+  if (a.dtype != GLA_F64) return gla_march5_pass_f32(a);
+  if (a.res) return m5_dispatch_ts<double, M5_RES>(a);
+  if (a.ldva > 0) return m5_dispatch_ts<double, M5_AOS>(a);
+  return m5_dispatch_ts<double, M5_PLAIN>(a);
 }
+#endif

@@ -435,6 +435,22 @@ __global__ __launch_bounds__(GLA_BLOCK) void dia_wrap_kernel(const uint16_t* __r
   if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(wraps, 1);
 }
 
+// Canonical 5-point reading, grid lines of S points: does EVERY row hold exactly the entries its grid position implies (north
+// unless on the first line, west unless first in its line, the centre, east unless last in its line, south unless the row S
+// further does not exist)?  The mask jacobi_march5_kernel expects of a row that takes its unmasked path; structure only.
+__global__ __launch_bounds__(GLA_BLOCK) void dia_full5_kernel(const uint16_t* __restrict__ mask, int64_t n_rows, int64_t S,
+                                                              int* __restrict__ broken) {
+  int bad = 0;
+  const int64_t nfull = n_rows / S, tail = n_rows - nfull * S;
+  for (int64_t r = (int64_t)blockIdx.x * GLA_BLOCK + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GLA_BLOCK) {
+    const int64_t gj = r / S, gi = r - gj * S;
+    const bool has_down = gj + 1 < nfull || (gj + 1 == nfull && gi < tail);
+    const unsigned em = 31u & ~(gi == 0 ? 2u : 0u) & ~(gi == S - 1 ? 8u : 0u) & ~(gj == 0 ? 1u : 0u) & ~(has_down ? 0u : 16u);
+    if ((unsigned)mask[r] != em) bad = 1;
+  }
+  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(broken, 1);
+}
+
 // Structure side, at plan creation: does every nonzero lie on one of <= 16 diagonals, rows in ascending order?
 int build_dia(gla_csr* p, hipStream_t st) {
   p->dia_state = -1;
@@ -521,6 +537,19 @@ int build_dia(gla_csr* p, hipStream_t st) {
       }
     }
     (void)hipFree(d_wrap);
+  }
+  p->dia_full = 0;
+  if (gla_dia_canon5(p) && p->dia_nowrap && p->dia_row_lo == 0 && p->dia_row_hi == p->n_rows && p->n_rows == p->n_cols) {
+    int* d_broken = nullptr;
+    int h_broken = 1;
+    DK(hipMalloc(&d_broken, sizeof(int)));
+    DK(hipMemsetAsync(d_broken, 0, sizeof(int), st));
+    hipLaunchKernelGGL(dia_full5_kernel, dim3(grid_for(p->n_rows)), dim3(GLA_BLOCK), 0, st, p->dia_mask, p->n_rows,
+                       (int64_t)p->dia_S, d_broken);
+    DK(hipMemcpyAsync(&h_broken, d_broken, sizeof(int), hipMemcpyDeviceToHost, st));
+    DK(hipStreamSynchronize(st));
+    (void)hipFree(d_broken);
+    p->dia_full = h_broken ? 0 : 1;
   }
   return GLA_OK;
 #undef DK
@@ -785,6 +814,7 @@ int gla_set_option(const char* name, int64_t value) {
   if (!strcmp(name, "dia")) { g_tuning.dia = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "sym")) { g_tuning.sym = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "jacobi_diag_flag")) { g_tuning.jacobi_diag_flag = value ? 1 : 0; return GLA_OK; }
+  if (!strcmp(name, "full_mask")) { g_tuning.full_mask = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "row_sum")) { g_tuning.row_sum = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "jacobi_fuse")) { if (value < 0 || value > 2) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_fuse = (int)value; return GLA_OK; }
   if (!strcmp(name, "jacobi_min_rows")) { if (value < 0) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_min_rows = value; return GLA_OK; }
@@ -1045,6 +1075,7 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->dia_B = info->dia ? p->dia_B : 0;
   info->dia_canon5 = info->dia && gla_dia_canon5(p) ? 1 : (info->dia && gla_dia_canon9(p) ? 9 : 0);
   info->dia_sym = info->dia && g_tuning.sym ? p->dia_sym : 0;
+  info->dia_full = info->dia && gla_dia_full5(p) ? 1 : 0;
   return GLA_OK;
 }
 

@@ -50,7 +50,7 @@ enum {
 /* 100 * major + minor; entry points are only ever added within a major version (110: + gla_edge_attr,
  * gla_segment_stats, gla_edge_dot, gla_mlp_relu3 / gla_mlp_work_bytes; 120: + gla_comm_*, gla_halo_*, gla_dist_jacobi_sweeps,
  * gla_pmis_split; 130: round 3 (power / Chebyshev / dist entry points); 140: + gla_comm_probe, option "sym",
- * gla_csr_info_t.dia_sym appended at the end of the struct). */
+ * gla_csr_info_t.dia_sym and .dia_full appended at the end of the struct). */
 int gla_version(void);
 /* Tuning knobs (process-wide): "spmv_variant" (kernel flavour for K = 1), "tile_nnz" (target nnz per row
  * tile for plans created afterwards; 0 = automatic), "compress" (1: value-dependent compression at gla_csr_set_values:
@@ -67,7 +67,9 @@ int gla_version(void);
  * stencil plan's diagonal pairs for A_ij == A_ji BIT FOR BIT; a lower diagonal that repeats its upper partner is then not
  * streamed by the K = 1 stencil kernels -- they read the partner's value at the row the entry points to, or keep it from the
  * line above in registers: 3 of a symmetric 5-point matrix's 5 diagonals cross HBM; per pair, bit-identical, any other
- * matrix keeps its diagonals; gla_csr_info_t.dia_sym), "row_sum" (1, the default: K = 1 CSR kernel, a row of 64 nonzeros or
+ * matrix keeps its diagonals; gla_csr_info_t.dia_sym), "full_mask" (1, the default: on a canonical 5-point plan whose every row
+ * has all the neighbours its grid position has -- gla_csr_info_t.dia_full, structure only -- the symmetric march passes skip the
+ * 2-byte row masks), "row_sum" (1, the default: K = 1 CSR kernel, a row of 64 nonzeros or
  * more is summed by its wave -- 64 chunks in edge order + a fixed cross-lane tree, a function of the row's own length; 0: one
  * lane per row strictly in edge order), "xcd_chunk",
  * "spmm_variant" (A/B knobs).  The environment variable GLA_OPTIONS="name=value,name=value" sets initial values when
@@ -112,6 +114,8 @@ typedef struct {
   int32_t dia_sym;          /* bit d set: diagonal d (negative offset) repeats its partner of the opposite offset bit for bit
                              * (A_ij == A_ji along it, checked at gla_csr_set_values) and option "sym" is on: kernels that say so
                              * read it from the partner -- a symmetric 5-point matrix streams 3 diagonals instead of 5 */
+  int32_t dia_full;         /* 1: canonical 5-point plan in which every row couples to every grid neighbour it has (structure only,
+                             * checked at plan creation) and option "full_mask" is on: the symmetric march passes read no row masks */
 } gla_csr_info_t;
 int gla_csr_info(gla_csr_t plan, gla_csr_info_t* info_host);
 

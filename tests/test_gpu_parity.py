@@ -1124,6 +1124,64 @@ def _symmetric_values(ei, n, seed):
     return ((key * 7919) % 1000003).to(torch.float64).reshape(-1, 1) / 1000003.0 + 0.25
 
 
+def test_rows_with_all_their_grid_neighbours_read_no_masks_bit_identical():
+    """Structure flag dia_full (set at plan creation, option "full_mask"): on a canonical 5-point plan in which every row has
+    exactly the entries its grid position implies the symmetric march passes do not load the 2-byte row masks.  Same
+    arithmetic: bit-identical to the same plan with full_mask = 0, with sym = 0 and to single sweeps, every pass size, the
+    residual level, the AoS module path, fp64 / fp32.  ONE missing pair of entries (a symmetric hole) or a ragged last line
+    clears the flag; such plans keep their masks and still match."""
+    default_layout_only()
+    from gnn_applied_linear_algebra_amd._lib import lib, check
+
+    def opt(name, v):
+        check(lib().gla_set_option(name, v))
+    gen = torch.Generator().manual_seed(78)
+    for Nx, Ny, hole, cut in ((300, 300, False, 0), (257, 41, False, 0), (300, 120, True, 0), (280, 50, False, 37)):
+        n = Nx * Ny - cut
+        ei, _ = rp.laplacianfun_torch(Nx, Ny)
+        if cut:                                             # a ragged last line: the first n rows / columns of the grid's matrix
+            keep = (ei[0] < n) & (ei[1] < n)
+            ei = ei[:, keep]
+        if hole:                                            # the entries (r, r + 1) and (r + 1, r) of one interior row are missing
+            r = (Ny // 2) * Nx + Nx // 3
+            keep = ~(((ei[0] == r) & (ei[1] == r + 1)) | ((ei[0] == r + 1) & (ei[1] == r)))
+            ei = ei[:, keep]
+        ev = _symmetric_values(ei, n, Nx)
+        for dtype in (torch.float64, torch.float32):
+            plan = gla.CsrPlan(d(ei), n)
+            plan.set_values(d(ev.to(dtype)))
+            assert plan.info.dia_canon5 == 1 and plan.info.dia_sym == 3, (Nx, Ny, plan.info.dia_sym)
+            assert plan.info.dia_full == (0 if (hole or cut) else 1), (Nx, Ny, hole, cut, plan.info.dia_full)
+            b = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            x = d(torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dtype))
+            diag = d((torch.rand(n, generator=gen, dtype=torch.float64) + 3.0).to(dtype))
+            for its in (2, 3, 6, 7, 8, 20):
+                got = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                xr = plan.jacobi_sweeps_residual(diag, b, x, 0.7, its) if its <= 7 else None
+                try:
+                    opt(b"full_mask", 0)
+                    masked = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                    opt(b"sym", 0)
+                    want = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                    opt(b"jacobi_fuse", 0)
+                    single = plan.jacobi_sweeps(diag, b, x, 0.7, its)
+                finally:
+                    opt(b"full_mask", 1)
+                    opt(b"sym", 1)
+                    opt(b"jacobi_fuse", 1)
+                eq(got, masked)
+                eq(got, want)
+                eq(got, single)
+                if xr is not None:
+                    eq(xr[0], want)
+                    eq(xr[1], plan.residual(b, want))
+            if dtype == torch.float64:                       # the module surface (AoS first pass) against the oracle
+                va = torch.cat([diag.reshape(-1, 1), b, x], 1)
+                ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+                g = torch.tensor([0.7], dtype=torch.float64)
+                eq(gla.JacobiGNN.JacobiGNN()(9, va, d(ei), d(ea), d(g)), rp.jacobi_forward(9, va.cpu(), ei, ea, g))
+
+
 def test_symmetric_value_sets_read_three_diagonals_bit_identical():
     """Option "sym" (default on): a 5-point plan whose VALUES are symmetric (A_ij == A_ji bit for bit, checked at
     gla_csr_set_values) is run by march kernels that read only the centre, east and south diagonals -- the west / north

@@ -12,9 +12,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = os.environ.get("OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
-KERNELS = [  # mangled-name fragments: <double, TS, MODE 0, RCP, HD, STATIC, SYM>
-    "jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1E", "jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb0E",
-    "jacobi_march5_kernelIdLi6ELi0ELb1ELi2ELb0ELb1E",
+KERNELS = [  # (mangled-name fragment <double, TS, MODE 0, RCP, HD, STATIC, SYM, FM>, 8-byte loads of a line step's own prefetch: x, b, A_ii, the diagonals read)
+    ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1ELb1E", 7), ("jacobi_march5_kernelIdLi6ELi0ELb1ELi2ELb0ELb1ELb1E", 7),
+    ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1ELb0E", 7), ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb0ELb0E", 8),
 ]
 
 
@@ -29,7 +29,7 @@ def disassemble(obj):
     return subprocess.run([OBJDUMP, "-d", os.path.join(tmp, co[0])], check=True, capture_output=True, text=True).stdout
 
 
-def check(text, frag):
+def check(text, frag, nloads):
     m = re.search(r"^[0-9a-f]+ <([^>]*%s[^>]*)>:\n" % re.escape(frag), text, re.M)
     if not m:
         return f"{frag}: kernel not found"
@@ -51,10 +51,10 @@ def check(text, frag):
     bad, n_steps = {}, 0
     for k, sg in enumerate(segs[len(segs) // 2:-1], len(segs) // 2):      # the steady-state line steps (unrolled over the sets)
         loads = [i for i, o in enumerate(sg) if o[0].startswith("global_load_dwordx2")]
-        if len(loads) < 7:
+        if len(loads) < nloads:
             continue
         n_steps += 1
-        head = loads[:8]                                      # the step's own prefetch (later loads belong to the rare generic path)
+        head = loads[:nloads]                                      # the step's own prefetch (later loads belong to the rare generic path)
         for i in range(head[0], head[-1]):
             o = sg[i]
             if (o[0] == "s_waitcnt" and any(a.startswith("vmcnt") for a in o[1:])) or o[0].startswith("s_cbranch"):
@@ -69,7 +69,7 @@ def check(text, frag):
 def main():
     obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gnn_applied_linear_algebra_amd", "csrc", "gla_march5.o")
     text = disassemble(obj)
-    errs = [e for e in (check(text, k) for k in KERNELS) if e]
+    errs = [e for e in (check(text, k, nl) for k, nl in KERNELS) if e]
     for e in errs:
         print(e)
     print(f"{os.path.basename(obj)}: {len(KERNELS) - len(errs)} of {len(KERNELS)} march kernels issue their line-step loads back to back")
