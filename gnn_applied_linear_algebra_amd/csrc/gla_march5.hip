@@ -98,12 +98,13 @@ struct M5Coef {               // one row's matrix data
 
 constexpr int M5_PLAIN = 0, M5_AOS = 1, M5_RES = 2;
 
-template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM>
-__global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, const T* __restrict__ diag,
-                                                                     const T* __restrict__ bvec, const T* __restrict__ x,
-                                                                     T* __restrict__ xo, T w, int lines, int nstrips, TileMap tm,
-                                                                     int tile_base0, int tile_split, int tile_base1, int64_t ldva,
-                                                                     T* __restrict__ diag_out, T* __restrict__ b_out) {
+// The pass (one workgroup's line block).  DGC: A_ii IS the row's centre coefficient -- neither loaded nor kept (12 registers per
+// coefficient set instead of 17, one load less per line step).
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, bool DGC>
+__device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ diag, const T* __restrict__ bvec,
+                                        const T* __restrict__ x, T* __restrict__ xo, T w, int lines, int nstrips, const TileMap& tm,
+                                        int tile_base0, int tile_split, int tile_base1, int64_t ldva, T* __restrict__ diag_out,
+                                        T* __restrict__ b_out) {
   constexpr bool AOS = MODE == M5_AOS, RES = MODE == M5_RES;
   constexpr int BW = GLA_BLOCK, LW = BW + 2;      // a line in LDS: lane tid at [1 + tid], one pad either side (stays +0)
   constexpr int LV = TS + (RES ? 1 : 0);          // levels: TS sweeps; RES: + one level that forms r = b - A x^(k+TS)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
   const T* __restrict__ val = static_cast<const T*>(dv.val);
   bool dg_raised = false;                          // (wave-uniform: this wave has raised the A_ii flag already)
   bool dg_center = false;                          // (kernel-uniform)
-  if constexpr (!AOS) dg_center = dv.dg_mode == 1 || (dv.dg_mode == 2 && __builtin_amdgcn_readfirstlane(*dv.dg_flag) != dv.dg_epoch);
+  if constexpr (!AOS && !DGC) dg_center = dv.dg_mode == 1 || (dv.dg_mode == 2 && __builtin_amdgcn_readfirstlane(*dv.dg_flag) != dv.dg_epoch);
   // A_ii = dg_base[row * dg_ld]: the caller's array, or the plan's centre diagonal (the row's own v[2]: an L1 hit, no HBM bytes)
   const T* const dg_base = dg_center || !diag ? val + 2 * dv.n_rows : diag;
   const uint32_t dg_ld = dg_center || !diag ? 1u : (uint32_t)dv.ldd;
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       c.v[4] = val[4 * dv.n_rows + rc];
       const T wv = val[3 * dv.n_rows + max(rc - 1, (int64_t)0)];      // west(r) = east(r - 1); a line's first point has none
       c.v[1] = gi == 0 ? T(0) : wv;
-      c.v[0] = T(0);                                                  // north: filled in at the set's first use (below)
+      c.v[0] = T(0);                                                  // (not kept: north(line l) = south(line l - 1), the set before)
+      if (J0 + jl < 0) c.v[4] = T(0);                                 // (a line above the grid: the grid's first line has no north)
     } else {
 #pragma unroll
       for (int d = 0; d < 5; ++d) c.v[d] = val[(int64_t)d * dv.n_rows + rc];
@@ -175,7 +177,8 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       c.b = x[ra * ldva + 1];
     } else {
       c.b = bvec[rc];
-      c.dg = dg_base[(int64_t)((uint32_t)rc * (uint64_t)dg_ld)];      // (base and stride chosen ONCE, below: see header)
+      if constexpr (DGC) c.dg = T(0);                // (A_ii IS the centre coefficient, known at launch: neither loaded nor kept)
+      else c.dg = dg_base[(int64_t)((uint32_t)rc * (uint64_t)dg_ld)];      // (base and stride chosen ONCE, below: see header)
     }
     if constexpr (FM) c.m = 0;                      // (every row has the mask of its position: gla_csr.dia_full; not read)
     else c.m = (int)dv.mask[rc];
@@ -196,11 +199,13 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
   T xpre = x0_load(j_first + 1);
   M5Coef<T> c[NC];                                 // set of line j_first + s lives in c[s % NC]
   T crc[NC];                                       // RN(1 / A_ii) of the set's rows (1 where the fast division is off anyway)
+  T s_ev = T(0);                                   // SYM: south coefficient of the line whose set has just left the ring
   bool cfast[NC];                                  // wave-uniform: a whole grid line, every row with the expected mask and a safe divisor
   c[0] = coef_at(j_first);
 #pragma unroll
   for (int s = 1; s < NC; ++s) c[s] = c[0];
-  if constexpr (SYM) c[NC - 1].v[4] = val[4 * dv.n_rows + row_clamped(j_first - 1)];    // (the set "before" the first: its south)
+  if constexpr (SYM)                               // (the set "before" the first: its south)
+    c[NC - 1].v[4] = J0 + j_first - 1 < 0 ? T(0) : val[4 * dv.n_rows + row_clamped(j_first - 1)];
 #pragma unroll
   for (int s = 0; s < NC; ++s) { crc[s] = T(1); cfast[s] = false; }
 
@@ -230,9 +235,8 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
     h[0][2] = (whole_next | live_at(jl + 1)) ? xpre : T(0);
     row_o[1] = h[0][2];                            // level 0, line jl + 1
     xpre = x0_load(jl + 2);
+    if constexpr (SYM) s_ev = c[(u + 1) % NC].v[4];   // the set about to be replaced is line jl - LV: its south is the north of the last level's line
     c[(u + 1) % NC] = coef_at(jl + 1);
-    if constexpr (SYM)                             // north(line jl) = south(line jl - 1); the grid's first line has none
-      c[u % NC].v[0] = J0 + jl <= 0 ? T(0) : c[(u + NC - 1) % NC].v[4];
     {                                              // first use of the set of line jl (loaded a step ago)
       const M5Coef<T>& cu = c[u % NC];
       const int64_t gj = J0 + jl;
@@ -241,9 +245,10 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
       const int em = em_i & ~(gj == 0 ? 1 : 0) & ~(has_down ? 0 : 16);
       bool dok = true;
       if constexpr (RCP) {
-        const T ad = __builtin_fabs(cu.dg);
-        dok = ad >= Lim::dlo && ad <= Lim::dhi && !Lim::all_ones(cu.dg);
-        crc[u % NC] = T(1) / (dok ? cu.dg : T(1));
+        const T cudg = DGC ? cu.v[2] : cu.dg;
+        const T ad = __builtin_fabs(cudg);
+        dok = ad >= Lim::dlo && ad <= Lim::dhi && !Lim::all_ones(cudg);
+        crc[u % NC] = T(1) / (dok ? cudg : T(1));
       }
       if constexpr (FM) { (void)em; cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all(dok) != 0; }
       else cfast[u % NC] = wave_in && jl >= jlo && jl < jhi && __all((cu.m & 0x1f) == em && dok) != 0;
@@ -284,7 +289,8 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
           else { left = row[0]; right = row[2]; }
           const M5Coef<T>& cc = c[ci];
           T acc = T(0);
-          acc = acc + cc.v[0] * h[t - 1][0];
+          const T vnorth = !SYM ? cc.v[0] : (t == LV ? s_ev : c[(ci + NC - 1) % NC].v[4]);
+          acc = acc + vnorth * h[t - 1][0];
           acc = acc + cc.v[1] * left;
           acc = acc + cc.v[2] * h[t - 1][1];
           acc = acc + cc.v[3] * right;
@@ -299,10 +305,10 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
               const T an = __builtin_fabs(num);
               bad = bad || !(an > Lim::nlo && an < Lim::nhi);
               const T q0 = num * crc[ci];
-              const T rem = fma_t(-q0, cc.dg, num);
+              const T rem = fma_t(-q0, DGC ? cc.v[2] : cc.dg, num);
               xn = h[t - 1][1] + fma_t(rem, crc[ci], q0);
             } else {
-              xn = h[t - 1][1] + num / cc.dg;
+              xn = h[t - 1][1] + num / (DGC ? cc.v[2] : cc.dg);
             }
             if (t < LV) { h[t][2] = xn; row[2 * LW + 1] = xn; }     // level t, same line (same parity)
             if (t == TS) { if (owner && (!RES || (line >= 0 && line < L))) xo[(J0 + line) * dv.S + gi] = xn; }
@@ -324,15 +330,16 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
           const T xs[5] = {h[t - 1][0], row[0], h[t - 1][1], row[2], h[t - 1][2]};
           const int m = lv ? (int)dv.mask[row_clamped(line)] : 0;      // (not kept per set: this path is rare)
           T acc = T(0);
+          const T vn_g = !SYM ? cc.v[0] : (t == LV ? s_ev : c[(ci + NC - 1) % NC].v[4]);
 #pragma unroll
           for (int d = 0; d < 5; ++d) {
-            const T nxt = acc + cc.v[d] * xs[d];
+            const T nxt = acc + (d == 0 ? vn_g : cc.v[d]) * xs[d];
             acc = ((m >> d) & 1) ? nxt : acc;
           }
           if (RES && t == LV) {
             if (lv && owner) b_out[(J0 + line) * dv.S + gi] = cc.b - acc;
           } else {
-            T xn = h[t - 1][1] + (w * (cc.b - acc)) / cc.dg;
+            T xn = h[t - 1][1] + (w * (cc.b - acc)) / (DGC ? cc.v[2] : cc.dg);
             xn = lv ? xn : T(0);
             if (t < LV) { h[t][2] = xn; row[2 * LW + 1] = xn; }
             if (t == TS) { if (lv && owner && (!RES || (line >= 0 && line < L))) xo[(J0 + line) * dv.S + gi] = xn; }
@@ -379,6 +386,32 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
   }
 }
 
+// DGM: where A_ii comes from.  0: `diag` / the centre diagonal through the address select of the body (every mode and layout);
+// 1: the centre coefficient, said so by the caller (diag == NULL on a symmetric full-stencil plan): the DGC body; 2: the device
+// flag of gla_jacobi_sweeps_aos decides, ONCE, at kernel start, between the two bodies -- the later passes of the module path
+// run the DGC body without a second launch (the flag is raised only where vertex_attr[:, 0] is not the matrix diagonal).
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, int DGM>
+__global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, const T* __restrict__ diag,
+                                                                     const T* __restrict__ bvec, const T* __restrict__ x,
+                                                                     T* __restrict__ xo, T w, int lines, int nstrips, TileMap tm,
+                                                                     int tile_base0, int tile_split, int tile_base1, int64_t ldva,
+                                                                     T* __restrict__ diag_out, T* __restrict__ b_out) {
+  if constexpr (DGM == 1) {
+    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+                                                           tile_base1, ldva, diag_out, b_out);
+  } else if constexpr (DGM == 2) {
+    if (__builtin_amdgcn_readfirstlane(*dv.dg_flag) != dv.dg_epoch)
+      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+                                                             tile_base1, ldva, diag_out, b_out);
+    else
+      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+                                                              tile_base1, ldva, diag_out, b_out);
+  } else {
+    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+                                                            tile_base1, ldva, diag_out, b_out);
+  }
+}
+
 // Markstein division and LDS prefetch depth per level count: what fits two waves per SIMD (256 registers; the build log of
 // csrc/build.sh shows the allocation of every instance)
 template <typename T, int LV, int MODE, bool SYM = false> struct M5Cfg {
@@ -388,16 +421,20 @@ template <typename T, int LV, int MODE, bool SYM = false> struct M5Cfg {
   static constexpr int hd = sizeof(T) == 4 ? 2 : (LV >= 8 || (MODE == M5_AOS && LV == 6) ? 0 : 2);
   static constexpr bool static_idx = sizeof(T) == 4 || LV >= 8;
 };
-#define M5_KERNEL(T, TS, MODE, LV, SYM, FM) jacobi_march5_kernel<T, TS, MODE, M5Cfg<T, LV, MODE, SYM>::rcp, M5Cfg<T, LV, MODE, SYM>::hd, M5Cfg<T, LV, MODE, SYM>::static_idx, SYM, FM>
+template <typename T, int TS, int MODE, int LV, bool SYM, bool FM, int DGM> struct M5Pick {
+  typedef M5Cfg<T, LV, MODE, SYM> C;
+  static constexpr auto kernel = jacobi_march5_kernel<T, TS, MODE, C::rcp, C::hd, C::static_idx, SYM, FM, DGM>;
+};
+#define M5_KERNEL(T, TS, MODE, LV, SYM, FM, DGM) M5Pick<T, TS, MODE, LV, SYM, FM, DGM>::kernel
 
-template <typename T, int TS, int MODE, bool SYM, bool FM>
+template <typename T, int TS, int MODE, bool SYM, bool FM, int DGM>
 int m5_blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     constexpr int LV = TS + (MODE == M5_RES ? 1 : 0);
     int nb = 0;
     const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, M5_KERNEL(T, TS, MODE, LV, SYM, FM), GLA_BLOCK, lds) != hipSuccess || nb < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, M5_KERNEL(T, TS, MODE, LV, SYM, FM, DGM), GLA_BLOCK, lds) != hipSuccess || nb < 1) {
       (void)hipGetLastError();
       nb = 2;
     }
@@ -406,7 +443,7 @@ int m5_blocks_per_cu() {
   return cached;
 }
 
-template <typename T, int TS, int MODE, bool SYM, bool FM>
+template <typename T, int TS, int MODE, bool SYM, bool FM, int DGM = 0>
 int m5_launch_sym(const gla_march5_args& a) {
   gla_csr* A = a.A;
   constexpr int LV = TS + (MODE == M5_RES ? 1 : 0);
@@ -447,7 +484,7 @@ int m5_launch_sym(const gla_march5_args& a) {
     // block height: the fewest lines per workgroup (least serial work, but every block re-reads 2 (LV - 1) coefficient
     // lines) for which all workgroups are resident at once.  Measured (tools/ab_jacobi_march.py): two workgroups per CU beat
     // three or four even where the registers allow more -- fewer, longer streams; one per CU cannot hide a line step
-    int per_cu = m5_blocks_per_cu<T, TS, MODE, SYM, FM>();
+    int per_cu = m5_blocks_per_cu<T, TS, MODE, SYM, FM, DGM>();
     if (per_cu > 2) per_cu = 2;
     // Interior / boundary split: the interior launch leaves 2 x nstrips workgroup slots FREE for the two edge line blocks that
     // a second stream launches once the ghost lines are in.  A march workgroup takes half a CU's registers, so on a chip full
@@ -475,7 +512,7 @@ int m5_launch_sym(const gla_march5_args& a) {
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
-  hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV, SYM, FM)), grid, block, lds, a.st, dv,
+  hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV, SYM, FM, DGM)), grid, block, lds, a.st, dv,
                      (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1,
                      a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out);
   GLA_LAUNCH_CHECK();
@@ -485,10 +522,18 @@ int m5_launch_sym(const gla_march5_args& a) {
 template <typename T, int TS, int MODE>
 int m5_launch(const gla_march5_args& a) {
   if (!gla_dia_sym5(a.A)) return m5_launch_sym<T, TS, MODE, false, false>(a);
-  // (the no-mask instances exist for the symmetric layout only: a plan whose values are not symmetric keeps its masks as well)
-  // (... and for up to seven levels: hipcc spills the eight-level no-mask instance, 205 registers of it)
+  // (the no-mask instances exist for the symmetric layout only: a plan whose values are not symmetric keeps its masks as well;
+  //  ... and for up to seven levels: hipcc spills the eight-level no-mask instance, 205 registers of it)
   constexpr bool fm_fits = TS + (MODE == M5_RES ? 1 : 0) <= 7;
-  if constexpr (fm_fits) { if (gla_dia_full5(a.A)) return m5_launch_sym<T, TS, MODE, true, true>(a); }
+  if constexpr (fm_fits) {
+    if (gla_dia_full5(a.A)) {
+      if constexpr (MODE == M5_PLAIN) {             // A_ii = the centre coefficient: said so by the caller / decided by the flag
+        if (a.dg_flag) return m5_launch_sym<T, TS, MODE, true, true, 2>(a);
+        if (!a.diag) return m5_launch_sym<T, TS, MODE, true, true, 1>(a);
+      }
+      return m5_launch_sym<T, TS, MODE, true, true>(a);
+    }
+  }
   return m5_launch_sym<T, TS, MODE, true, false>(a);
 }
 

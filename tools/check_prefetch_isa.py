@@ -12,9 +12,12 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = os.environ.get("OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
-KERNELS = [  # (mangled-name fragment <double, TS, MODE 0, RCP, HD, STATIC, SYM, FM>, 8-byte loads of a line step's own prefetch: x, b, A_ii, the diagonals read)
-    ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1ELb1E", 7), ("jacobi_march5_kernelIdLi6ELi0ELb1ELi2ELb0ELb1ELb1E", 7),
-    ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1ELb0E", 7), ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb0ELb0E", 8),
+KERNELS = [  # (mangled-name fragment <double, TS, MODE 0, RCP, HD, STATIC, SYM, FM, DGM>, 8-byte loads of a line step's own prefetch:
+    #  x, b, the diagonals read, A_ii unless it is the centre coefficient (DGM 1; DGM 2 holds both bodies);
+    #  line steps that may carry a conservative wait: one per loop header, i.e. per body)
+    ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1ELb1ELi2E", 6, 2), ("jacobi_march5_kernelIdLi6ELi0ELb1ELi2ELb0ELb1ELb1ELi2E", 6, 2),
+    ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1ELb1ELi1E", 6, 1), ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1ELb1ELi0E", 7, 1),
+    ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb1ELb0ELi0E", 7, 1), ("jacobi_march5_kernelIdLi7ELi0ELb1ELi2ELb0ELb0ELb0ELi0E", 8, 1),
 ]
 
 
@@ -29,7 +32,7 @@ def disassemble(obj):
     return subprocess.run([OBJDUMP, "-d", os.path.join(tmp, co[0])], check=True, capture_output=True, text=True).stdout
 
 
-def check(text, frag, nloads):
+def check(text, frag, nloads, headers):
     m = re.search(r"^[0-9a-f]+ <([^>]*%s[^>]*)>:\n" % re.escape(frag), text, re.M)
     if not m:
         return f"{frag}: kernel not found"
@@ -63,13 +66,13 @@ def check(text, frag, nloads):
     #  kernel too; a wait or a branch inside the load sequence of SEVERAL copies is the drain this tool is here to catch)
     if n_steps < 4:
         return f"{frag}: only {n_steps} steady-state line steps recognised"
-    return f"{frag}: " + "; ".join(list(bad.values())[:3]) if len(bad) > 1 else None
+    return f"{frag}: " + "; ".join(list(bad.values())[:3]) if len(bad) > headers else None
 
 
 def main():
     obj = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gnn_applied_linear_algebra_amd", "csrc", "gla_march5.o")
     text = disassemble(obj)
-    errs = [e for e in (check(text, k, nl) for k, nl in KERNELS) if e]
+    errs = [e for e in (check(text, k, nl, hd) for k, nl, hd in KERNELS) if e]
     for e in errs:
         print(e)
     print(f"{os.path.basename(obj)}: {len(KERNELS) - len(errs)} of {len(KERNELS)} march kernels issue their line-step loads back to back")
