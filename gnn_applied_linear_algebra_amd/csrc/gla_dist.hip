@@ -99,6 +99,21 @@ struct gla_comm {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;      // gla_dist_jacobi_temporal: compute stream <-> second stream
 };
 
+// Rows [lo0, hi0) and [lo1, hi1) of an extended block's A_ii copy against the plan's centre diagonal, bit for bit: the rows the
+// two edge line blocks read (hand copies of own rows + the neighbours' ghost lines), which the AoS interior launch does not see.
+// A difference raises the call's flag (gla_jacobi_dg_slot); the march passes then read the copy instead of the coefficient.
+template <typename U>
+__global__ __launch_bounds__(256) void dg_check_kernel(const U* __restrict__ d_ext, const U* __restrict__ centre, int64_t lo0,
+                                                       int64_t hi0, int64_t lo1, int64_t hi1, int* __restrict__ flag, int epoch) {
+  const int64_t n0 = hi0 - lo0, n1 = hi1 - lo1;
+  bool mis = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n0 + n1; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i < n0 ? lo0 + i : lo1 + (i - n0);
+    mis = mis || d_ext[r] != centre[r];
+  }
+  if (__any(mis) && (threadIdx.x & 63) == 0) atomicExch(flag, epoch);
+}
+
 extern "C" {
 
 int gla_comm_unique_id(void* id_host) {
@@ -309,6 +324,19 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
   int rc;
   void* cur = xa;
   void* nxt = n_passes == 1 ? x_last : xb;
+  // A_ii = the matrix diagonal (what JacobiGNN.py:160-170 passes) is found out inside pass 0 -- the AoS interior launch compares
+  // its rows, dg_check_kernel the rows the edge blocks read -- and every later launch then runs the body that neither loads nor
+  // keeps A_ii (gla_march5.hip, DGM 2); the copy d_ext is still written: it is what a raised flag falls back to.
+  int* dg_flag = nullptr;
+  int dg_epoch = 0;
+  if (g_tuning.jacobi_diag_flag && gla_dia_sym5(A) && gla_dia_full5(A) && A->dia_val) {
+    rc = gla_jacobi_dg_slot(A, &dg_flag, &dg_epoch);
+    if (rc) return rc;
+  }
+  auto parts = [&](const void* dg, const void* bb, const void* xin, void* xout, int ts, int part, hipStream_t st) -> int {
+    if (dg_flag) return gla_jacobi_parts_flagged(A, dtype, nullptr, 0, 0, 0, dg, bb, xin, nullptr, nullptr, xout, w, ts, part, ghost, dg_flag, dg_epoch, st);
+    return gla_jacobi_fused_parts(A, dtype, dg, bb, xin, xout, w, ts, part, ghost, st);
+  };
   // ---- pass 0 ---------------------------------------------------------------------------------------------------------------
   {
     const int ts = passes[0];
@@ -336,7 +364,9 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
     forked = true;
-    rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, ghost, mn); if (rc) return bail(rc);
+    if (dg_flag) rc = gla_jacobi_parts_flagged(A, dtype, va, ldva, off, n_local, nullptr, nullptr, nullptr, d_ext, b_ext, nxt, w, ts, 1, ghost, dg_flag, dg_epoch, mn);
+    else rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, ghost, mn);
+    if (rc) return bail(rc);
     rc = gla_halo_end(c, sd); if (rc) return bail(rc);
     k = 0;
     for (int col = 0; col < 3; ++col) {                       // the neighbour above's LAST lines / below's FIRST lines
@@ -344,7 +374,18 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
       if (down) { src[k] = at(recv, (int64_t)down_src * 6 * m + 2 * m * col); dst[k] = atw(dst3[col], off + n_local); cnt[k] = m; strd[k] = 1; ++k; }
     }
     if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return bail(rc); }
-    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 2, ghost, sd); if (rc) return bail(rc);
+    if (dg_flag) {                                            // the rows the edge blocks read: [0, E) and [n_ext - E, n_ext)
+      const int64_t nchk = 2 * E;
+      const unsigned grid = (unsigned)((nchk + 255) / 256 < 1024 ? (nchk + 255) / 256 : 1024);
+      if (dtype == GLA_F64)
+        hipLaunchKernelGGL((dg_check_kernel<unsigned long long>), dim3(grid), dim3(256), 0, sd, (const unsigned long long*)d_ext,
+                           (const unsigned long long*)A->dia_val + 2 * n_ext, (int64_t)0, E, n_ext - E, n_ext, dg_flag, dg_epoch);
+      else
+        hipLaunchKernelGGL((dg_check_kernel<unsigned>), dim3(grid), dim3(256), 0, sd, (const unsigned*)d_ext,
+                           (const unsigned*)A->dia_val + 2 * n_ext, (int64_t)0, E, n_ext - E, n_ext, dg_flag, dg_epoch);
+      if (hipGetLastError() != hipSuccess) return bail(GLA_ERR_INVALID_ARG);
+    }
+    rc = parts(d_ext, b_ext, cur, nxt, ts, 2, sd); if (rc) return bail(rc);
   }
   // ---- passes 1 .. ----------------------------------------------------------------------------------------------------------
   for (int i = 1; i <= n_passes; ++i) {
@@ -367,14 +408,14 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
     forked = true;
-    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 1, ghost, mn); if (rc) return bail(rc);
+    rc = parts(d_ext, b_ext, cur, nxt, ts, 1, mn); if (rc) return bail(rc);
     rc = gla_halo_end(c, sd); if (rc) return bail(rc);
     const void* src[2]; void* dst[2]; int64_t cnt[2];
     int k = 0;
     if (up) { src[k] = at(recv, (int64_t)up_src * 2 * m + m); dst[k] = cur; cnt[k] = m; ++k; }
     if (down) { src[k] = at(recv, (int64_t)down_src * 2 * m); dst[k] = atw(cur, off + n_local); cnt[k] = m; ++k; }
     if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, nullptr, sd); if (rc) return bail(rc); }
-    rc = gla_jacobi_fused_parts(A, dtype, d_ext, b_ext, cur, nxt, w, ts, 2, ghost, sd); if (rc) return bail(rc);
+    rc = parts(d_ext, b_ext, cur, nxt, ts, 2, sd); if (rc) return bail(rc);
   }
   return GLA_OK;
 }

@@ -162,6 +162,11 @@ int gla_march5_pass(const gla_march5_args& a);
 // GLA_OK iff gla_jacobi_fused_parts(_aos) would run `sweeps` sweeps on this canonical 5-point plan with these value types
 // (gla_rows.hip); otherwise the status it would return.  For callers that must know BEFORE they enqueue anything (gla_dist.hip).
 int gla_jacobi_parts_status(const gla_csr* A, int dtype, int sweeps);
+// the A_ii flag word and number of one call, and the march passes that raise / obey it (gla_rows.hip; for gla_dist.hip)
+int gla_jacobi_dg_slot(gla_csr* A, int** flag, int* epoch);
+int gla_jacobi_parts_flagged(gla_csr* A, int dtype, const void* va, int64_t ldva, int64_t row_offset, int64_t n_attr_rows,
+                             const void* diag, const void* B, const void* X, void* diag_out, void* b_out, void* Xout, double w,
+                             int sweeps, int part, int ghost_lines, int* dg_flag, int dg_epoch, hipStream_t st);
 
 // jacobik.hip: `sweeps` (2 .. GLA_JACOBIK_TS_MAX) Jacobi sweeps of K right-hand sides in one temporally blocked pass
 constexpr int GLA_JACOBIK_TS_MAX = 5;

@@ -1820,6 +1820,29 @@ inline int jacobi_plan_ts(const JacobiPlan& p, int i) {      // sweeps of launch
 
 std::mutex g_dg_mutex;                               // guards every plan's dg_flags / dg_calls (taken once per gla_jacobi_sweeps_aos call)
 
+}  // namespace
+
+// The "A_ii is not the matrix diagonal" flag of ONE call (gla_jacobi_sweeps_aos, gla_dist_jacobi_temporal).  The flags live in
+// the plan (GLA_DG_SLOTS words, zero when allocated): call number k uses word k mod GLA_DG_SLOTS and stores k into it to raise
+// it, so no word ever has to be reset -- a memset in front of every call was 15-19 us of launch gap per step.
+int gla_jacobi_dg_slot(gla_csr* A, int** flag, int* epoch) {
+  std::lock_guard<std::mutex> lock(g_dg_mutex);
+  if (!A->dg_flags) {
+    GLA_HIP_CHECK(hipMalloc(&A->dg_flags, GLA_DG_SLOTS * sizeof(int)));
+    GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, GLA_DG_SLOTS * sizeof(int)));
+  }
+  if (++A->dg_calls >= 0x7fffff00u) {                 // (wrap-around after 2^31 calls: start over with clean words)
+    GLA_HIP_CHECK(hipDeviceSynchronize());
+    GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, GLA_DG_SLOTS * sizeof(int)));
+    A->dg_calls = 1;
+  }
+  *epoch = (int)A->dg_calls;
+  *flag = A->dg_flags + (A->dg_calls % GLA_DG_SLOTS);
+  return GLA_OK;
+}
+
+namespace {
+
 template <typename T>
 int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T* Xout, T* Xtmp, T w,
                       const JacobiPlan& plan, hipStream_t st) {
@@ -1834,20 +1857,8 @@ int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T
   int* flag = nullptr;
   int epoch = 0;
   if (flagged) {
-    // The flag lives in the plan (GLA_DG_SLOTS words, zero when allocated): call number k uses word k mod GLA_DG_SLOTS and stores
-    // k into it to raise it, so no word ever has to be reset -- a memset in front of every call was 15-19 us of launch gap per step
-    std::lock_guard<std::mutex> lock(g_dg_mutex);
-    if (!A->dg_flags) {
-      GLA_HIP_CHECK(hipMalloc(&A->dg_flags, GLA_DG_SLOTS * sizeof(int)));
-      GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, GLA_DG_SLOTS * sizeof(int)));
-    }
-    if (++A->dg_calls >= 0x7fffff00u) {               // (wrap-around after 2^31 calls: start over with clean words)
-      GLA_HIP_CHECK(hipDeviceSynchronize());
-      GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, GLA_DG_SLOTS * sizeof(int)));
-      A->dg_calls = 1;
-    }
-    epoch = (int)A->dg_calls;
-    flag = A->dg_flags + (A->dg_calls % GLA_DG_SLOTS);
+    const int rc = gla_jacobi_dg_slot(A, &flag, &epoch);
+    if (rc) return rc;
   }
   (void)dwork;
   for (int i = 1; i <= n_launch; ++i) {
@@ -1974,6 +1985,26 @@ int gla_jacobi_parts_status(const gla_csr* A, int dtype, int sweeps) {
   if (A->nnz > 0 && A->val_dtype != dtype) return GLA_ERR_NO_VALUES;
   if (!(dtype == GLA_F64 ? jacobi_fused_ok<double>(A) : jacobi_fused_ok<float>(A)) || !jacobi_canon(A)) return GLA_ERR_UNSUPPORTED;
   return GLA_OK;
+}
+
+// gla_jacobi_fused_parts / gla_jacobi_fused_parts_aos with the A_ii flag of a call (gla_dist.hip; arguments checked by the
+// caller, canonical 5-point plans only).  va != NULL: the AoS first pass -- copies of A_ii / b go to diag_out / b_out AND every
+// owned row whose A_ii differs from its centre coefficient raises the flag; va == NULL: a plain pass that takes A_ii from the
+// centre coefficient unless the flag is raised (then from `diag`).
+int gla_jacobi_parts_flagged(gla_csr* A, int dtype, const void* va, int64_t ldva, int64_t row_offset, int64_t n_attr_rows,
+                             const void* diag, const void* B, const void* X, void* diag_out, void* b_out, void* Xout, double w,
+                             int sweeps, int part, int ghost_lines, int* dg_flag, int dg_epoch, hipStream_t st) {
+  if (!jacobi_canon(A)) return GLA_ERR_UNSUPPORTED;
+  if (dtype == GLA_F64) {
+    if (va) return launch_jacobi_fused_ts<double>(sweeps, A, nullptr, nullptr, (const double*)va, (double*)Xout, (double)w, st, part, ldva,
+                                                  (double*)diag_out, (double*)b_out, ghost_lines, row_offset, n_attr_rows, 1, dg_flag, dg_epoch);
+    return launch_jacobi_fused_ts<double>(sweeps, A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st,
+                                          part, 0, nullptr, nullptr, ghost_lines, 0, -1, 1, dg_flag, dg_epoch);
+  }
+  if (va) return launch_jacobi_fused_ts<float>(sweeps, A, nullptr, nullptr, (const float*)va, (float*)Xout, (float)w, st, part, ldva,
+                                               (float*)diag_out, (float*)b_out, ghost_lines, row_offset, n_attr_rows, 1, dg_flag, dg_epoch);
+  return launch_jacobi_fused_ts<float>(sweeps, A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part,
+                                       0, nullptr, nullptr, ghost_lines, 0, -1, 1, dg_flag, dg_epoch);
 }
 
 extern "C" {

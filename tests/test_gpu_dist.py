@@ -659,8 +659,27 @@ def test_temporal_route_self_halo_rccl(Nx, Ny, up, down):
 
     def periodic(own):                                   # [own's last T lines | own | own's first T lines]
         return torch.cat(([own[-m:]] if up else []) + [own] + ([own[:m]] if down else []))
-    d_e, b_e = periodic(va[:, 0].contiguous()), periodic(va[:, 1].contiguous())
-    for its in (2, 7, 9, 16, 20, 23):
+    # A_ii: random (the route's flag is raised by every row: the passes read the copies), the matrix diagonal (what the reference
+    # passes, JacobiGNN.py:160-170: the flag stays clean, the passes neither load nor keep A_ii), and the diagonal with ONE row an
+    # ulp off -- in a line that is a neighbour's ghost line, in the window the edge blocks read, in the interior
+    cases = [("random", None)]
+    if up and down:
+        cases += [("diagonal", []), ("ghost line", [3]), ("edge window", [(2 * T + 1) * Nx + 5]), ("interior", [n // 2 + 7]),
+                  ("last own row", [n - 1])]
+    for a_name, off_rows in cases:
+      if off_rows is not None:
+        va[:, 0] = -4.0                                    # (laplacianfun_torch: the negative Laplacian, UtilsGNN.py:58-59)
+        for r in off_rows:
+            va[r, 0] = torch.nextafter(va[r, 0], torch.tensor(0.0, dtype=torch.float64, device=dev))
+      d_e, b_e = periodic(va[:, 0].contiguous()), periodic(va[:, 1].contiguous())
+      _temporal_route_case(plan, drv, va, g, d_e, b_e, periodic, up, down, n, n_ext, off, dev, a_name,
+                           (2, 7, 9, 16, 20, 23) if off_rows is None else (7, 20))
+    torch.cuda.synchronize()
+
+
+def _temporal_route_case(plan, drv, va, g, d_e, b_e, periodic, up, down, n, n_ext, off, dev, a_name, its_list):
+    from gnn_applied_linear_algebra_amd._lib import check, lib
+    for its in its_list:
         x = va[:, 2].contiguous()
         try:
             check(lib().gla_set_option(b"jacobi_fuse", 0))
@@ -678,7 +697,7 @@ def test_temporal_route_self_halo_rccl(Nx, Ny, up, down):
                                   torch.zeros(n_ext, dtype=torch.float64, device=dev), torch.zeros(n_ext, dtype=torch.float64, device=dev))
             got = drv.forward(its, va, g)
             if up and down:
-                assert torch.equal(got.reshape(-1), x), (its, overlap, float((got.reshape(-1) - x).abs().max()))
+                assert torch.equal(got.reshape(-1), x), (a_name, its, overlap, float((got.reshape(-1) - x).abs().max()))
             else:
                 # One neighbour only (the first / last rank of a partition).  "My neighbour is myself" is then not a consistent
                 # problem -- the neighbour's last line has nothing below it, my ghost copy of it has my first line -- so there is
@@ -697,8 +716,7 @@ def test_temporal_route_self_halo_rccl(Nx, Ny, up, down):
                     assert torch.equal(got, first_route), (its, "overlapped vs sequential")
             d_ext, b_ext = drv.ext["buffers"][0], drv.ext["buffers"][1]
             assert torch.equal(d_ext[off:off + n], va[:, 0]) and torch.equal(b_ext[off:off + n], va[:, 1]), (its, overlap)
-            assert torch.equal(d_ext, d_e) and torch.equal(b_ext, b_e), (its, overlap, "ghost lines of A_ii / b")
-    torch.cuda.synchronize()
+            assert torch.equal(d_ext, d_e) and torch.equal(b_ext, b_e), (a_name, its, overlap, "ghost lines of A_ii / b")
 
 
 def test_k_wide_ghost_routes_self_halo_rccl():
