@@ -93,6 +93,7 @@ template <> struct M5Lim<float> {
 template <typename T>
 struct M5Coef {               // one row's matrix data
   T v[5], b, dg;
+  T xv;                       // PF > 1: x^(k) of the NEXT line rides along (same prefetch distance as the coefficients)
   int m;                      // diagonal mask exactly as loaded; read once, at the set's first use (a line step after the load:
 };                            // no arithmetic on it earlier, the load must stay in flight)
 
@@ -100,7 +101,7 @@ constexpr int M5_PLAIN = 0, M5_AOS = 1, M5_RES = 2;
 
 // The pass (one workgroup's line block).  DGC: A_ii IS the row's centre coefficient -- neither loaded nor kept (12 registers per
 // coefficient set instead of 17, one load less per line step).
-template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, bool DGC>
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, bool DGC, int PF = 1>
 __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ diag, const T* __restrict__ bvec,
                                         const T* __restrict__ x, T* __restrict__ xo, T w, int lines, int nstrips, const TileMap& tm,
                                         int tile_base0, int tile_split, int tile_base1, int64_t ldva, T* __restrict__ diag_out,
@@ -108,7 +109,7 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
   constexpr bool AOS = MODE == M5_AOS, RES = MODE == M5_RES;
   constexpr int BW = GLA_BLOCK, LW = BW + 2;      // a line in LDS: lane tid at [1 + tid], one pad either side (stays +0)
   constexpr int LV = TS + (RES ? 1 : 0);          // levels: TS sweeps; RES: + one level that forms r = b - A x^(k+TS)
-  constexpr int NC = LV + 1, U = NC;              // coefficient sets in flight (lines jl + 1 .. jl - LV + 1); unroll: static set index
+  constexpr int NC = LV + PF, U = NC;             // coefficient sets in flight (lines jl + 1 .. jl - LV + 1); unroll: static set index
   typedef M5Lim<T> Lim;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* buf = reinterpret_cast<T*>(smem_raw);        // [LV][2][LW]: buf[t][p] = the latest line of parity p of x^(k+t)
@@ -180,6 +181,7 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
       if constexpr (DGC) c.dg = T(0);                // (A_ii IS the centre coefficient, known at launch: neither loaded nor kept)
       else c.dg = dg_base[(int64_t)((uint32_t)rc * (uint64_t)dg_ld)];      // (base and stride chosen ONCE, below: see header)
     }
+    if constexpr (PF > 1) c.xv = x0_load(jl + 1); else c.xv = T(0);
     if constexpr (FM) c.m = 0;                      // (every row has the mask of its position: gla_csr.dia_full; not read)
     else c.m = (int)dv.mask[rc];
     return c;
@@ -196,14 +198,15 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
     h[0][2] = live_at(j_first) ? b0 : T(0);
   }
   buf[((j_first + 64) & 1) * LW + 1 + tid] = h[0][2];
-  T xpre = x0_load(j_first + 1);
+  T xpre = PF > 1 ? T(0) : x0_load(j_first + 1);
   M5Coef<T> c[NC];                                 // set of line j_first + s lives in c[s % NC]
   T crc[NC];                                       // RN(1 / A_ii) of the set's rows (1 where the fast division is off anyway)
   T s_ev = T(0);                                   // SYM: south coefficient of the line whose set has just left the ring
   bool cfast[NC];                                  // wave-uniform: a whole grid line, every row with the expected mask and a safe divisor
-  c[0] = coef_at(j_first);
 #pragma unroll
-  for (int s = 1; s < NC; ++s) c[s] = c[0];
+  for (int s = 0; s < PF; ++s) c[s] = coef_at(j_first + s);
+#pragma unroll
+  for (int s = PF; s < NC; ++s) c[s] = c[0];
   if constexpr (SYM)                               // (the set "before" the first: its south)
     c[NC - 1].v[4] = J0 + j_first - 1 < 0 ? T(0) : val[4 * dv.n_rows + row_clamped(j_first - 1)];
 #pragma unroll
@@ -232,11 +235,11 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
     const bool whole_next = wave_in & (jl + 1 >= jlo) & (jl + 1 < jhi);          // wave-uniform: line jl + 1 exists for every lane
     // (bitwise on purpose: hipcc 7.0 dropped the exec-masked move of `uniform || per_lane ? x : 0` in unrolled copies of
     // jacobi_marchk_kernel's line step -- profiles/r03/marchk_miscompile.txt; a plain v_cndmask has no such region)
-    h[0][2] = (whole_next | live_at(jl + 1)) ? xpre : T(0);
+    h[0][2] = (whole_next | live_at(jl + 1)) ? (PF > 1 ? c[u % NC].xv : xpre) : T(0);
     row_o[1] = h[0][2];                            // level 0, line jl + 1
-    xpre = x0_load(jl + 2);
-    if constexpr (SYM) s_ev = c[(u + 1) % NC].v[4];   // the set about to be replaced is line jl - LV: its south is the north of the last level's line
-    c[(u + 1) % NC] = coef_at(jl + 1);
+    if constexpr (PF == 1) xpre = x0_load(jl + 2);
+    if constexpr (SYM) s_ev = c[(u + PF) % NC].v[4];   // the set about to be replaced is line jl - LV: its south is the north of the last level's line
+    c[(u + PF) % NC] = coef_at(jl + PF);
     {                                              // first use of the set of line jl (loaded a step ago)
       const M5Coef<T>& cu = c[u % NC];
       const int64_t gj = J0 + jl;
@@ -288,9 +291,8 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
           if constexpr (HD > 0) { left = nl[t - 1]; right = nr[t - 1]; }
           else { left = row[0]; right = row[2]; }
           const M5Coef<T>& cc = c[ci];
-          T acc = T(0);
           const T vnorth = !SYM ? cc.v[0] : (t == LV ? s_ev : c[(ci + NC - 1) % NC].v[4]);
-          acc = acc + vnorth * h[t - 1][0];
+          T acc = fma_t(vnorth, h[t - 1][0], T(0));   // == +0 + RN(v x) bit for bit (one rounding of an exact product; -0 + +0 = +0)
           acc = acc + cc.v[1] * left;
           acc = acc + cc.v[2] * h[t - 1][1];
           acc = acc + cc.v[3] * right;
@@ -390,24 +392,24 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
 // 1: the centre coefficient, said so by the caller (diag == NULL on a symmetric full-stencil plan): the DGC body; 2: the device
 // flag of gla_jacobi_sweeps_aos decides, ONCE, at kernel start, between the two bodies -- the later passes of the module path
 // run the DGC body without a second launch (the flag is raised only where vertex_attr[:, 0] is not the matrix diagonal).
-template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, int DGM>
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, int DGM, int PF = 1>
 __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, const T* __restrict__ diag,
                                                                      const T* __restrict__ bvec, const T* __restrict__ x,
                                                                      T* __restrict__ xo, T w, int lines, int nstrips, TileMap tm,
                                                                      int tile_base0, int tile_split, int tile_base1, int64_t ldva,
                                                                      T* __restrict__ diag_out, T* __restrict__ b_out) {
   if constexpr (DGM == 1) {
-    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true, PF>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                            tile_base1, ldva, diag_out, b_out);
   } else if constexpr (DGM == 2) {
     if (__builtin_amdgcn_readfirstlane(*dv.dg_flag) != dv.dg_epoch)
-      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true, PF>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                              tile_base1, ldva, diag_out, b_out);
     else
-      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false, PF>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                               tile_base1, ldva, diag_out, b_out);
   } else {
-    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false, PF>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                             tile_base1, ldva, diag_out, b_out);
   }
 }
@@ -512,6 +514,22 @@ int m5_launch_sym(const gla_march5_args& a) {
   set_tile_mapping(tm);
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
+#ifdef GLA_M5_VARIANTS
+  if constexpr (sizeof(T) == 8 && TS == 7 && MODE == M5_PLAIN && SYM && FM && DGM == 1) {
+    const int v = g_tuning.m5_variant;
+#define M5V(HDV, SIV, PFV) hipLaunchKernelGGL((jacobi_march5_kernel<T, TS, MODE, true, HDV, SIV, SYM, FM, DGM, PFV>), grid, block, lds, a.st, dv, (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1, a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out)
+    if (v > 0) {
+      switch (v) {
+        case 1: M5V(0, false, 1); break; case 2: M5V(1, false, 1); break; case 3: M5V(3, false, 1); break;
+        case 4: M5V(2, false, 2); break; case 5: M5V(0, false, 2); break; case 6: M5V(3, false, 2); break;
+        case 7: M5V(2, false, 3); break; case 8: M5V(0, false, 3); break;
+        default: return GLA_ERR_INVALID_ARG;
+      }
+      GLA_LAUNCH_CHECK();
+      return GLA_OK;
+    }
+  }
+#endif
   hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV, SYM, FM, DGM)), grid, block, lds, a.st, dv,
                      (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1,
                      a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out);
