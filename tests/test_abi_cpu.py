@@ -87,3 +87,28 @@ def test_header_is_valid_c(tmp_path):
                    + "size_t n_entries(void) { return sizeof(table) / sizeof(table[0]); }\n")
     subprocess.run([gcc, "-std=c11", "-Wall", "-Werror", "-c", str(src),
                     "-I" + os.path.join(root, "include"), "-o", str(tmp_path / "use_gla.o")], check=True)
+
+
+def test_csr_info_struct_layout_matches_the_header(tmp_path):
+    """gla_csr_info_t as the C compiler lays it out (include/gla.h) == the ctypes mirror the Python host passes to gla_csr_info:
+    same size, same offset for every field (fields are appended round by round; a field added on one side only would shift
+    everything the library writes)."""
+    import ctypes
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from gnn_applied_linear_algebra_amd._lib import CsrInfo
+    fields = [f[0] for f in CsrInfo._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include "gla.h"\n#include <stddef.h>\n#include <stdio.h>\nint main(void) {\n'
+                   + '  printf("%zu\\n", sizeof(gla_csr_info_t));\n'
+                   + "".join(f'  printf("%zu\\n", offsetof(gla_csr_info_t, {f}));\n' for f in fields)
+                   + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c11", "-Wall", "-Werror", str(src), "-I" + os.path.join(root, "include"), "-o", str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(CsrInfo), (out[0], ctypes.sizeof(CsrInfo))
+    assert out[1:] == [getattr(CsrInfo, f).offset for f in fields]
