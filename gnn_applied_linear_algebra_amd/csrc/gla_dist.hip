@@ -114,6 +114,15 @@ __global__ __launch_bounds__(256) void dg_check_kernel(const U* __restrict__ d_e
   if (__any(mis) && (threadIdx.x & 63) == 0) atomicExch(flag, epoch);
 }
 
+// The flag of the call is raised: rows [lo, hi) of the A_ii copy are filled from column 0 of the AoS rows after all (the AoS
+// interior launch of a flagged call does not write them); otherwise every workgroup leaves at once.
+template <typename U>
+__global__ __launch_bounds__(256) void dg_repair_kernel(const U* __restrict__ va, int64_t ldva, int64_t off, U* __restrict__ d_ext,
+                                                        int64_t lo, int64_t hi, const int* __restrict__ flag, int epoch) {
+  if (__builtin_amdgcn_readfirstlane(*flag) != epoch) return;
+  for (int64_t r = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; r < hi; r += (int64_t)gridDim.x * 256) d_ext[r] = va[(r - off) * ldva];
+}
+
 extern "C" {
 
 int gla_comm_unique_id(void* id_host) {
@@ -326,7 +335,8 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
   void* nxt = n_passes == 1 ? x_last : xb;
   // A_ii = the matrix diagonal (what JacobiGNN.py:160-170 passes) is found out inside pass 0 -- the AoS interior launch compares
   // its rows, dg_check_kernel the rows the edge blocks read -- and every later launch then runs the body that neither loads nor
-  // keeps A_ii (gla_march5.hip, DGM 2); the copy d_ext is still written: it is what a raised flag falls back to.
+  // keeps A_ii (gla_march5.hip, DGM 2).  The copy d_ext is what a raised flag falls back to: its edge windows and ghost lines are
+  // always filled (by hand, below), its interior only by dg_repair_kernel, after pass 0, when the flag IS raised.
   int* dg_flag = nullptr;
   int dg_epoch = 0;
   if (g_tuning.jacobi_diag_flag && gla_dia_sym5(A) && gla_dia_full5(A) && A->dia_val) {
@@ -364,7 +374,7 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
     forked = true;
-    if (dg_flag) rc = gla_jacobi_parts_flagged(A, dtype, va, ldva, off, n_local, nullptr, nullptr, nullptr, d_ext, b_ext, nxt, w, ts, 1, ghost, dg_flag, dg_epoch, mn);
+    if (dg_flag) rc = gla_jacobi_parts_flagged(A, dtype, va, ldva, off, n_local, nullptr, nullptr, nullptr, nullptr, b_ext, nxt, w, ts, 1, ghost, dg_flag, dg_epoch, mn);
     else rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, ghost, mn);
     if (rc) return bail(rc);
     rc = gla_halo_end(c, sd); if (rc) return bail(rc);
@@ -401,6 +411,19 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     GLA_HIP_CHECK(hipStreamWaitEvent(mn, c->ev_join, 0));
     forked = false;
     if (i == n_passes) break;
+    if (i == 1 && dg_flag) {                                  // (both streams joined: pass 0 is complete, the flag final)
+      const int64_t E0 = (int64_t)(2 * ghost + passes[0]) * S;
+      const int64_t lo = E0 > off ? E0 : off, hi = n_ext - E0 < off + n_local ? n_ext - E0 : off + n_local;
+      if (hi > lo) {
+        if (dtype == GLA_F64)
+          hipLaunchKernelGGL((dg_repair_kernel<unsigned long long>), dim3(1024), dim3(256), 0, mn, (const unsigned long long*)va, ldva, off,
+                             (unsigned long long*)d_ext, lo, hi, dg_flag, dg_epoch);
+        else
+          hipLaunchKernelGGL((dg_repair_kernel<unsigned>), dim3(1024), dim3(256), 0, mn, (const unsigned*)va, ldva, off, (unsigned*)d_ext, lo, hi,
+                             dg_flag, dg_epoch);
+        if (hipGetLastError() != hipSuccess) return GLA_ERR_INVALID_ARG;
+      }
+    }
     { void* t = cur; cur = nxt; nxt = t; }
     if (i == 1) nxt = xb == cur ? xa : xb;                    // (pass 0 wrote xb or x_last; from now on ping-pong xa / xb)
     if (i == n_passes - 1) nxt = x_last;

@@ -715,8 +715,15 @@ def _temporal_route_case(plan, drv, va, g, d_e, b_e, periodic, up, down, n, n_ex
                 else:
                     assert torch.equal(got, first_route), (its, "overlapped vs sequential")
             d_ext, b_ext = drv.ext["buffers"][0], drv.ext["buffers"][1]
-            assert torch.equal(d_ext[off:off + n], va[:, 0]) and torch.equal(b_ext[off:off + n], va[:, 1]), (its, overlap)
-            assert torch.equal(d_ext, d_e) and torch.equal(b_ext, b_e), (a_name, its, overlap, "ghost lines of A_ii / b")
+            assert torch.equal(b_ext[off:off + n], va[:, 1]) and torch.equal(b_ext, b_e), (a_name, its, overlap, "b and its ghost lines")
+            # the A_ii copy: always the lines the edge blocks read (hand copies + ghost lines); the interior only where some
+            # A_ii is NOT the matrix diagonal (the library-driven route fills it after pass 0 then; the Python-driven one always)
+            # (a single pass never reads the copy's interior; nor do later passes while every A_ii is the matrix diagonal)
+            if not bool(torch.isnan(d_ext).any()) or (a_name != "diagonal" and len(plan.jacobi_schedule(its)) >= 2):
+                assert torch.equal(d_ext, d_e), (a_name, its, overlap, "A_ii copy")
+            else:
+                Er = (2 * drv.TS_MAX + plan.jacobi_schedule(its)[0]) * drv.ext["S"]
+                assert torch.equal(d_ext[:Er], d_e[:Er]) and torch.equal(d_ext[-Er:], d_e[-Er:]), (a_name, its, overlap, "A_ii windows")
 
 
 def test_k_wide_ghost_routes_self_halo_rccl():
