@@ -218,8 +218,14 @@ class CsrPlan:
         Xout = torch.empty((self.n_rows, K), dtype=X0.dtype, device=self.device)
         Xtmp = torch.empty_like(Xout) if n_iters > 1 else None
         no_stream = diag_is_matrix_diagonal and self._diag_from_matrix(K, n_iters, X0.dtype, ldb == 1 and ldx0 == 1)
-        check(lib().gla_jacobi_sweeps(self._h, dtype_code(X0.dtype), K, None if no_stream else ptr(diag), ptr(B), ldb, ptr(X0), ldx0,
-                                      ptr(Xout), ptr(Xtmp), K, float(w), int(n_iters), stream_ptr(self.device)))
+
+        def run(dg):
+            return lib().gla_jacobi_sweeps(self._h, dtype_code(X0.dtype), K, dg, ptr(B), ldb, ptr(X0), ldx0, ptr(Xout), ptr(Xtmp), K,
+                                           float(w), int(n_iters), stream_ptr(self.device))
+        rc = run(None if no_stream else ptr(diag))
+        if rc == -1 and no_stream:                           # the library would not do without the array (option jacobi_march = 0: the
+            rc = run(ptr(diag))                              # canonical plans run the generic kernels); refused BEFORE anything was enqueued
+        check(rc)
         return Xout
 
     @_on_device
@@ -267,8 +273,12 @@ class CsrPlan:
         Xout = torch.empty((self.n_rows, 1), dtype=X0.dtype, device=self.device)
         R = torch.empty_like(Xout)
         try:
-            check(lib().gla_jacobi_fused_residual(self._h, dtype_code(X0.dtype), None if diag_is_matrix_diagonal else ptr(diag),
-                                                  ptr(B), ptr(x), ptr(Xout), ptr(R), float(w), last, stream_ptr(self.device)))
+            rc = lib().gla_jacobi_fused_residual(self._h, dtype_code(X0.dtype), None if diag_is_matrix_diagonal else ptr(diag),
+                                                 ptr(B), ptr(x), ptr(Xout), ptr(R), float(w), last, stream_ptr(self.device))
+            if rc == -1 and diag_is_matrix_diagonal:         # (as in jacobi_sweeps: the plan's kernels want the array)
+                rc = lib().gla_jacobi_fused_residual(self._h, dtype_code(X0.dtype), ptr(diag), ptr(B), ptr(x), ptr(Xout), ptr(R),
+                                                     float(w), last, stream_ptr(self.device))
+            check(rc)
         except GlaError as err:
             if err.code == -5:                               # GLA_ERR_UNSUPPORTED (small matrix, options)
                 return None
