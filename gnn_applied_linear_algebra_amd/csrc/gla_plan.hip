@@ -804,7 +804,7 @@ gla_tuning g_tuning;
 
 extern "C" {
 
-int gla_version(void) { return 140; }   // 100: round-1 core; 110: + edge_attr, segment_stats, edge_dot, mlp_relu3; 140: + gla_comm_probe, option sym, dia_sym
+int gla_version(void) { return 140; }   // 100: round-1 core; 110: + edge_attr, segment_stats, edge_dot, mlp_relu3; 140: + gla_comm_probe, options sym / full_mask, dia_sym, dia_full
 
 int gla_set_option(const char* name, int64_t value) {
   if (!name) return GLA_ERR_INVALID_ARG;
