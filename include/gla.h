@@ -162,7 +162,11 @@ int gla_jacobi_sweep(gla_csr_t A, int dtype, int K, const void* diag, const void
 /* n_iters sweeps ping-ponging between Xout and Xtmp so that the last sweep lands in Xout; X0 is not
  * mutated.  JacobiGNN.forward, JacobiGNN.py:138-148.  Square plans only.  On 2-D stencil plans the sweeps are taken several
  * at a time in one pass over the data (temporal blocking, bit-identical: see gla_jacobi_sweeps_schedule for K = 1; K right-hand
- * sides that fill whole 16-byte vectors take up to five sweeps per pass on canonical 5-point plans, three on 9-point plans). */
+ * sides that fill whole 16-byte vectors take up to five sweeps per pass on canonical 5-point plans, three on 9-point plans).
+ * diag == NULL: "A_ii is this plan's matrix diagonal" (what the reference always passes: JacobiGNN.py:160-170, VCycle.py:160-166).
+ * Accepted for K = 1 on canonical 5- / 9-point plans whose schedule for n_iters consists of march passes only (every pass of two
+ * sweeps or more, option "jacobi_march" on): the passes then take A_ii from the centre coefficient and stream no A_ii array;
+ * GLA_ERR_INVALID_ARG otherwise, before anything is enqueued -- call again with the array. */
 int gla_jacobi_sweeps(gla_csr_t A, int dtype, int K, const void* diag, const void* B, int64_t ldb,
                       const void* X0, int64_t ldx0, void* Xout, void* Xtmp, int64_t ldw, double w,
                       int n_iters, gla_stream_t stream);
