@@ -82,6 +82,8 @@ def parse_args(argv=None):
                     help="rehearsal only: all ranks share cuda:0 (needs --backend gloo)")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="parent only: print the child command lines + environment as JSON and exit")
+    ap.add_argument("--stack-dump-s", type=float, default=20.0,
+                    help="N > 1: rank 0 dumps its Python stacks to stderr every so many seconds (0: never)")
     ap.add_argument("--child-timeout", type=float, default=1500.0, help="parent: seconds before the ranks are killed")
     return ap.parse_args(argv)
 
@@ -217,11 +219,13 @@ def cpu_baseline(n_grid, sweeps):
 
 
 def measure_traffic(n_grid, timeout_s):
-    """HBM bytes per launch of the dominant Jacobi kernel from the PMC counters, measured NOW on this box: two child runs of
-    `rocprofv3 --pmc <counter> -- python3 tools/pmc_workload.py N` (FETCH_SIZE, WRITE_SIZE: separate passes, KiB units,
+    """HBM bytes per launch of EVERY Jacobi pass of the module step from the PMC counters, measured NOW on this box: two child runs
+    of `rocprofv3 --pmc <counter> -- python3 tools/pmc_workload.py N` (FETCH_SIZE, WRITE_SIZE: separate passes, KiB units,
     FETCH_SIZE x 2 on gfx950 -- MI355X_MICROARCH.md, HBM section; the factor is checked against the workload's calibration
-    kernel of known volume).  Returns a dict, or {"error": ...}.  The children are started as ordinary subprocesses of this
-    (GPU-initialised) process -- nothing is exec'ed in place -- and stopped by PID on a time-out."""
+    kernel of known volume), plus a third child run with --kernel-trace only (no counters) for the in-step duration of every
+    pass instance.  Returns a dict (the dominant plain pass at top level, every instance under "instances"), or {"error": ...}.
+    The children are started as ordinary subprocesses of this (GPU-initialised) process -- nothing is exec'ed in place -- and
+    stopped by PID on a time-out."""
     import csv
     import glob
     import re
@@ -234,11 +238,26 @@ def measure_traffic(n_grid, timeout_s):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    vals = {}
+
+    def kernel_key(name):
+        """("jacobi", sweeps per launch, "plain" | "aos" | "res") of a Jacobi kernel name, ("calib", 0, "") of the calibration copy"""
+        m = re.search(r"jacobi_march5_kernel<\w+,\s*(\d+),\s*(\d+)", name)
+        if m:
+            return ("jacobi", int(m.group(1)), ("plain", "aos", "res")[min(int(m.group(2)), 2)])
+        m = re.search(r"jacobi_fused_dia2d_kernel<\w+,\s*\d+,\s*(\d+)(?:,\s*(\w+))?", name)
+        if m:
+            return ("jacobi", int(m.group(1)), "aos" if (m.group(2) or "") in ("true", "1") else "plain")
+        if "EpiJacobi" in name:
+            return ("jacobi", 1, "plain")
+        if "CUDAFunctor_add" in name:
+            return ("calib", 0, "")
+        return None
+
+    vals, inst = {}, {}
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", None):
+            d = os.path.join(tmp, ctr or "trace")
+            cmd = [exe] + (["--pmc", ctr] if ctr else []) + ["--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
                    sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), str(n_grid)]
             pr_ = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             try:
@@ -246,51 +265,87 @@ def measure_traffic(n_grid, timeout_s):
             except subprocess.TimeoutExpired:
                 pr_.kill()
                 pr_.wait()
-                return {"error": f"rocprofv3 --pmc {ctr} pass timed out after {timeout_s:.0f} s"}
+                return {"error": f"rocprofv3 {'--pmc ' + ctr if ctr else '--kernel-trace'} pass timed out after {timeout_s:.0f} s"}
             if rc != 0:
-                return {"error": f"rocprofv3 --pmc {ctr} pass exited with {rc}"}
+                return {"error": f"rocprofv3 {'--pmc ' + ctr if ctr else '--kernel-trace'} pass exited with {rc}"}
+            if ctr is None:                                  # durations of every pass instance inside the step (no counters attached)
+                for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        key = kernel_key(r["Kernel_Name"])
+                        if key and key[0] == "jacobi":
+                            inst.setdefault(key, {}).setdefault("us", []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+                continue
             rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
             cover, per = {}, {}
             for r in rows:
-                name = r["Kernel_Name"]
-                m = re.search(r"jacobi_march5_kernel<\w+,\s*(\d+),\s*(\d+)", name)
-                if m and int(m.group(2)) != 0:               # (the AoS first pass / residual pass: not the dominant kernel)
-                    continue
-                m = m or re.search(r"jacobi_fused_dia2d_kernel<\w+,\s*\d+,\s*(\d+)", name)
-                key = None
-                if m:
-                    key = ("jacobi", int(m.group(1)))
-                elif "EpiJacobi" in name:
-                    key = ("jacobi", 1)
-                elif "CUDAFunctor_add" in name:
-                    key = ("calib", 0)
+                key = kernel_key(r["Kernel_Name"])
                 if key:
                     per.setdefault(key, []).append(float(r["Counter_Value"]))
-                    if key[0] == "jacobi":
+                    if key[0] == "jacobi" and key[2] == "plain":      # (the dominant kernel is picked among the plain passes)
                         cover[key] = cover.get(key, 0) + key[1]
-            if not cover or ("calib", 0) not in per:
+            if not cover or ("calib", 0, "") not in per:
                 return {"error": f"no Jacobi / calibration kernel rows in the {ctr} pass"}
             dom = max(cover, key=lambda k: (cover[k], k[1]))
-            vals[ctr] = (dom[1], sum(per[dom]) / len(per[dom]), sum(per[("calib", 0)]) / len(per[("calib", 0)]), len(per[dom]))
-        spl_f, fetch_kib, calib_f, nl = vals["FETCH_SIZE"]
-        spl_w, write_kib, calib_w, _ = vals["WRITE_SIZE"]
-        if spl_f != spl_w:
+            calib = sum(per[("calib", 0, "")]) / len(per[("calib", 0, "")])
+            vals[ctr] = (dom, calib, len(per[dom]))
+            for key, v in per.items():
+                if key[0] == "jacobi":
+                    inst.setdefault(key, {})[ctr] = sum(v) / len(v)
+        dom_f, calib_f, nl = vals["FETCH_SIZE"]
+        dom_w, calib_w, _ = vals["WRITE_SIZE"]
+        if dom_f != dom_w:
             return {"error": "the two passes disagree on the dominant kernel"}
         fetch_factor = 2 * 512 * 1024 / calib_f          # the calibration kernel reads 2 x 512 MiB, writes 512 MiB
         write_factor = 512 * 1024 / calib_w
         if not (1.8 < fetch_factor < 2.2 and 0.9 < write_factor < 1.1):
             return {"error": f"calibration kernel off: fetch x{fetch_factor:.3f}, write x{write_factor:.3f}"}
-        rd, wr = fetch_kib * 1024 * 2.0, write_kib * 1024
-        return {"sweeps_per_launch": spl_f, "launches_averaged": nl, "hbm_read_bytes_per_launch": int(rd),
+        instances = []
+        for key in sorted(inst, key=lambda k: (k[2] != "aos", -k[1])):
+            v = inst[key]
+            if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+                continue
+            rd_, wr_ = v["FETCH_SIZE"] * 1024 * 2.0, v["WRITE_SIZE"] * 1024
+            us = sorted(v.get("us", []))
+            instances.append({"sweeps_per_launch": key[1], "kind": key[2], "hbm_read_bytes": int(rd_), "hbm_write_bytes": int(wr_),
+                              "hbm_bytes": int(rd_ + wr_), "in_step_us_kernel_trace": round(sum(us) / len(us), 2) if us else None,
+                              "launches_traced": len(us)})
+        d_ = inst[dom_f]
+        rd, wr = d_["FETCH_SIZE"] * 1024 * 2.0, d_["WRITE_SIZE"] * 1024
+        return {"sweeps_per_launch": dom_f[1], "launches_averaged": nl, "hbm_read_bytes_per_launch": int(rd),
                 "hbm_write_bytes_per_launch": int(wr), "hbm_bytes_per_launch": int(rd + wr),
                 "calibration_fetch_factor_measured": round(fetch_factor, 4),
-                "calibration_write_factor_measured": round(write_factor, 4)}
+                "calibration_write_factor_measured": round(write_factor, 4), "instances": instances}
     except Exception as exc:                                 # (a measurement aid: never the reason a bench run fails)
         return {"error": f"{type(exc).__name__}: {exc}"[:300]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pass_row_bytes(D, n_sym, no_mask, kind, a_ii_streamed, flagged=True):
+    """Bytes ONE ROW moves in one pass of the stencil Jacobi kernels with the layout the plan really has: 8 per diagonal that is
+    read (D - n_sym: a symmetric value set reads its lower diagonals from their upper partners), 2 of row mask unless the plan
+    is a full stencil (no_mask), and
+      plain pass : b, x in, x out (+ A_ii unless it is taken from the centre coefficient)
+      AoS pass   : the 24-byte AoS row [A_ii, b, x] in; x out and the contiguous copy of b (flag flow) / of A_ii and b out."""
+    mat = 8 * (D - n_sym) + (0 if no_mask else 2)
+    if kind == "aos":
+        return mat + 24 + 8 + (8 if flagged else 16)
+    return mat + 24 + (8 if a_ii_streamed else 0)
+
+
+def step_layout(info, sched, dg_center, aos_first):
+    """[(kind, sweeps, bytes per row)] of the passes behind one JacobiGNN.forward on a canonical 5-point march plan"""
+    D = int(info.dia)
+    march5 = int(info.dia_canon5) == 1
+    n_sym = bin(int(info.dia_sym)).count("1") if march5 else 0
+    no_mask = bool(n_sym and int(getattr(info, "dia_full", 0)))
+    out = []
+    for i, ts in enumerate(sched):
+        kind = "aos" if (i == 0 and aos_first) else "plain"
+        out.append((kind, ts, pass_row_bytes(D, n_sym, no_mask, kind, not dg_center, flagged=dg_center)))
+    return out
 
 
 def median(xs):
@@ -373,7 +428,15 @@ def single_gpu(args, gla, dev):
     # kernel is ~10 % slower in the first tens of milliseconds of a process: profiles/r04/clock_ramp.txt).  W = 5 warm-up steps
     # are 3.5 ms.  The step is therefore run untimed for --ramp-ms of wall time first (exactly what a production loop sees
     # after its first moments); the W warm-up steps and the K timed steps of the contract follow unchanged.
+    no_ramp = None
     if args.ramp_ms > 0:
+        # ... and the contract's protocol WITHOUT it first (W warm-up + K timed steps straight after the plan was built: what
+        # BENCH_r01..r03 measured), reported beside the headline as `no_clock_ramp`
+        el0, ms0 = timed_steps(step, args.steps, args.warmup)
+        no_ramp = {"what": f"the same {args.steps} steps after {args.warmup} warm-up steps and NO clock ramp (the protocol of rounds 1-3), "
+                           "measured in this process before the ramp",
+                   "value": round(args.steps * args.sweeps / el0, 2), "unit": "sweeps/s", "ms_per_step": round(1e3 * el0 / args.steps, 4),
+                   "ms_per_step_median": round(median(ms0), 4)}
         t_end = time.perf_counter() + args.ramp_ms * 1e-3
         while time.perf_counter() < t_end:
             for _ in range(5):
@@ -489,6 +552,41 @@ def single_gpu(args, gla, dev):
         roof["pmc"] = pmc
     if traffic is not None:
         roof["traffic_over_layout"] = round(traffic / Bl, 4)
+    # The WHOLE STEP: every pass behind one JacobiGNN.forward with its own bytes and time -- the dominant kernel above is the plain
+    # 7-sweep pass, but the pass with the largest share of the step is the AoS first pass (it reads the 24-byte AoS rows and writes
+    # the contiguous copy of b: 64 instead of 48 bytes per row).  bytes = PMC traffic of each instance where measured in this run
+    # (else the layout's bytes), time = the contract's ms_per_step; per pass: the instance's average duration inside the step from
+    # the --kernel-trace child pass.
+    ms_step = 1e3 * elapsed / args.steps
+    step_bytes, step_bytes_is = moved * launches, "dominant kernel's bytes x launches (no per-pass figures)"
+    if fused and int(info.dia) > 0 and not bool(info.packed):
+        lay = step_layout(info, sched, dg_center, aos_first=True)
+        by = {(i_["kind"], i_["sweeps_per_launch"]): i_ for i_ in (pmc or {}).get("instances", [])} if pmc and "error" not in pmc else {}
+        passes_rec, tot_pmc, tot_lay, all_pmc = [], 0, 0, True
+        for kind, ts_, rb in lay:
+            i_ = by.get((kind, ts_))
+            rec_ = {"kernel": (f"jacobi_march{5 if int(info.dia_canon5) == 1 else 9}_kernel" if march else "jacobi_fused_dia2d_kernel")
+                              + f"<double,{ts_}>" + (" AoS first pass (MODE 1)" if kind == "aos" else ""),
+                    "sweeps": ts_, "layout_bytes_per_row": rb, "layout_bytes": rb * pr.n_local}
+            tot_lay += rb * pr.n_local
+            if i_ is not None:
+                rec_.update({"hbm_bytes": i_["hbm_bytes"], "hbm_read_bytes": i_["hbm_read_bytes"], "hbm_write_bytes": i_["hbm_write_bytes"],
+                             "in_step_us": i_["in_step_us_kernel_trace"],
+                             "frac": None if not i_["in_step_us_kernel_trace"] else round(i_["hbm_bytes"] / (i_["in_step_us_kernel_trace"] * 1e-6) / HBM_PEAK, 4)})
+                tot_pmc += i_["hbm_bytes"]
+            else:
+                all_pmc = False
+            passes_rec.append(rec_)
+        if all_pmc and passes_rec:
+            step_bytes, step_bytes_is = tot_pmc, "PMC traffic of every pass of the step, measured in this run (rocprofv3 --pmc child passes)"
+        else:
+            step_bytes, step_bytes_is = tot_lay, "layout bytes of every pass of the step"
+        roof["whole_step"] = {"bytes": int(step_bytes), "bytes_is": step_bytes_is, "layout_bytes": int(tot_lay), "ms_per_step": round(ms_step, 4),
+                              "achieved": round(step_bytes / (ms_step * 1e-3) / 1e9, 1), "unit": "GB/s",
+                              "frac": round(step_bytes / (ms_step * 1e-3) / HBM_PEAK, 4),
+                              "in_step_us_is": "average duration of the instance over the launches of a rocprofv3 --kernel-trace child run of "
+                                               "the same step (no counters attached)",
+                              "passes": passes_rec}
 
     out = {
         "metric": "Jacobi-GNN sweeps/sec (2D Laplacian, fp64)", "value": round(total_sweeps / elapsed, 2),
@@ -499,12 +597,43 @@ def single_gpu(args, gla, dev):
                                f"{Nx}x{Nx} vertices per GPU (global grid {Nx}x{Nx}), fp64, w=0.7",
                    "N": Nx, "rows_per_gpu": pr.n_local, "nnz_per_gpu": pr.nnz, "sweeps_per_step": args.sweeps,
                    "clock_ramp_ms": args.ramp_ms,
-                   "bytes_moved_GBps_whole_step": round(moved * launches * args.steps / elapsed / 1e9, 1),
+                   "bytes_moved_GBps_whole_step": round(step_bytes * args.steps / elapsed / 1e9, 1),
+                   "bytes_moved_whole_step_is": step_bytes_is,
                    "model_equivalent_GBps_whole_step": round(pr.B * total_sweeps / elapsed / 1e9, 1)},
         "roofline": roof,
     }
+    if no_ramp is not None:
+        out["value_protocol"] = (f"{args.ramp_ms:.0f} ms of untimed steps (clock ramp of the card's power management), then the contract's "
+                                 f"{args.warmup} warm-up + {args.steps} timed steps; `no_clock_ramp` = the same without the ramp")
+        out["no_clock_ramp"] = no_ramp
     default_layout = not (args.compress or args.no_col16 or args.no_dia)
     side = default_layout and not args.no_side
+    # ---- side: setup in front of the step ("COO -> CSR and AoS <-> SoA reported separately") ------------------
+    if side:
+        def timed_ms(fn, reps=3):
+            ts_ = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                r_ = fn()
+                torch.cuda.synchronize()
+                ts_.append(1e3 * (time.perf_counter() - t0_))
+                del r_
+            return median(ts_)
+        ei_s = pr.ei.clone()
+        plans_ = []
+        t_plan = timed_ms(lambda: plans_.append(gla.CsrPlan(ei_s, pr.n_local)) or 0)
+        t_vals = timed_ms(lambda: plans_[-1].set_values(pr.edge_attr))
+        t_graph = timed_ms(lambda: gla.UtilsGNN.laplacianfun_torch(Nx, device=dev))
+        del plans_, ei_s
+        out["setup"] = {
+            "what": "once per graph, outside the timed step (the reference re-discovers the rows inside every scatter call and re-coalesces "
+                    "per smoother call, VCycle.py:63,141,157); host wall time incl. a device synchronise, median of 3",
+            "graph_builder_ms": round(t_graph, 3), "coo_to_plan_ms": round(t_plan, 3), "set_values_ms": round(t_vals, 3),
+            "aos_to_soa": "no separate pass: the first pass of gla_jacobi_sweeps_aos reads the AoS rows itself (its 16 extra bytes per row "
+                          "are in roofline.whole_step.passes[0])",
+            "steps_to_amortise_plan_and_values": round((t_plan + t_vals) / ms_step, 1)}
+        torch.cuda.empty_cache()
 
     # ---- side: the opt-in packed matrix stream (value-dependent; bit-identical) -------------------------------------
     if side and not args.no_optin:
@@ -544,12 +673,15 @@ def single_gpu(args, gla, dev):
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 1e-3 / args.sweeps)
             tl = median(ts)
-            Bl = (8 * int(info.dia) + 2 + 32) * pr.n_local
+            n_sym1 = bin(int(info.dia_sym)).count("1")     # spmv_dia_kernel reads the lower diagonals of a symmetric value set from their partners
+            rb1 = 8 * (int(info.dia) - n_sym1) + 2 + 32
+            Bl = rb1 * pr.n_local
             out["one_sweep_per_pass"] = {
                 "what": "same step with option jacobi_fuse=0: spmv_dia_kernel<double,EpiJacobi>, one launch per sweep",
                 "value": round(total_sweeps / el, 2), "unit": "sweeps/s", "launch_us": round(tl * 1e6, 2),
                 "achieved": round(Bl / tl / 1e9, 1), "frac": round(Bl / tl / HBM_PEAK, 4),
-                "bytes_moved_is": f"layout bytes of one pass ({8 * int(info.dia) + 34} B per row)", "layout_bytes_per_launch": Bl,
+                "bytes_moved_is": f"layout bytes of one pass ({rb1} B per row: {int(info.dia) - n_sym1} diagonals read, mask, A_ii, b, x in, x out)",
+                "layout_bytes_per_launch": Bl,
                 "pass_model_frac": round(pr.B / tl / HBM_PEAK, 4), "bit_identical_to_default": same}
         finally:
             check(L.gla_set_option(b"jacobi_fuse", 1))
@@ -686,12 +818,17 @@ def single_gpu(args, gla, dev):
             p4 = Problem(gla, 8192, 8192, 0, 8192 * 8192, dev, 24601)
             el4, ms4 = timed_steps(lambda: jac(args.sweeps, p4.vertex_attr, p4.ei, p4.edge_attr, p4.g), 3, 1)
             t4 = median(ms4) * 1e-3 / args.sweeps
-            m4 = (8 * 5 + 2 + 32) * p4.n_local * launches / args.sweeps           # bytes moved per sweep: one pass per launch
+            plan4 = gla.plan_for(p4.ei, p4.n_local, edge_attr=p4.edge_attr)
+            lay4 = step_layout(plan4.info, plan4.jacobi_schedule(args.sweeps), dg_center, aos_first=True)
+            m4 = sum(rb for _, _, rb in lay4) * p4.n_local / args.sweeps          # bytes moved per sweep with the layout the passes really read
             out["config4_1gpu"] = {"what": "JacobiGNN.forward, 20 sweeps, 8192^2 Laplacian fp64 on one GPU",
                                    "value": round(1.0 / t4, 2), "unit": "sweeps/s", "us_per_sweep": round(t4 * 1e6, 1),
+                                   "ms_per_step": round(t4 * args.sweeps * 1e3, 4),
                                    "achieved": round(m4 / t4 / 1e9, 1), "frac": round(m4 / t4 / HBM_PEAK, 4),
-                                   "bytes_moved_is": f"layout bytes: {launches} passes of 74 B per row per {args.sweeps} sweeps",
+                                   "bytes_moved_is": "layout bytes: passes of " + " + ".join(f"{rb} ({k}, {ts_} sweeps)" for k, ts_, rb in lay4)
+                                                     + f" B per row per {args.sweeps} sweeps",
                                    "model_ratio": round(p4.B / t4 / HBM_PEAK, 4)}
+            del plan4
             del p4
             torch.cuda.empty_cache()
 
@@ -700,21 +837,10 @@ def single_gpu(args, gla, dev):
         # ncclAllGather on the library's stream, interior line blocks, ghost fill + edge blocks on a second stream.  Its
         # ratio to `value` is what weak scaling can reach before inter-GPU latency (tools/bench_dist_selfhalo.py)
         try:
-            import types
-            from gnn_applied_linear_algebra_amd.dist import LibComm, RowBlockJacobi
-            T_ = RowBlockJacobi.TS_MAX
+            from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi
             Nn = args.n
-            ei_e, ev_e = gla.UtilsGNN.laplacianfun_torch(Nn, Ny=Nn + 2 * T_, device=dev)
-            plan_e = gla.CsrPlan(ei_e, Nn * (Nn + 2 * T_))
-            plan_e.set_values(ev_e)
-            del ei_e, ev_e
-            drv = RowBlockJacobi.__new__(RowBlockJacobi)
-            comm_ = LibComm()
-            drv.comm, drv.overlap, drv._ghost_pending = comm_, True, None
-            drv.part = types.SimpleNamespace(world=1, rank=0, n_local=Nn * Nn, group=None)
-            drv._sched = plan_e.jacobi_schedule
-            drv.ext = dict(plan=plan_e, S=Nn, n_ext=Nn * (Nn + 2 * T_), off=Nn * T_, up=True, down=True, slab=T_ * Nn,
-                           dtype=torch.float64, dev=dev, up_src=0, down_src=0)
+            drv = RowBlockJacobi.rehearsal_self_halo(Nn, Nn, dev)
+            comm_, plan_e = drv.comm, drv.ext["plan"]
             va_d = pr.vertex_attr
             eld, msd = timed_steps(lambda: drv.forward(args.sweeps, va_d, pr.g), 20, 3)
             td = median(msd) * 1e-3
@@ -732,11 +858,8 @@ def single_gpu(args, gla, dev):
 
                     def k_driver(cls):
                         d_ = cls.__new__(cls)
-                        d_.comm, d_.overlap, d_._ghost_pending, d_._lib_send = comm_, True, None, {}
-                        d_.part = types.SimpleNamespace(world=1, rank=0, n_local=Nn * Nn, group=None, n_in=Nn * Nn, S=0)
-                        d_._sched = plan_e.jacobi_schedule
-                        d_.ext = dict(plan=plan_e, S=Nn, n_ext=Nn * (Nn + 2 * T_), off=Nn * T_, up=True, down=True, slab=T_ * Nn,
-                                      dtype=torch.float64, dev=dev, up_src=0, down_src=0)
+                        d_.__dict__.update(drv.__dict__)
+                        d_._lib_send, d_._ghost_pending, d_.ext = {}, None, dict(drv.ext)
                         return d_
                     genk = torch.Generator().manual_seed(7)
                     vj = torch.rand(Nn * Nn, 3, K16, generator=genk, dtype=torch.float64).to(dev)
@@ -788,6 +911,10 @@ def single_gpu(args, gla, dev):
         # ---- side: config 5 is "8 x MI355X": a rank's share of the distributed cycle rehearsed on this GPU (child process: it
         # needs a one-rank RCCL process group of its own)
         out["dist_vcycle_one_rank"] = side_dist_vcycle(120.0)
+        # ---- side: BASELINE config 4's REAL 8-rank block (1024 lines x 8192 points) over a one-rank RCCL communicator, eager and
+        # replayed from a HIP graph, next to the whole 8192^2 matrix on this GPU (child process: tools/bench_dist_config4_block.py)
+        out["dist_route_one_gpu_config4_block"] = side_child_json([os.path.join(ROOT, "tools", "bench_dist_config4_block.py"), "8192", "8",
+                                                                    str(args.sweeps), "--json"], 240.0)
         # ---- side: non-stencil matrices through the CSR-adaptive kernels (stream / vector / long bins) ----------------------
         try:
             out["csr_irregular"] = side_irregular(gla, dev)
@@ -856,16 +983,40 @@ def side_config5(gla, dev, m):
     return rec
 
 
-def _row_bytes(drv, blocked):
-    """Bytes a 5-point row moves per pass of a row-block driver: 8 per diagonal read (3 of the 5 where the block's value set is
-    symmetric and its passes are the temporally blocked ones: option "sym"), 2 of mask, b, A_ii, x in, x out."""
-    n_sym, mask_b = 0, 2
+def _row_bytes(drv, blocked, sweeps=None):
+    """Bytes a 5-point row of a row-block driver moves per STEP of `sweeps` sweeps divided by the passes it takes (i.e. the average
+    per pass), from the layout its passes really read: the temporally blocked route runs the single-GPU path's kernels on the
+    extended block (step_layout: symmetric value sets read 3 of 5 diagonals, full stencils no masks, the first pass reads the
+    AoS rows, the later ones take A_ii from the centre coefficient where the call's flag stays clean -- the bench's A_ii IS the
+    diagonal); the exchange-per-sweep route streams 5 diagonals, the mask, A_ii, b, x in, x out."""
     ext = getattr(drv, "ext", None)
-    if blocked and ext is not None and ext.get("plan") is not None:
-        n_sym = bin(int(ext["plan"].info.dia_sym)).count("1")
-        if n_sym and int(getattr(ext["plan"].info, "dia_full", 0)):
-            mask_b = 0
-    return 8 * (5 - n_sym) + mask_b + 32
+    if blocked and ext is not None and ext.get("plan") is not None and sweeps:
+        info = ext["plan"].info
+        sched = drv._sched(sweeps)
+        flag_flow = bool(int(info.dia_canon5) == 1 and bin(int(info.dia_sym)).count("1") and int(getattr(info, "dia_full", 0))
+                         and min(sched) >= 2 and len(sched) >= 2)
+        lay = step_layout(info, sched, flag_flow, aos_first=True)
+        return sum(rb for _, _, rb in lay) / len(lay)
+    return 8 * 5 + 2 + 32
+
+
+def side_child_json(argv, timeout_s):
+    """Run a tool as a child process (its own RCCL process group / communicator) and return the JSON object it prints last."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() + 7) % 400))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        pr_ = subprocess.Popen([sys.executable] + list(argv), env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        try:
+            so, _ = pr_.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            pr_.kill()
+            pr_.wait()
+            return {"error": f"timed out after {timeout_s:.0f} s"}
+        lines = [ln for ln in so.decode(errors="replace").splitlines() if ln.startswith("{")]
+        return json.loads(lines[-1]) if pr_.returncode == 0 and lines else {"error": f"child exited with {pr_.returncode}"}
+    except Exception as exc:                                 # (a side record: never the reason a bench run fails)
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
 
 def side_dist_vcycle(timeout_s):
@@ -1005,11 +1156,11 @@ def multi_gpu(args, gla, dev, world, rank):
     # bytes a rank moves per step: one pass over its block (74 B per row: values, mask, b, A_ii, x in, x out) per launch
     sched_fn = getattr(drv, "_sched", None)
     passes = len(sched_fn(args.sweeps)) if sched_fn is not None and drv.mode.startswith("temporally blocked") else args.sweeps
-    row_b = _row_bytes(drv, passes < args.sweeps)
+    row_b = _row_bytes(drv, passes < args.sweeps, args.sweeps)
     moved_sweep = row_b * pr.n_local * passes / args.sweeps
     roof = {"bound": "hbm", "achieved": round(moved_sweep / t_sweep / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(moved_sweep / t_sweep / HBM_PEAK, 4), "traffic": None,
-            "bytes_moved_is": f"layout bytes per rank: {passes} passes of {row_b} B per row per {args.sweeps} sweeps",
+            "bytes_moved_is": f"layout bytes per rank: {passes} passes of {row_b:.1f} B per row on average per {args.sweeps} sweeps",
             "kernel": "per-rank step incl. halo exchange (interior + boundary launches), per sweep",
             "passes_per_step": passes, "algorithmic_bytes_per_sweep": pr.B,
             "model_ratio": round(pr.B / t_sweep / HBM_PEAK, 4), "avg_launch_us": round(t_sweep * 1e6 * args.sweeps / passes, 2)}
@@ -1048,7 +1199,7 @@ def multi_gpu(args, gla, dev, world, rank):
                "aggregate_model_equivalent_GBps": round(B4_global / t4 / 1e9, 1)}
         sf4 = getattr(d4, "_sched", None)
         ps4 = len(sf4(args.sweeps)) if sf4 is not None and d4.mode.startswith("temporally blocked") else args.sweeps
-        m4 = _row_bytes(d4, ps4 < args.sweeps) * p4.n_local * ps4 / args.sweeps
+        m4 = _row_bytes(d4, ps4 < args.sweeps, args.sweeps) * p4.n_local * ps4 / args.sweeps
         rec.update({"bytes_moved_GBps_per_gpu": round(m4 / t4 / 1e9, 1), "frac_per_gpu": round(m4 / t4 / HBM_PEAK, 4),
                     "passes_per_step": ps4})
         del p4, d4
@@ -1092,9 +1243,15 @@ def worker(args):
     sys.stdout.flush()
     _JSON_FD = os.dup(1)
     os.dup2(2, 1)
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # a slow phase must say WHERE it is: rank 0 of a multi-rank run dumps its Python stacks to stderr every --stack-dump-s seconds
+    # (faulthandler: a watchdog thread, no cost to the run); round 4's fresh-box rehearsal sat 27-98 s in setup phases nobody
+    # could name afterwards
+    if args.stack_dump_s > 0 and world > 1 and rank == 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.stack_dump_s, repeat=True, file=sys.stderr)
+    import torch
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

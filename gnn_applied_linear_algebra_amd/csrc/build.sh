@@ -24,6 +24,8 @@ echo "built $(realpath $OUT)"
 # nothing in it; 12 s).  Part of every build -- a hit fails it; GLA_ISA_CHECK=0 skips the scan.
 if [ "${GLA_ISA_CHECK:-1}" != "0" ]; then
   ../../tools/check_isa.sh
-  # ... and the headline kernel's line steps for a wait / branch inside their load sequence (tools/check_prefetch_isa.py, 12 s)
-  python3 ../../tools/check_prefetch_isa.py gla_march5.o
+  # ... and the headline kernel's line steps for a wait / branch inside their load sequence (tools/check_prefetch_isa.py, 12 s).
+  # A PERFORMANCE lint (results stay bit-identical through such an accident): a warning here, never a failed build -- the hard
+  # gate for it is tests/test_isa_cpu.py (which skips when llvm-objdump is absent)
+  python3 ../../tools/check_prefetch_isa.py gla_march5.o || echo "WARNING: check_prefetch_isa.py flagged gla_march5.o (performance lint; the library is built)" >&2
 fi

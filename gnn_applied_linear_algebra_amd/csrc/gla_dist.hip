@@ -340,7 +340,7 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
   int* dg_flag = nullptr;
   int dg_epoch = 0;
   if (g_tuning.jacobi_diag_flag && gla_dia_sym5(A) && gla_dia_full5(A) && A->dia_val) {
-    rc = gla_jacobi_dg_slot(A, &dg_flag, &dg_epoch);
+    rc = gla_jacobi_dg_slot(A, (hipStream_t)main_stream, &dg_flag, &dg_epoch);
     if (rc) return rc;
   }
   auto parts = [&](const void* dg, const void* bb, const void* xin, void* xout, int ts, int part, hipStream_t st) -> int {

@@ -24,6 +24,7 @@ constexpr int GLA_LONG_ROW = GLA_LDS_ELEMS_MAX - GLA_TILE_NNZ_MIN;
 // K = 1 CSR stream kernel: rows of this many nonzeros or more are summed by their wave (64 fixed chunks + xor tree; option row_sum)
 constexpr int GLA_WAVE_ROW = 64;
 constexpr int GLA_DG_SLOTS = 64;        // calls of gla_jacobi_sweeps_aos that may be in flight on ONE plan at a time (on different streams)
+constexpr int GLA_DG_CAPTURE_SLOTS = 192;   // ... and calls captured into HIP graphs over the plan's lifetime (a flag word each)
 
 struct gla_csr {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
@@ -56,6 +57,7 @@ struct gla_csr {
   void* dia_val = nullptr;       // [dia_D][n_rows] values, diagonal-major (0 where the row has no entry)
   int* dg_flags = nullptr;       // [GLA_DG_SLOTS] device words of gla_jacobi_sweeps_aos' "A_ii is not the matrix diagonal" flags: call k uses
   uint32_t dg_calls = 0;         // word k mod GLA_DG_SLOTS and stores k there to raise it (never reset; guarded by dg_mutex)
+  int32_t dg_captured = 0;       // words [GLA_DG_SLOTS, +GLA_DG_CAPTURE_SLOTS) handed to calls captured into HIP graphs, one each
   int32_t dia_sym = 0;           // bit d set: diagonal d (offset < 0) repeats its partner of offset -off bit for bit, A[r][r + off] ==
                                  // A[r + off][r] for every row (0 where r + off < 0): the kernels need not read it (option "sym")
   int32_t dia_full = 0;          // canonical 5-point plans: 1 = EVERY row couples to every grid neighbour it has (its mask is the one its
@@ -164,7 +166,7 @@ int gla_march5_pass(const gla_march5_args& a);
 // (gla_rows.hip); otherwise the status it would return.  For callers that must know BEFORE they enqueue anything (gla_dist.hip).
 int gla_jacobi_parts_status(const gla_csr* A, int dtype, int sweeps);
 // the A_ii flag word and number of one call, and the march passes that raise / obey it (gla_rows.hip; for gla_dist.hip)
-int gla_jacobi_dg_slot(gla_csr* A, int** flag, int* epoch);
+int gla_jacobi_dg_slot(gla_csr* A, hipStream_t st, int** flag, int* epoch);
 int gla_jacobi_parts_flagged(gla_csr* A, int dtype, const void* va, int64_t ldva, int64_t row_offset, int64_t n_attr_rows,
                              const void* diag, const void* B, const void* X, void* diag_out, void* b_out, void* Xout, double w,
                              int sweeps, int part, int ghost_lines, int* dg_flag, int dg_epoch, hipStream_t st);

@@ -1823,13 +1823,28 @@ std::mutex g_dg_mutex;                               // guards every plan's dg_f
 }  // namespace
 
 // The "A_ii is not the matrix diagonal" flag of ONE call (gla_jacobi_sweeps_aos, gla_dist_jacobi_temporal).  The flags live in
-// the plan (GLA_DG_SLOTS words, zero when allocated): call number k uses word k mod GLA_DG_SLOTS and stores k into it to raise
-// it, so no word ever has to be reset -- a memset in front of every call was 15-19 us of launch gap per step.
-int gla_jacobi_dg_slot(gla_csr* A, int** flag, int* epoch) {
+// the plan (zero when allocated).  EAGER calls: call number k uses word k mod GLA_DG_SLOTS and stores k into it to raise it, so no
+// word ever has to be reset -- a memset in front of every call was 15-19 us of launch gap per step.  A call made while `st` is
+// being CAPTURED into a HIP graph would freeze its word and its number into the graph, and a replay could then meet an eager call
+// k + 64 j on the same word: a captured call gets a word of its own for the plan's lifetime (GLA_DG_CAPTURE_SLOTS of
+// them; GLA_ERR_UNSUPPORTED once they are used up), the number 1, and a memset NODE in front of its first pass -- inside a graph
+// that is an edge, not a launch gap.  The words are allocated at the first eager call (hipMalloc is not capturable; a capture
+// of a plan that has never run eagerly is refused: callers warm up first, as torch's graph capture requires anyway).
+int gla_jacobi_dg_slot(gla_csr* A, hipStream_t st, int** flag, int* epoch) {
   std::lock_guard<std::mutex> lock(g_dg_mutex);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (cap != hipStreamCaptureStatusNone) {
+    if (!A->dg_flags || A->dg_captured >= GLA_DG_CAPTURE_SLOTS) return GLA_ERR_UNSUPPORTED;
+    int* word = A->dg_flags + GLA_DG_SLOTS + A->dg_captured++;
+    GLA_HIP_CHECK(hipMemsetAsync(word, 0, sizeof(int), st));
+    *epoch = 1;
+    *flag = word;
+    return GLA_OK;
+  }
   if (!A->dg_flags) {
-    GLA_HIP_CHECK(hipMalloc(&A->dg_flags, GLA_DG_SLOTS * sizeof(int)));
-    GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, GLA_DG_SLOTS * sizeof(int)));
+    GLA_HIP_CHECK(hipMalloc(&A->dg_flags, (GLA_DG_SLOTS + GLA_DG_CAPTURE_SLOTS) * sizeof(int)));
+    GLA_HIP_CHECK(hipMemset(A->dg_flags, 0, (GLA_DG_SLOTS + GLA_DG_CAPTURE_SLOTS) * sizeof(int)));
   }
   if (++A->dg_calls >= 0x7fffff00u) {                 // (wrap-around after 2^31 calls: start over with clean words)
     GLA_HIP_CHECK(hipDeviceSynchronize());
@@ -1857,7 +1872,7 @@ int jacobi_sweeps_aos(gla_csr* A, const T* va, int64_t ld, T* dwork, T* bwork, T
   int* flag = nullptr;
   int epoch = 0;
   if (flagged) {
-    const int rc = gla_jacobi_dg_slot(A, &flag, &epoch);
+    const int rc = gla_jacobi_dg_slot(A, st, &flag, &epoch);
     if (rc) return rc;
   }
   (void)dwork;

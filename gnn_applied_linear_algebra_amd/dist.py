@@ -185,7 +185,9 @@ def _publish_rows(ei, ev, row_lo, row_hi, wanted_by_rank, group):
         pub_i, pub_v = ei[:, m].t().contiguous(), ev.reshape(-1)[m].contiguous()
     else:
         pub_i, pub_v = torch.zeros((0, 2), dtype=torch.int64, device=dev), torch.zeros(0, dtype=ev.dtype, device=dev)
+    _tlog("publish rows: this rank's published rows selected")
     pool_i, pool_v = _gather_var(pub_i, group), _gather_var(pub_v, group)
+    _tlog("publish rows: gathered")
     want = wanted_by_rank[rank].to(dev)
     got_i, got_v = [], []
     for q, (pi, pv) in enumerate(zip(pool_i, pool_v)):
@@ -247,7 +249,9 @@ class RowBlockPartition:
         _tlog("partition: blocks known")
         # the off-block input entries this rank reads
         off = (col < self.in_lo) | (col >= self.in_hi)
+        _tlog("partition: off-block column mask")
         need = torch.unique(col[off]).cpu()                       # sorted global ids
+        _tlog("partition: unique off-block columns")
         if self.distributed:
             needs = [t_.cpu() for t_ in _gather_var(need, group)]
         else:
@@ -267,6 +271,7 @@ class RowBlockPartition:
             m = owner == q
             if bool(m.any()):
                 slot[m] = q * self.S + torch.searchsorted(send_lists[q], need[m])
+        _tlog("partition: send lists and slots (host)")
         need_d, slot_d = need.to(dev), slot.to(dev)
         col_local = col - self.in_lo
         if need_d.numel():
@@ -421,8 +426,10 @@ class RowBlockOps:
         if good and not bool(inside.all()):
             all_ei, all_ev = all_ei[:, inside], all_ev[inside]
         plan = None
+        _tlog("extended edge list assembled")
         if good:
             plan = CsrPlan(all_ei - elo, ehi - elo, ehi - elo)
+            _tlog("extended plan: structure")
             plan.set_values(all_ev)
             sched = plan.jacobi_schedule(4 * T, all_ev.dtype)
             good = int((not need_jacobi_passes or 1 < max(sched) <= T) and int(plan.info.dia_stride) == S)
@@ -764,12 +771,41 @@ class RowBlockJacobi(RowBlockOps):
         self._ghost_pending = None
         return own(cur).unsqueeze(1)
 
+    @classmethod
+    def rehearsal_self_halo(cls, Nx, lines, device, comm=None):
+        """A driver for ONE rank's block of `lines` grid lines x Nx points whose upper and lower neighbour are the rank itself (the
+        grid is periodic in the line direction), over a real one-rank RCCL communicator of the library: everything a rank of an
+        N-rank job does per forward() -- pack, ncclAllGather on the library's stream, interior line blocks, ghost fill + edge
+        blocks on a second stream, join -- except waiting for other GPUs.  No multi-GPU hardware is needed: bench.py's
+        `dist_route_one_gpu*` records, tools/bench_dist_config4_block.py and tests/test_gpu_dist.py use it.  Not a product
+        path: a real job builds RowBlockJacobi(edgeij_pair, edge_attr, ...) per rank."""
+        import types
+        from . import UtilsGNN
+        from .plan import CsrPlan
+        T = cls.TS_MAX
+        ei, ev = UtilsGNN.laplacianfun_torch(Nx, Ny=lines + 2 * T, device=device)
+        plan = CsrPlan(ei, Nx * (lines + 2 * T))
+        plan.set_values(ev)
+        drv = cls.__new__(cls)
+        drv.comm, drv.overlap, drv._ghost_pending, drv._lib_send = comm if comm is not None else LibComm(), True, None, {}
+        drv.part = types.SimpleNamespace(world=1, rank=0, n_local=Nx * lines, group=None, n_in=Nx * lines, S=0)
+        drv._sched = plan.jacobi_schedule
+        drv.ext = dict(plan=plan, S=Nx, n_ext=Nx * (lines + 2 * T), off=Nx * T, up=True, down=True, slab=T * Nx,
+                       dtype=ev.dtype, dev=torch.device(device), up_src=0, down_src=0)
+        drv.mode = "temporally blocked, one-rank self-halo rehearsal"
+        return drv
+
     def capture_forward(self, n_iters, vertex_attr, g):
-        """forward(n_iters, vertex_attr, g) captured into a HIP graph (torch.cuda.CUDAGraph): returns run(vertex_attr) -> x.
-        The exchange-per-sweep loop is ~6 enqueues per sweep (pack, event record / wait, ncclAllGather on the library's side
-        stream, two launches): 29 us of host time per sweep eager, 17 us replayed (tools/graph_dist_loop.py, one-rank RCCL
-        communicator, bit-identical) -- for hosts that cannot keep the launch queue ahead of ~0.1 ms sweeps.  `g` must be a CPU
-        tensor or already read (no device-to-host copy inside a capture); operands keep the captured shape."""
+        """forward(n_iters, vertex_attr, g) captured into a HIP graph (torch.cuda.CUDAGraph): returns run(vertex_attr) -> x;
+        run.graph.replay() re-runs it on run.static_va in place (result in run.out).  Every rank must capture and replay alike.
+
+        Both routes capture: the exchange-per-sweep loop (~6 enqueues per sweep: 29 us of host time per sweep eager, 17 us
+        replayed, tools/graph_dist_loop.py) and -- round 5 -- the TEMPORALLY BLOCKED route (gla_dist_jacobi_temporal: per pass
+        a pack launch, ncclAllGather on the library's stream, the interior launch, ghost fill + edge launch on the second stream,
+        event fork / join: ~10 enqueues and 89 us of host time per pass, next to ~100 us of GPU time per pass on BASELINE
+        config 4's block of one of 8 ranks, 1024 x 8192).  The call's A_ii flag word is one of the plan's capture words with a
+        memset node in front (gla_jacobi_dg_slot), so replays and eager calls never share a word.  `g` must be a CPU tensor
+        or already read (no device-to-host copy inside a capture); operands keep the captured shape."""
         dev = vertex_attr.device
         static_va = vertex_attr.clone()
         side = torch.cuda.Stream(device=dev)
@@ -786,7 +822,7 @@ class RowBlockJacobi(RowBlockOps):
             static_va.copy_(va)
             graph.replay()
             return out.clone()
-        run.graph = graph
+        run.graph, run.static_va, run.out = graph, static_va, out
         return run
 
     def forward(self, n_iters, vertex_attr, g):

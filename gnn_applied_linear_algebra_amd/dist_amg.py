@@ -337,14 +337,16 @@ class RowBlockAMG:
         vecs = []
         if b is not None:
             # b is copied into the level's extended block unless it is already there: restrict() writes a coarse level's
-            # right-hand side straight into this buffer, and the caller's level-0 b is recognised across cycles by identity and
-            # version counter (the reference to it is kept: an address alone could be a new tensor in recycled memory)
+            # right-hand side straight into this buffer.  The caller's level-0 b is copied on EVERY cycle unless the caller
+            # vouches that it has not changed (cycle(..., b_unchanged=True)): torch's version counter does not see writes
+            # made through raw pointers (the library's own out= entry points, HIP-graph replays), so it cannot vouch
             src = a.get("b_src")
             if b.data_ptr() == own(a["b"]).data_ptr() and b.numel() == nl:
                 a["b_src"] = None
-            elif getattr(self, "_capturing", False) or not (src is not None and src[0] is b and src[1] == b._version):
+            elif not (getattr(self, "_b_unchanged", False) and not getattr(self, "_capturing", False)
+                      and src is not None and src is b):
                 own(a["b"]).copy_(b.reshape(-1))
-                a["b_src"] = (b, b._version)
+                a["b_src"] = b
             vecs.append(a["b"])
         x_full = ops._ext_of(x, (1,))                        # x allocated with its ghost rows (correct() does): used in place
         if x_full is not None:
@@ -451,8 +453,12 @@ class RowBlockAMG:
         run.graph = graph
         return run
 
-    def cycle(self, b, x, level=0):
-        """One V-cycle on this rank's rows: b, x are the LOCAL parts ([n_local, 1]) of the level vectors."""
+    def cycle(self, b, x, level=0, b_unchanged=False):
+        """One V-cycle on this rank's rows: b, x are the LOCAL parts ([n_local, 1]) of the level vectors.
+        b_unchanged=True: the caller vouches that b is the tensor of the previous cycle() call with the same contents (a solver
+        loop on one right-hand side): its copy into the level's extended block is skipped."""
+        if level == 0:
+            self._b_unchanged = bool(b_unchanged)
         if level == self.n_dist:
             # replicated from here on: one all-gather of the right-hand side, the rest of the cycle on this GPU alone
             lo, hi = self.blocks[level][self.rank]

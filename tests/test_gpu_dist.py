@@ -384,7 +384,15 @@ def _amg_one_rank_worker(port, q):
         assert torch.equal(D.cycle(b2, xd), H.cycle(b2, xs))
         b2.mul_(0.5)                                                             # ... and an in-place change of the same tensor
         assert torch.equal(D.cycle(b2, xd), H.cycle(b2, xs))
-        run = D.capture_cycle()                                                  # the rank's cycle as one HIP graph, RCCL all-gathers included
+        # ... and a change torch's version counter cannot see: the library's own out= entry points write through raw
+        # pointers -- a solver loop that refreshes its residual tensor that way must not smooth against the previous one
+        v0 = b2._version
+        H.plans[0].residual(b, xs, out=b2)
+        assert b2._version == v0, "(the premise of this check: a raw-pointer write does not bump the version counter)"
+        assert torch.equal(D.cycle(b2, xd), H.cycle(b2, xs)), "stale right-hand side after an out= write"
+        # the opt-in: the caller vouches for an unchanged b, the copy is skipped, same bits
+        assert torch.equal(D.cycle(b2, xd, b_unchanged=True), H.cycle(b2, xs))
+        run = D.capture_cycle()                                                 # the rank's cycle as one HIP graph, RCCL all-gathers included
         for rhs in (b, b2, b):
             xg = run(rhs, xd)
             assert torch.equal(xg, D.cycle(rhs, xd)) and torch.equal(xg, H.cycle(rhs, xs)), "captured cycle"

@@ -1024,6 +1024,34 @@ def test_full_size_config4_8192():
     eq(r, b.numpy() - A.spmm(want))
 
 
+def test_full_size_config4_8192_module_step_20_sweeps_vs_c_oracle():
+    """BASELINE config 4's STEP at size (missing #4): JacobiGNN.forward, 20 sweeps, on the 8192^2 Laplacian -- the AoS
+    first pass with the A_ii flag, then the symmetric no-mask passes on the centre coefficient (7 + 7 + 6), exactly what
+    bench.py's config4_1gpu times and what every rank of config4_strong runs on its block -- bit-exact against the
+    single-threaded C oracle (JacobiGNN.py:138-148; about 30 s of host time)."""
+    import c_oracle
+    N = 8192
+    n = N * N
+    ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=DEV)
+    gen = torch.Generator().manual_seed(24601)
+    b = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    x = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+    diag = torch.full((n, 1), -4.0, dtype=torch.float64)
+    ea = torch.cat([ev, torch.zeros_like(ev)], 1)
+    plan = gla.plan_for(ei, n, edge_attr=ea)
+    sched = plan.jacobi_schedule(20)
+    import os
+    opts = os.environ.get("GLA_OPTIONS", "")               # (conftest adds jacobi_min_rows=0 to whatever the caller set)
+    if not any(k in opts for k in ("dia=0", "col16=0", "compress=1", "jacobi_fuse=", "jacobi_march=", "jacobi_ts_max", "sym=0")):
+        assert sched == (7, 7, 6), sched                     # the default configuration: the schedule the bench times
+    got = gla.JacobiGNN.JacobiGNN()(20, d(torch.cat([diag, b, x], 1)), ei, ea, torch.tensor([0.7], dtype=torch.float64))
+    torch.cuda.synchronize()
+    A = c_oracle.Csr(ei.cpu().numpy(), ev.cpu().numpy(), n)
+    del ei, ea, plan
+    want = A.jacobi(diag.numpy(), b.numpy(), x.numpy(), 0.7, 20)
+    eq(got, want)
+
+
 def test_dia_layout_bit_identical():
     """Stencil matrices (every nonzero on one of <= 15 diagonals, rows in ascending order) get the diagonal layout
     (option "dia", default): no index stream at all.  Same products in the same order: every fused K = 1 op equals the
