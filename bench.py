@@ -915,6 +915,22 @@ def single_gpu(args, gla, dev):
         # replayed from a HIP graph, next to the whole 8192^2 matrix on this GPU (child process: tools/bench_dist_config4_block.py)
         out["dist_route_one_gpu_config4_block"] = side_child_json([os.path.join(ROOT, "tools", "bench_dist_config4_block.py"), "8192", "8",
                                                                     str(args.sweeps), "--json"], 240.0)
+        # ---- side: the price of bit-exactness, measured once (never the default): the same step through the
+        # opt-in build variant libgla_hip_contracted.so (FMA contraction in the row sums, division as one multiply-add with
+        # RN(1 / A_ii)) next to the default library, each in a child process of its own (tools/bench_contracted_fp.py)
+        lib_c = os.path.join(ROOT, "gnn_applied_linear_algebra_amd", "libgla_hip_contracted.so")
+        if os.path.exists(lib_c):
+            tool = os.path.join(ROOT, "tools", "bench_contracted_fp.py")
+            rec_d = side_child_json([tool, str(args.n), str(args.sweeps), "--json"], 120.0)
+            rec_c = side_child_json([tool, str(args.n), str(args.sweeps), "--json"], 120.0, extra_env={"GLA_LIB_PATH": lib_c})
+            out["contracted_fp"] = {
+                "what": "opt-in BUILD VARIANT, not the product: gla_march5.hip compiled with -ffp-contract=fast -DGLA_CONTRACTED_FP (row sums "
+                        "as FMA chains, x + num * RN(1 / A_ii) instead of the correctly rounded quotient); deviation = largest "
+                        "|x - x_ref| / max |x_ref| after the step against a plain torch fp64 iteration (north_star's bar: 1e-6; the "
+                        "default build is bit-exact against the oracle)",
+                "default_build": rec_d, "contracted_build": rec_c,
+                "speedup": (round(rec_d["ms_per_step"] / rec_c["ms_per_step"], 4)
+                            if "ms_per_step" in rec_d and "ms_per_step" in rec_c else None)}
         # ---- side: non-stencil matrices through the CSR-adaptive kernels (stream / vector / long bins) ----------------------
         try:
             out["csr_irregular"] = side_irregular(gla, dev)
@@ -1000,9 +1016,10 @@ def _row_bytes(drv, blocked, sweeps=None):
     return 8 * 5 + 2 + 32
 
 
-def side_child_json(argv, timeout_s):
+def side_child_json(argv, timeout_s, extra_env=None):
     """Run a tool as a child process (its own RCCL process group / communicator) and return the JSON object it prints last."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() + 7) % 400))
+    env.update(extra_env or {})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     try:
@@ -1049,10 +1066,11 @@ def side_dist_vcycle(timeout_s):
 
 
 def side_irregular(gla, dev):
-    """SpMV and one Jacobi sweep on matrices that are NOT stencils (the CSR-adaptive kernels: stream tiles, the vector bin for
+    """SpMV, one Jacobi sweep and a 16-column SpMM on matrices that are NOT stencils (the CSR-adaptive kernels: stream tiles, the vector bin for
     tiles whose rows average >= 32 nonzeros, the long bin): us per launch, GB/s and fraction of 8 TB/s on SURVEY 8(d)'s bytes
     (12 nnz + 4 (n + 1) + 16 n / + 32 n; the x gather counted once)."""
     import torch
+    check, L = gla._lib.check, gla._lib.lib()
 
     def measure(name, ei, ev, n):
         nnz = ei.shape[1]
@@ -1067,9 +1085,22 @@ def side_irregular(gla, dev):
         t_j = _median_us(lambda: plan.jacobi_sweep(dg, bb, x, xo, 0.7))
         B_mv, B_j = 12 * nnz + 4 * (n + 1) + 16 * n, 12 * nnz + 4 * (n + 1) + 32 * n
         lens = torch.bincount(ei[0], minlength=n)
+        # K = 16 right-hand sides through the same plan (spmm_stream_vec2_kernel; rows of >= 64 nonzeros: the K-wide vector bin)
+        K16 = 16
+        x16 = torch.rand(n, K16, generator=gen, dtype=torch.float64).to(dev)
+        y16 = torch.empty_like(x16)
+        t_mm = _median_us(lambda: plan.spmm(x16, out=y16))
+        B_mm = 12 * nnz + 4 * (n + 1) + 16 * n * K16
+        check(L.gla_set_option(b"row_sum", 0))
+        try:
+            t_mm0 = _median_us(lambda: plan.spmm(x16, out=y16))
+        finally:
+            check(L.gla_set_option(b"row_sum", 1))
         return {"matrix": name, "rows": n, "nnz": nnz, "avg_row": round(nnz / n, 2), "max_row": int(lens.max()),
                 "spmv_us": round(t_mv, 1), "spmv_GBps": round(B_mv / t_mv / 1e3, 1), "spmv_frac": round(B_mv / (t_mv * 1e-6) / HBM_PEAK, 4),
-                "jacobi_us": round(t_j, 1), "jacobi_GBps": round(B_j / t_j / 1e3, 1), "jacobi_frac": round(B_j / (t_j * 1e-6) / HBM_PEAK, 4)}
+                "jacobi_us": round(t_j, 1), "jacobi_GBps": round(B_j / t_j / 1e3, 1), "jacobi_frac": round(B_j / (t_j * 1e-6) / HBM_PEAK, 4),
+                "spmm_k16_us": round(t_mm, 1), "spmm_k16_GBps": round(B_mm / t_mm / 1e3, 1),
+                "spmm_k16_frac": round(B_mm / (t_mm * 1e-6) / HBM_PEAK, 4), "spmm_k16_us_one_lane_group_per_row": round(t_mm0, 1)}
 
     recs = []
     m = 4095
@@ -1121,15 +1152,26 @@ def multi_gpu(args, gla, dev, world, rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    setup_log = []
+
     def run_block(Nx, lines, steps, warmup):
         """Row block of `lines` grid lines per rank of the (lines*world) x Nx grid; returns (elapsed, problem, drv)."""
         Ny = lines * world
         n_local = Nx * lines
+        torch.cuda.synchronize()
+        t_s0 = time.perf_counter()
         pr = Problem(gla, Nx, Ny, rank * n_local, (rank + 1) * n_local, dev, 24601 + rank)
+        torch.cuda.synchronize()
+        t_s1 = time.perf_counter()
         log(f"{Ny} x {Nx} grid, {lines} lines per rank: local problem built")
         drv = RowBlockJacobi(pr.ei, pr.edge_attr, n_global=Nx * Ny, row_lo=rank * n_local, row_hi=(rank + 1) * n_local,
                              overlap=not args.no_overlap, host_loop=args.host_loop)
+        torch.cuda.synchronize()
+        t_s2 = time.perf_counter()
         log(f"row-block driver ready ({drv.mode})")
+        # setup in front of the timed steps, slowest rank (VERDICT r4: "put setup_s per block into the N > 1 line")
+        setup_log.append({"block": f"{lines} lines x {Nx} points per rank", "problem_s": round(max_over_ranks(t_s1 - t_s0), 3),
+                          "row_block_driver_s": round(max_over_ranks(t_s2 - t_s1), 3)})
         if args.ramp_ms > 0:
             # clock ramp as in the single-GPU line (profiles/r04/clock_ramp.txt).  Every forward() is a collective: the number
             # of ramp steps is agreed (from the slowest rank's time for two steps), never a per-rank clock
@@ -1217,11 +1259,15 @@ def multi_gpu(args, gla, dev, world, rank):
             rec.update({"one_gpu_sweeps_per_s": round(1.0 / t1, 2), "speedup_vs_one_gpu": round(t1 / t4, 3),
                         "parallel_efficiency": round(t1 / t4 / world, 3)})
         out["config4_strong"] = rec
+    out["setup_s"] = {"what": "seconds in front of the timed steps per block, slowest rank: the synthetic problem (graph builder + operands) and "
+                              "the row-block driver (partition, block plan, ghost rows of the matrix, extended plan, communicator)",
+                      "blocks": setup_log}
     if rank == 0:
         emit(out)
 
 
 _JSON_FD = None
+_STACK_FILE = None
 
 
 def emit(obj):
@@ -1248,9 +1294,12 @@ def worker(args):
     # a slow phase must say WHERE it is: rank 0 of a multi-rank run dumps its Python stacks to stderr every --stack-dump-s seconds
     # (faulthandler: a watchdog thread, no cost to the run); round 4's fresh-box rehearsal sat 27-98 s in setup phases nobody
     # could name afterwards
-    if args.stack_dump_s > 0 and world > 1 and rank == 0:
+    if args.stack_dump_s > 0 and world > 1 and (rank == 0 or os.environ.get("GLA_BENCH_STACK_DIR")):
         import faulthandler
-        faulthandler.dump_traceback_later(args.stack_dump_s, repeat=True, file=sys.stderr)
+        sdir = os.environ.get("GLA_BENCH_STACK_DIR")        # (every rank into a file of its own: who waits for whom)
+        global _STACK_FILE
+        _STACK_FILE = open(os.path.join(sdir, f"stacks_rank{rank}.txt"), "w") if sdir else sys.stderr
+        faulthandler.dump_traceback_later(args.stack_dump_s, repeat=True, file=_STACK_FILE)
     import torch
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)

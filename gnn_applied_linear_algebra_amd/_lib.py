@@ -108,6 +108,10 @@ SIGNATURES = {
     "gla_dist_jacobi_sweeps": (_I, [_P, _P, _I, _I, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _P, _D, _I, _I, _P]),
     "gla_dist_jacobi_temporal": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _D,
                                       ctypes.POINTER(_I), _I, _P, _P]),
+    "gla_dist_jacobi_temporal_graph": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _D,
+                                            ctypes.POINTER(_I), _I, ctypes.POINTER(_P)]),
+    "gla_graph_launch": (_I, [_P, _P]),
+    "gla_graph_destroy": (_I, [_P]),
 }
 
 _lib = None

@@ -16,10 +16,25 @@ for f in $SRCS; do
     pids+=($!)
   fi
 done
+# The opt-in "contracted_fp" build variant of the headline kernel (NEVER the default, never bit-exact: FMA contraction in the row
+# sums, the division as one multiply-add with RN(1 / A_ii)): libgla_hip_contracted.so = the same objects with this one swapped.
+# It exists to MEASURE what the bit-exact formulation costs (bench.py side record `contracted_fp`; parity at 1e-12 in the GPU
+# suite); picked up only through GLA_LIB_PATH.  GLA_BUILD_CONTRACTED=0 skips it.
+if [ "${GLA_BUILD_CONTRACTED:-1}" != "0" ]; then
+  if [ ! -f gla_march5_contracted.o ] || [ gla_march5.hip -nt gla_march5_contracted.o ] || [ gla_internal.h -nt gla_march5_contracted.o ] || [ gla_device.h -nt gla_march5_contracted.o ] || [ ../../include/gla.h -nt gla_march5_contracted.o ]; then
+    rm -f gla_march5_contracted.o
+    $HIPCC ${FLAGS/-ffp-contract=off/-ffp-contract=fast} -DGLA_CONTRACTED_FP -c gla_march5.hip -o gla_march5_contracted.o &
+    pids+=($!)
+  fi
+fi
 for p in "${pids[@]}"; do wait $p; done          # (set -e: a failed translation unit stops the build)
 OBJS=""; for f in $SRCS; do OBJS="$OBJS $f.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $OUT
 echo "built $(realpath $OUT)"
+if [ "${GLA_BUILD_CONTRACTED:-1}" != "0" ]; then
+  $HIPCC --offload-arch=gfx950 -shared -fPIC ${OBJS/gla_march5.o/gla_march5_contracted.o} -ldl -o ../libgla_hip_contracted.so
+  echo "built $(realpath ../libgla_hip_contracted.so) (opt-in contracted_fp variant)"
+fi
 # Scan the code objects for the hipcc miscompile signature of profiles/r03/marchk_miscompile.txt (an exec-masked region with
 # nothing in it; 12 s).  Part of every build -- a hit fails it; GLA_ISA_CHECK=0 skips the scan.
 if [ "${GLA_ISA_CHECK:-1}" != "0" ]; then

@@ -363,21 +363,26 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
         src[k] = at(va, (a - off) * ldva + col); dst[k] = atw(dst3[col], a); cnt[k] = b - a; strd[k] = ldva; ++k;
       }
     }
-    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, mn); if (rc) return bail(rc); }
-    k = 0;                                                    // send = per column [first m own rows | last m own rows]
-    for (int col = 0; col < 3; ++col) {
-      src[k] = at(va, col); dst[k] = atw(send, 2 * m * col); cnt[k] = m; strd[k] = ldva; ++k;
-      src[k] = at(va, (n_local - m) * ldva + col); dst[k] = atw(send, 2 * m * col + m); cnt[k] = m; strd[k] = ldva; ++k;
-    }
-    rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, mn); if (rc) return bail(rc);
-    rc = gla_comm_all_gather_begin(c, dtype, send, recv, 6 * m, mn); if (rc) return bail(rc);
+    // Two streams, no third: the exchange runs ON the second stream -- its producer (the pack) and its consumer (the ghost fill)
+    // are there anyway, so a communicator stream of its own bought nothing, and a capture of three streams that wait for one
+    // another (main -> {side, comm}, comm -> side, side -> comm) dies inside hipStreamEndCapture on ROCm 7.0 (round 5,
+    // tools/capture_variants.py: every two-stream form captures, every three-stream form crashes).
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
     forked = true;
     if (dg_flag) rc = gla_jacobi_parts_flagged(A, dtype, va, ldva, off, n_local, nullptr, nullptr, nullptr, nullptr, b_ext, nxt, w, ts, 1, ghost, dg_flag, dg_epoch, mn);
     else rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, ghost, mn);
     if (rc) return bail(rc);
-    rc = gla_halo_end(c, sd); if (rc) return bail(rc);
+    // (the interior launch reads the AoS rows and leaves the edge windows of d_ext / b_ext alone: the hand copies may run beside it)
+    if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return bail(rc); }
+    k = 0;                                                    // send = per column [first m own rows | last m own rows]
+    for (int col = 0; col < 3; ++col) {
+      src[k] = at(va, col); dst[k] = atw(send, 2 * m * col); cnt[k] = m; strd[k] = ldva; ++k;
+      src[k] = at(va, (n_local - m) * ldva + col); dst[k] = atw(send, 2 * m * col + m); cnt[k] = m; strd[k] = ldva; ++k;
+    }
+    rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return bail(rc);
+    { const int r_ = g_rccl.all_gather(send, recv, (size_t)(6 * m), dtype == GLA_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32, c->comm, sd);
+      if (r_ != 0) return bail(-(3000 + r_)); }
     k = 0;
     for (int col = 0; col < 3; ++col) {                       // the neighbour above's LAST lines / below's FIRST lines
       if (up) { src[k] = at(recv, (int64_t)up_src * 6 * m + 2 * m * col + m); dst[k] = dst3[col]; cnt[k] = m; strd[k] = 1; ++k; }
@@ -405,12 +410,13 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
       void* dst[2] = {send, atw(send, m)};
       const int64_t cnt[2] = {m, m};
       rc = gla_copy_batch(dtype, 2, src, dst, cnt, nullptr, sd); if (rc) return bail(rc);
-      rc = gla_comm_all_gather_begin(c, dtype, send, recv, 2 * m, sd); if (rc) return bail(rc);
     }
-    GLA_HIP_CHECK(hipEventRecord(c->ev_join, sd));
+    GLA_HIP_CHECK(hipEventRecord(c->ev_join, sd));            // (BEFORE the all-gather: the main stream waits for the edge blocks only)
     GLA_HIP_CHECK(hipStreamWaitEvent(mn, c->ev_join, 0));
     forked = false;
     if (i == n_passes) break;
+    { const int r_ = g_rccl.all_gather(send, recv, (size_t)(2 * m), dtype == GLA_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32, c->comm, sd);
+      if (r_ != 0) { forked = true; return bail(-(3000 + r_)); } }      // (the second stream holds work the main stream has not joined)
     if (i == 1 && dg_flag) {                                  // (both streams joined: pass 0 is complete, the flag final)
       const int64_t E0 = (int64_t)(2 * ghost + passes[0]) * S;
       const int64_t lo = E0 > off ? E0 : off, hi = n_ext - E0 < off + n_local ? n_ext - E0 : off + n_local;
@@ -432,7 +438,6 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
     forked = true;
     rc = parts(d_ext, b_ext, cur, nxt, ts, 1, mn); if (rc) return bail(rc);
-    rc = gla_halo_end(c, sd); if (rc) return bail(rc);
     const void* src[2]; void* dst[2]; int64_t cnt[2];
     int k = 0;
     if (up) { src[k] = at(recv, (int64_t)up_src * 2 * m + m); dst[k] = cur; cnt[k] = m; ++k; }
@@ -440,6 +445,68 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, nullptr, sd); if (rc) return bail(rc); }
     rc = parts(d_ext, b_ext, cur, nxt, ts, 2, sd); if (rc) return bail(rc);
   }
+  return GLA_OK;
+}
+
+// ---- the same call as ONE HIP graph ------------------------------------------------------------------------------------------
+// gla_dist_jacobi_temporal is ~10 enqueues per pass (pack launch, event record / wait, ncclAllGather, interior launch, ghost fill,
+// edge launch, fork / join): 89 us of host time per pass, next to ~100 us of GPU time per pass on the block of one of 8 ranks of
+// BASELINE config 4 (1024 lines x 8192 points).  Captured once -- on two streams the graph owns, RCCL's all-gathers on the
+// communicator's stream included, the call's A_ii flag word a capture word with its memset node (gla_jacobi_dg_slot) -- and
+// replayed with one hipGraphLaunch per forward().  Operand ADDRESSES are frozen into the graph: the caller keeps the buffers and
+// refreshes vertex_attr in place.  Every rank of the communicator must capture and launch alike (the all-gathers are collective).
+struct gla_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t mn = nullptr, sd = nullptr;
+};
+
+int gla_dist_jacobi_temporal_graph(gla_csr_t A, gla_comm_t c, int dtype, const void* va, int64_t ldva, int64_t off, int64_t n_local,
+                                   void* d_ext, void* b_ext, void* xa, void* xb, void* x_last, void* send, void* recv, int ghost,
+                                   int up, int down, int up_src, int down_src, double w, const int* passes, int n_passes,
+                                   gla_graph_t* out) {
+  if (!out) return GLA_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!A || !c) return GLA_ERR_INVALID_ARG;
+  // everything a capture may not do comes first: the plan's flag words (hipMalloc), the kernels' occupancy queries and code
+  // loads (one eager pass through the whole sequence on the graph's own streams -- it is also the check that the sequence runs)
+  gla_graph* g = new gla_graph();
+  hipError_t e = hipStreamCreateWithFlags(&g->mn, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->sd, hipStreamNonBlocking);
+  if (e != hipSuccess) { (void)hipGetLastError(); gla_graph_destroy(g); return -(1000 + (int)e); }
+  int rc = gla_dist_jacobi_temporal(A, c, dtype, va, ldva, off, n_local, d_ext, b_ext, xa, xb, x_last, send, recv, ghost, up, down,
+                                    up_src, down_src, w, passes, n_passes, g->mn, g->sd);
+  if (rc == GLA_OK && hipStreamSynchronize(g->mn) != hipSuccess) rc = GLA_ERR_INVALID_ARG;
+  if (rc != GLA_OK) { (void)hipGetLastError(); gla_graph_destroy(g); return rc; }
+  e = hipStreamBeginCapture(g->mn, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) { (void)hipGetLastError(); gla_graph_destroy(g); return -(1000 + (int)e); }
+  rc = gla_dist_jacobi_temporal(A, c, dtype, va, ldva, off, n_local, d_ext, b_ext, xa, xb, x_last, send, recv, ghost, up, down,
+                                up_src, down_src, w, passes, n_passes, g->mn, g->sd);
+  e = hipStreamEndCapture(g->mn, &g->graph);           // (also after a failed enqueue: the stream must leave capture mode)
+  if (rc != GLA_OK || e != hipSuccess || !g->graph) {
+    (void)hipGetLastError();
+    gla_graph_destroy(g);
+    return rc != GLA_OK ? rc : -(1000 + (int)e);
+  }
+  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); gla_graph_destroy(g); return -(1000 + (int)e); }
+  *out = g;
+  return GLA_OK;
+}
+
+int gla_graph_launch(gla_graph_t g, gla_stream_t stream) {
+  if (!g || !g->exec) return GLA_ERR_INVALID_ARG;
+  GLA_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return GLA_OK;
+}
+
+int gla_graph_destroy(gla_graph_t g) {
+  if (!g) return GLA_OK;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  if (g->mn) { (void)hipStreamSynchronize(g->mn); (void)hipStreamDestroy(g->mn); }
+  if (g->sd) { (void)hipStreamSynchronize(g->sd); (void)hipStreamDestroy(g->sd); }
+  delete g;
   return GLA_OK;
 }
 

@@ -58,6 +58,13 @@ struct gla_csr {
   int* dg_flags = nullptr;       // [GLA_DG_SLOTS] device words of gla_jacobi_sweeps_aos' "A_ii is not the matrix diagonal" flags: call k uses
   uint32_t dg_calls = 0;         // word k mod GLA_DG_SLOTS and stores k there to raise it (never reset; guarded by dg_mutex)
   int32_t dg_captured = 0;       // words [GLA_DG_SLOTS, +GLA_DG_CAPTURE_SLOTS) handed to calls captured into HIP graphs, one each
+  // (the symmetry check of gla_csr_set_values is ASYNCHRONOUS: a check kernel, a copy into a pinned host word and an event on the
+  //  caller's stream; the first reader -- gla_dia_sym_bits, at the first launch or gla_csr_info -- waits for the event.  No
+  //  malloc / free / stream synchronise per value set: callers that refresh values every step stay asynchronous)
+  int* sym_dev = nullptr;        // device word the check kernel ORs broken pairs into
+  int* sym_host = nullptr;       // pinned host copy
+  hipEvent_t sym_event = nullptr;
+  int32_t sym_pending = 0, sym_mask = 0;
   int32_t dia_sym = 0;           // bit d set: diagonal d (offset < 0) repeats its partner of offset -off bit for bit, A[r][r + off] ==
                                  // A[r + off][r] for every row (0 where r + off < 0): the kernels need not read it (option "sym")
   int32_t dia_full = 0;          // canonical 5-point plans: 1 = EVERY row couples to every grid neighbour it has (its mask is the one its
@@ -158,7 +165,16 @@ struct gla_march5_args {
   int* dg_flag = nullptr;      // AoS pass: raised where A_ii differs from the centre diagonal; plain passes: A_ii is `diag` if raised,
 };                             // the centre diagonal otherwise.  diag == nullptr (plain passes, no flag): A_ii = the centre diagonal
 // every lower diagonal of the canonical 5-point plan repeats its upper partner (and the option allows using that)
-inline bool gla_dia_sym5(const gla_csr* A) { return g_tuning.sym && gla_dia_canon5(A) && (A->dia_sym & 3) == 3; }
+inline int32_t gla_dia_sym_bits(const gla_csr* A) {          // resolves a pending check (one event wait, once per value set)
+  if (A->sym_pending) {
+    gla_csr* p = const_cast<gla_csr*>(A);
+    (void)hipEventSynchronize(p->sym_event);
+    p->dia_sym = p->sym_mask & ~*p->sym_host;
+    p->sym_pending = 0;
+  }
+  return A->dia_sym;
+}
+inline bool gla_dia_sym5(const gla_csr* A) { return g_tuning.sym && gla_dia_canon5(A) && (gla_dia_sym_bits(A) & 3) == 3; }
 // ... and no row lacks a neighbour its grid position has (and the option allows using that): no mask stream
 inline bool gla_dia_full5(const gla_csr* A) { return g_tuning.full_mask && gla_dia_canon5(A) && A->dia_full == 1; }
 int gla_march5_pass(const gla_march5_args& a);

@@ -101,7 +101,9 @@ constexpr int M5_PLAIN = 0, M5_AOS = 1, M5_RES = 2;
 
 // The pass (one workgroup's line block).  DGC: A_ii IS the row's centre coefficient -- neither loaded nor kept (12 registers per
 // coefficient set instead of 17, one load less per line step).
-template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, bool DGC, int PF = 1>
+// DBG (GLA_M5_VARIANTS builds only; results are WRONG with any bit set -- timing experiments): 1 no barrier, 2 no output store,
+// 4 no s_setprio, 8 no levels (the memory side alone: loads, LDS line of level 0, the store stream)
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, bool DGC, int PF = 1, int DBG = 0>
 __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ diag, const T* __restrict__ bvec,
                                         const T* __restrict__ x, T* __restrict__ xo, T w, int lines, int nstrips, const TileMap& tm,
                                         int tile_base0, int tile_split, int tile_base1, int64_t ldva, T* __restrict__ diag_out,
@@ -220,9 +222,9 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
   // memory -- and which of the two forms the register allocator handles without spilling depends on the instance (M5Cfg)
   auto do_step = [&](const int jl, auto u_c, auto nact_c) {
     const int u = ic_val(u_c), nact = ic_val(nact_c);
-    __syncthreads();
+    if constexpr (!(DBG & 1)) __syncthreads();
     const int pj = (jl + 64) & 1;
-    if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    if constexpr (!(DBG & 4)) { if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
     T* const row_e = buf + pj * LW + tid;          // lines of the parity of jl:     [0] left, [1] own, [2] right
     T* const row_o = buf + (1 - pj) * LW + tid;    // lines of the other parity
     auto lds_row = [&](int t) -> T* { return ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LW; };   // level t - 1, line of level t
@@ -273,6 +275,13 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((DBG & 8) != 0) {                  // the memory side alone: every loaded value is consumed, one store per row
+      const M5Coef<T>& cc = c[u % NC];
+      const T sum_ = (((cc.v[1] + cc.v[2]) + (cc.v[3] + cc.v[4])) + cc.b) + (h[0][1] + row_o[0]);
+      const int line = jl - (LV - 1);
+      if (nact == LV && owner && line >= 0 && line < L) xo[(J0 + line) * dv.S + gi] = sum_;
+      return;
+    }
     bool fast = true;
 #pragma unroll
     for (int t = 1; t <= LV; ++t)
@@ -304,16 +313,23 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
             const T num = w * (cc.b - acc);
             T xn;
             if constexpr (RCP) {
+#ifdef GLA_CONTRACTED_FP
+              // (the opt-in "contracted_fp" BUILD VARIANT, never the default and never bit-exact: the row sum above contracts into
+              //  FMAs under -ffp-contract=fast and the division becomes ONE multiply-add with RN(1 / A_ii): what the bit-exact
+              //  formulation costs is measured with it -- bench.py side record `contracted_fp`, parity at 1e-12 in the GPU suite)
+              xn = fma_t(num, crc[ci], h[t - 1][1]);
+#else
               const T an = __builtin_fabs(num);
               bad = bad || !(an > Lim::nlo && an < Lim::nhi);
               const T q0 = num * crc[ci];
               const T rem = fma_t(-q0, DGC ? cc.v[2] : cc.dg, num);
               xn = h[t - 1][1] + fma_t(rem, crc[ci], q0);
+#endif
             } else {
               xn = h[t - 1][1] + num / (DGC ? cc.v[2] : cc.dg);
             }
             if (t < LV) { h[t][2] = xn; row[2 * LW + 1] = xn; }     // level t, same line (same parity)
-            if (t == TS) { if (owner && (!RES || (line >= 0 && line < L))) xo[(J0 + line) * dv.S + gi] = xn; }
+            if (t == TS) { if ((DBG & 2) ? (owner && xn == T(123.456)) : (owner && (!RES || (line >= 0 && line < L)))) xo[(J0 + line) * dv.S + gi] = xn; }
           }
           __builtin_amdgcn_sched_barrier(0);       // levels stay in program order: the scheduler's own interleaving of seven
         }                                          // levels costs more registers than the two waves per SIMD leave
@@ -392,24 +408,24 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
 // 1: the centre coefficient, said so by the caller (diag == NULL on a symmetric full-stencil plan): the DGC body; 2: the device
 // flag of gla_jacobi_sweeps_aos decides, ONCE, at kernel start, between the two bodies -- the later passes of the module path
 // run the DGC body without a second launch (the flag is raised only where vertex_attr[:, 0] is not the matrix diagonal).
-template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, int DGM, int PF = 1>
+template <typename T, int TS, int MODE, bool RCP, int HD, bool STATIC_IDX, bool SYM, bool FM, int DGM, int PF = 1, int DBG = 0>
 __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, const T* __restrict__ diag,
                                                                      const T* __restrict__ bvec, const T* __restrict__ x,
                                                                      T* __restrict__ xo, T w, int lines, int nstrips, TileMap tm,
                                                                      int tile_base0, int tile_split, int tile_base1, int64_t ldva,
                                                                      T* __restrict__ diag_out, T* __restrict__ b_out) {
   if constexpr (DGM == 1) {
-    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true, PF>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true, PF, DBG>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                            tile_base1, ldva, diag_out, b_out);
   } else if constexpr (DGM == 2) {
     if (__builtin_amdgcn_readfirstlane(*dv.dg_flag) != dv.dg_epoch)
-      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true, PF>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true, PF, DBG>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                              tile_base1, ldva, diag_out, b_out);
     else
-      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false, PF>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+      m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false, PF, DBG>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                               tile_base1, ldva, diag_out, b_out);
   } else {
-    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false, PF>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
+    m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, false, PF, DBG>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                             tile_base1, ldva, diag_out, b_out);
   }
 }
@@ -523,6 +539,9 @@ int m5_launch_sym(const gla_march5_args& a) {
         case 1: M5V(0, false, 1); break; case 2: M5V(1, false, 1); break; case 3: M5V(3, false, 1); break;
         case 4: M5V(2, false, 2); break; case 5: M5V(0, false, 2); break; case 6: M5V(3, false, 2); break;
         case 7: M5V(2, false, 3); break; case 8: M5V(0, false, 3); break;
+#define M5D(DBGV) hipLaunchKernelGGL((jacobi_march5_kernel<T, TS, MODE, true, 2, false, SYM, FM, DGM, 1, DBGV>), grid, block, lds, a.st, dv, (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1, a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out)
+        case 9: M5D(1); break; case 10: M5D(2); break; case 11: M5D(4); break; case 12: M5D(8); break;
+        case 13: M5D(3); break; case 14: M5D(9); break; case 15: M5D(5); break;
         default: return GLA_ERR_INVALID_ARG;
       }
       GLA_LAUNCH_CHECK();

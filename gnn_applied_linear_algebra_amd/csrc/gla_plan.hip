@@ -623,6 +623,7 @@ __global__ __launch_bounds__(GLA_BLOCK) void dia_sym_kernel(const T* __restrict_
 
 template <typename T, typename U>
 int detect_dia_sym(gla_csr* p, hipStream_t st) {
+  if (p->sym_pending) (void)gla_dia_sym_bits(p);     // (a check still in flight writes the words this one reuses)
   p->dia_sym = 0;
   if (p->dia_state != 1 || !p->dia_val || p->dia_row_lo != 0 || p->dia_row_hi != p->n_rows || p->n_rows != p->n_cols ||
       p->dia_S <= 0 || !p->dia_nowrap)
@@ -630,20 +631,23 @@ int detect_dia_sym(gla_csr* p, hipStream_t st) {
   int n_neg = 0;
   for (int d = 0; d < p->dia_D; ++d) n_neg += p->dia_off[d] < 0;
   if (n_neg == 0) return GLA_OK;
-  int* d_broken = nullptr;
-  int h_broken = 0;
-  hipError_t e = hipMalloc(&d_broken, sizeof(int));
-  if (e != hipSuccess) return -(1000 + (int)e);
-  e = hipMemsetAsync(d_broken, 0, sizeof(int), st);
+  hipError_t e = hipSuccess;
+  if (!p->sym_dev) {                                 // once per plan
+    e = hipMalloc(&p->sym_dev, sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc(&p->sym_host, sizeof(int));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->sym_event, hipEventDisableTiming);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -(1000 + (int)e); }
+  }
+  e = hipMemsetAsync(p->sym_dev, 0, sizeof(int), st);
   if (e == hipSuccess) {
     hipLaunchKernelGGL((dia_sym_kernel<T, U>), dim3(grid_for(p->n_rows)), dim3(GLA_BLOCK), 0, st, (const T*)p->dia_val, p->n_rows,
-                       p->dia_D, dia_offsets_of(p), d_broken);
-    e = hipMemcpyAsync(&h_broken, d_broken, sizeof(int), hipMemcpyDeviceToHost, st);
+                       p->dia_D, dia_offsets_of(p), p->sym_dev);
+    e = hipMemcpyAsync(p->sym_host, p->sym_dev, sizeof(int), hipMemcpyDeviceToHost, st);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(d_broken);
-  if (e != hipSuccess) return -(1000 + (int)e);
-  p->dia_sym = ((1 << n_neg) - 1) & ~h_broken;
+  if (e == hipSuccess) e = hipEventRecord(p->sym_event, st);
+  if (e != hipSuccess) { (void)hipGetLastError(); return -(1000 + (int)e); }
+  p->sym_mask = (1 << n_neg) - 1;
+  p->sym_pending = 1;                                // (resolved by the first reader: gla_dia_sym_bits)
   return GLA_OK;
 }
 
@@ -889,6 +893,10 @@ int gla_csr_destroy(gla_csr_t p) {
   if (p->dia_mask) (void)hipFree(p->dia_mask);
   if (p->dia_val) (void)hipFree(p->dia_val);
   if (p->dg_flags) (void)hipFree(p->dg_flags);
+  if (p->sym_pending && p->sym_event) (void)hipEventSynchronize(p->sym_event);
+  if (p->sym_dev) (void)hipFree(p->sym_dev);
+  if (p->sym_host) (void)hipHostFree(p->sym_host);
+  if (p->sym_event) (void)hipEventDestroy(p->sym_event);
   if (p->vcode) (void)hipFree(p->vcode);
   if (p->vdict) (void)hipFree(p->vdict);
   delete p;
@@ -1047,6 +1055,7 @@ int gla_csr_set_values(gla_csr_t p, const void* edge_val, int64_t stride, int dt
     if (rc) return rc;
   }
   p->dia_const = 0;
+  if (p->sym_pending) (void)gla_dia_sym_bits(p);
   p->dia_sym = 0;
   if (g_tuning.sym) {                                 // (one pass over the diagonals + a host wait, once per value set)
     const int rc = dtype == GLA_F64 ? detect_dia_sym<double, uint64_t>(p, st) : detect_dia_sym<float, uint32_t>(p, st);
@@ -1075,7 +1084,7 @@ int gla_csr_info(gla_csr_t p, gla_csr_info_t* info) {
   info->dia_A = info->dia ? p->dia_A : 0;
   info->dia_B = info->dia ? p->dia_B : 0;
   info->dia_canon5 = info->dia && gla_dia_canon5(p) ? 1 : (info->dia && gla_dia_canon9(p) ? 9 : 0);
-  info->dia_sym = info->dia && g_tuning.sym ? p->dia_sym : 0;
+  info->dia_sym = info->dia && g_tuning.sym ? gla_dia_sym_bits(p) : 0;
   info->dia_full = info->dia && gla_dia_full5(p) ? 1 : 0;
   return GLA_OK;
 }

@@ -598,6 +598,19 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_kernel(
 // MODE 1: branch-free clamped batches (surplus lanes re-read the last entry and are masked out of the sum).
 constexpr int SPMM_ROWCAP = 1024;               // row offsets staged per tile (more rows -> read rowptr directly)
 
+// Sum over the N consecutive chunks c0 .. c0 + N - 1 of a heavy row in the association order of the K = 1 kernel's xor tree
+// (level l adds the blocks of 2^l chunks that differ in bit l): a balanced binary tree over aligned blocks of chunks.
+template <int N, typename V, class F>
+__device__ __forceinline__ V chunk_tree(int c0, const F& chunk) {
+  if constexpr (N == 1) {
+    return chunk(c0);
+  } else {
+    const V lo = chunk_tree<N / 2, V>(c0, chunk);
+    const V hi = chunk_tree<N / 2, V>(c0 + N / 2, chunk);
+    return lo + hi;
+  }
+}
+
 template <typename T, int LPR, int MODE, class Epi, int VW = 2, bool FLAT = false>
 __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const T* __restrict__ val,
@@ -694,12 +707,75 @@ __global__ __launch_bounds__(GLA_BLOCK) void spmm_stream_vec2_kernel(
     constexpr int RPP = GLA_BLOCK / LPR;          // rows per pass
     const int rsub = tid / LPR;
     const auto gxs0 = epi.template gx_load<T2>(min(k0, max(K - VW, 0)));
-    for (int r = r0 + rsub; r < r1; r += RPP) {
-      int a, b;
-      row_bounds(r, a, b);
-      for (int k = k0; k < K; k += VW * LPR) {
-        if (k == k0) row_vec(r, k, a, b, gxs0);
-        else row_vec(r, k, a, b, epi.template gx_load<T2>(k));
+    // The VECTOR BIN for K > 1 (round 5; option row_sum, as for K = 1).  A row of GLA_WAVE_ROW (64) nonzeros or more is summed
+    // by ALL 64 lanes of the wave its lane group belongs to instead of by its LPR lanes alone (a tile of a few long rows kept
+    // 8 x LPR of 256 lanes busy): the row is cut into the SAME 64 contiguous chunks of ceil(len / 64) nonzeros as in
+    // spmv_stream_vec2_kernel, lane (g, kv) -- group g of 64 / LPR, right-hand-side vector kv -- sums chunks g LPR .. g LPR +
+    // LPR - 1 for its vector in edge order and combines them in the xor tree's order (chunk_tree), the groups meet in
+    // cross-lane shuffles at distances LPR, 2 LPR, ..: per right-hand side exactly the association order of the K = 1 kernel,
+    // a function of the row's own length -- column k of an SpMM equals the SpMV on column k bit for bit, on any partition.
+    constexpr bool VECBIN = MODE == 0 && LPR <= 32;
+    const int lane = tid & 63;
+    for (int rb = r0; rb < r1; rb += RPP) {       // (wave-uniform: the heavy rows of a wave are worked on by all its lanes)
+      const int r = rb + rsub;
+      const bool have = r < r1;
+      int a = 0, b = 0;
+      if (have) row_bounds(r, a, b);
+      bool heavy = false;
+      unsigned long long hm0 = 0;
+      if constexpr (VECBIN) {
+        heavy = tm.vec && have && (b - a) >= GLA_WAVE_ROW;
+        hm0 = __ballot(heavy && (lane % LPR) == 0);
+      }
+      for (int kk = 0; kk < K; kk += VW * LPR) {
+        const int k = kk + k0;
+        const bool kact = k < K;
+        T2 hacc = T2(T(0));
+        if constexpr (VECBIN) {
+          unsigned long long hm = hm0;
+          while (hm) {                            // (wave-uniform loop)
+            const int hl = __ffsll((long long)hm) - 1;
+            hm &= hm - 1;
+            const int ha = __shfl(a, hl, 64), hb = __shfl(b, hl, 64);
+            const int chunk = (hb - ha + 63) >> 6;
+            const auto gxs = epi.template gx_load<T2>(kact ? k : max(K - VW, 0));
+            const T* Xk = X + (kact ? k : 0);
+            auto chunk_sum = [&](int c) -> T2 {
+              int j = ha + c * chunk;
+              const int jend = min(j + chunk, hb);
+              T2 acc = T2(T(0));
+              for (; j + 4 <= jend; j += 4) {
+                T2 xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = epi.gx(ldv<T2>(Xk + (int64_t)scol[j + u] * ldx), gxs);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = acc + sval[j + u] * xv[u];
+              }
+              for (; j < jend; ++j) acc = acc + sval[j] * epi.gx(ldv<T2>(Xk + (int64_t)scol[j] * ldx), gxs);
+              return acc;
+            };
+            T2 part = chunk_tree<LPR, T2>((lane / LPR) * LPR, chunk_sum);
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) {
+              T2 oth;
+#pragma unroll
+              for (int i = 0; i < VW; ++i) oth[i] = __shfl_xor(part[i], off, 64);
+              part = part + oth;
+            }
+            if (lane / LPR == hl / LPR) hacc = part;
+          }
+        }
+        if (have && kact) {
+          if (heavy) {
+            const auto pre = epi.template loadv<T2>((int64_t)r, k);
+            epi.template applyv<T2>((int64_t)r, k, hacc, pre);
+            if constexpr (Epi::NRED > 0) red = red + epi.template redv<T2>(hacc, pre);
+          } else if (kk == 0) {
+            row_vec(r, k, a, b, gxs0);
+          } else {
+            row_vec(r, k, a, b, epi.template gx_load<T2>(k));
+          }
+        }
       }
     }
   }
@@ -1382,7 +1458,7 @@ inline bool jacobi_canon(const gla_csr* A) { return g_tuning.jacobi_march && gla
 inline bool jacobi_canon9(const gla_csr* A) { return g_tuning.jacobi_march && gla_dia_canon9(A); }
 constexpr int JACOBI_TS_MAX9 = 6;
 
-inline bool jacobi_sym9(const gla_csr* A) { return g_tuning.sym && gla_dia_canon9(A) && (A->dia_sym & 15) == 15; }
+inline bool jacobi_sym9(const gla_csr* A) { return g_tuning.sym && gla_dia_canon9(A) && (gla_dia_sym_bits(A) & 15) == 15; }
 // the SYM instances that keep two waves per SIMD (256 registers; the others are not built: those passes read all nine diagonals)
 template <typename T, int TS, bool AOS, bool RES>
 constexpr bool march9_sym_fits() { return sizeof(T) == 4 || (AOS || RES ? TS <= 4 : TS <= 5); }
@@ -1666,7 +1742,7 @@ int launch_rows(gla_csr* A, int K, const T* X, int64_t ldx, const Epi& epi, int 
       for (int i = 0; i < GLA_DIA_MAX; ++i) dv.partner[i] = -1;
       if (g_tuning.sym && d_lo == 0 && d_hi == A->n_rows && A->n_rows == A->n_cols)
         for (int i = 0; i < A->dia_D; ++i)
-          if (A->dia_off[i] < 0 && ((A->dia_sym >> i) & 1))
+          if (A->dia_off[i] < 0 && ((gla_dia_sym_bits(A) >> i) & 1))
             for (int q = i + 1; q < A->dia_D; ++q)
               if (A->dia_off[q] == -A->dia_off[i]) dv.partner[i] = q;
       if (constv && which == 0 && A->dia_D <= 5)

@@ -825,6 +825,65 @@ class RowBlockJacobi(RowBlockOps):
         run.graph, run.static_va, run.out = graph, static_va, out
         return run
 
+    def capture_forward_native(self, n_iters, vertex_attr, g):
+        """forward(n_iters, vertex_attr, g) of the temporally blocked route as ONE HIP graph built by the library itself
+        (gla_dist_jacobi_temporal_graph: hipStreamBeginCapture on streams the graph owns -- no torch graph machinery, which is
+        what a C++ host would call).  Returns run(vertex_attr) -> x [n_local, 1]; run.replay() launches the graph on torch's
+        current stream with the operands as they stand (run.static_va in, run.out out).  The graph has its OWN extended work
+        vectors: eager forward() calls and replays do not share buffers.  Every rank must build and replay alike.  Raises
+        GlaError where the library declines (the block is not a canonical 5-point block, a pass of one sweep, ...)."""
+        import ctypes
+        from ._lib import check, dtype_code, lib, ptr, stream_ptr
+        e, p = self.ext, self.part
+        if e is None or self.comm is None or vertex_attr.dim() != 2 or vertex_attr.dtype != e["dtype"]:
+            raise ValueError("capture_forward_native needs the temporally blocked route on the library's communicator (K = 1)")
+        va = vertex_attr.clone() if vertex_attr.stride(1) == 1 else vertex_attr.contiguous().clone()
+        n_ext, off, nl = e["n_ext"], e["off"], p.n_local
+        dev, dt = va.device, va.dtype
+        T, S = self.TS_MAX, e["S"]
+        m = T * S
+        passes = list(self._sched(int(n_iters), dt))
+        bufs = [torch.ones(n_ext, dtype=dt, device=dev)] + [torch.zeros(n_ext, dtype=dt, device=dev) for _ in range(4)]
+        d_ext, b_ext, xa, xb, x_last = bufs
+        send, recv = torch.empty(6 * m, dtype=dt, device=dev), torch.empty(p.world * 6 * m, dtype=dt, device=dev)
+        arr = (ctypes.c_int * len(passes))(*passes)
+        h = ctypes.c_void_p()
+        torch.cuda.synchronize(dev)
+        check(lib().gla_dist_jacobi_temporal_graph(e["plan"]._h, self.comm._h, dtype_code(dt), ptr(va), va.stride(0), off, nl, ptr(d_ext),
+                                                   ptr(b_ext), ptr(xa), ptr(xb), ptr(x_last), ptr(send), ptr(recv), T, int(e["up"]),
+                                                   int(e["down"]), int(e.get("up_src", p.rank - 1)), int(e.get("down_src", p.rank + 1)),
+                                                   scalar0(g), arr, len(passes), ctypes.byref(h)))
+        out = x_last[off:off + nl].reshape(-1, 1)
+        n_ex = len(passes)
+
+        class _Run:
+            static_va, graph_handle = va, h
+            _keep = (bufs, send, recv, self)
+
+            def replay(self_):
+                check(lib().gla_graph_launch(h, stream_ptr(dev)))
+                EXCHANGES[0] += n_ex
+
+            def __call__(self_, v):
+                va.copy_(v)
+                self_.replay()
+                return out.clone()
+
+            def close(self_):
+                if self_.graph_handle is not None:
+                    torch.cuda.synchronize(dev)
+                    lib().gla_graph_destroy(self_.graph_handle)
+                    self_.graph_handle = None
+
+            def __del__(self_):
+                try:
+                    self_.close()
+                except Exception:                            # noqa: BLE001 -- interpreter shutdown
+                    pass
+        run = _Run()
+        run.out = out
+        return run
+
     def forward(self, n_iters, vertex_attr, g):
         p = self.part
         va = vertex_attr

@@ -437,6 +437,20 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
                              void* recv, int ghost_lines, int up, int down, int up_src, int down_src, double w,
                              const int* passes, int n_passes, gla_stream_t main_stream, gla_stream_t side_stream);
 
+/* The same call captured ONCE into a HIP graph (two streams owned by the graph + the communicator's stream; RCCL's all-gathers
+ * and the A_ii flag's memset node included) and replayed with one launch per forward(): the eager call is ~10 enqueues and
+ * ~90 us of host time per pass, which bounds a rank once its block is small (BASELINE config 4 on 8 GPUs: ~100 us of GPU time
+ * per pass).  Runs the sequence once eagerly first (code loads, the plan's flag words), then captures it.  Operand ADDRESSES
+ * are frozen into the graph: keep the buffers, refresh vertex_attr in place, read the result from x_last after
+ * gla_graph_launch.  Every rank of the communicator must create and launch alike.  JacobiGNN.py:138-148, multi-GPU form. */
+typedef struct gla_graph* gla_graph_t;
+int gla_dist_jacobi_temporal_graph(gla_csr_t A, gla_comm_t c, int dtype, const void* vertex_attr, int64_t ld, int64_t row_offset,
+                                   int64_t n_local, void* diag_ext, void* b_ext, void* xa, void* xb, void* x_last, void* send,
+                                   void* recv, int ghost_lines, int up, int down, int up_src, int down_src, double w,
+                                   const int* passes, int n_passes, gla_graph_t* out);
+int gla_graph_launch(gla_graph_t g, gla_stream_t stream);
+int gla_graph_destroy(gla_graph_t g);
+
 /* ---- builders ----------------------------------------------------------------------------------- */
 /* 5-point negative Laplacian on an Ny x Nx grid (reference: Ny == Nx == N), COO sorted row-major with
  * ascending columns: row/col int64 [nnz], val [nnz], nnz = 5*Nx*Ny - 2*Nx - 2*Ny.

@@ -1,5 +1,7 @@
-"""Experimental instances of the 7-sweep DGC pass (GLA_M5_VARIANTS builds): option m5_variant 0 (shipped) .. 8.
-Usage: python tools/ab_m5_variants.py [N=4096]"""
+"""Experimental instances of the 7-sweep DGC pass (GLA_M5_VARIANTS builds: libgla_hip_variants.so, picked up through GLA_LIB_PATH):
+option m5_variant 0 (shipped) .. 8 (LDS read-ahead / prefetch depth, bit-identical) and 9 .. 15 (TIMING experiments with WRONG
+results: no barrier, no output store, no s_setprio, the memory side alone, and combinations -- what each part of a line step
+costs).  Usage: GLA_LIB_PATH=gnn_applied_linear_algebra_amd/libgla_hip_variants.so python tools/ab_m5_variants.py [N=4096]"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import gnn_applied_linear_algebra_amd as gla
@@ -14,7 +16,9 @@ b = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
 x = torch.rand(n, 1, generator=gen, dtype=torch.float64).to(dev)
 out = torch.empty_like(x)
 st = stream_ptr(dev)
-names = {0: "shipped (hd2)", 1: "hd0", 2: "hd1", 3: "hd3", 4: "pf2 hd2", 5: "pf2 hd0", 6: "pf2 hd3", 7: "pf3 hd2", 8: "pf3 hd0"}
+names = {0: "shipped (hd2)", 1: "hd0", 2: "hd1", 3: "hd3", 4: "pf2 hd2", 5: "pf2 hd0", 6: "pf2 hd3", 7: "pf3 hd2", 8: "pf3 hd0",
+         9: "NO BARRIER", 10: "NO OUTPUT STORE", 11: "no s_setprio", 12: "MEMORY SIDE ONLY (no levels)", 13: "no barrier, no store",
+         14: "memory side only, no barrier", 15: "no barrier, no s_setprio"}
 
 
 def med(fn, reps=15):
@@ -33,9 +37,9 @@ for _ in range(300):
 torch.cuda.synchronize()
 ref = out.clone()
 for rnd in range(3):
-    for v in range(9):
+    for v in range(16):
         if lib().gla_set_option(b"m5_variant", v) != 0:
             continue
         m, mn = med(run)
-        print(f"variant {v} {names[v]:14s}: {m:7.1f} us (min {mn:.1f})  identical {bool(torch.equal(out, ref))}")
+        print(f"variant {v:2d} {names[v]:30s}: {m:7.1f} us (min {mn:.1f})  identical {bool(torch.equal(out, ref))}")
 check(lib().gla_set_option(b"m5_variant", 0))

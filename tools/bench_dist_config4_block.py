@@ -6,8 +6,8 @@ the rank itself (RowBlockJacobi.rehearsal_self_halo) -- everything a rank does p
 
   * eager: gla_dist_jacobi_temporal enqueues ~10 operations per pass from the host (89 us per pass, profiles/r03/
     dist_route_host_cost.txt) next to ~100 us of GPU time per pass at this block size: host-bound;
-  * replayed from a HIP graph (RowBlockJacobi.capture_forward: the pack launches, ncclAllGathers on the library's stream,
-    interior / edge launches on two streams, the A_ii flag's memset node) -- bit-identical;
+  * replayed from a HIP graph built by the library (RowBlockJacobi.capture_forward_native -> gla_dist_jacobi_temporal_graph: the
+    pack launches, ncclAllGathers, interior / edge launches on two streams, the A_ii flag's memset node) -- bit-identical;
 
 next to JacobiGNN.forward on the whole 8192 x 8192 matrix on this GPU.  bound_on_speedup = (8192^2 step) / (block step): what 8
 GPUs can reach on config 4 before inter-GPU latency and load imbalance (north_star asks for >= 6).
@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 as_json = "--json" in sys.argv
+block_only = "--block-only" in sys.argv                        # (for kernel traces: no graph, no whole-matrix run)
 Nx = int(args[0]) if len(args) > 0 else 8192
 ranks = int(args[1]) if len(args) > 1 else 8
 sweeps = int(args[2]) if len(args) > 2 else 20
@@ -81,14 +82,16 @@ rec = {"what": f"one rank's block of BASELINE config 4 cut {ranks} ways ({lines}
        "eager_ms_per_step": round(w_e * 1e3, 4), "eager_host_us_per_step": round(h_e * 1e6, 1),
        "eager_host_us_per_pass": round(h_e * 1e6 / len(sched), 1)}
 try:
-    run = drv.capture_forward(sweeps, va, g)
+    if block_only:
+        raise RuntimeError("--block-only")
+    run = drv.capture_forward_native(sweeps, va, g)
     note("captured")
     out = run(va)
     torch.cuda.synchronize()
     same = bool(torch.equal(out, want))
     # ... and against an eager call made AFTER the capture (the eager path must not trust what the capture left behind)
     same = same and bool(torch.equal(drv.forward(sweeps, va, g), want)) and bool(torch.equal(run(va), want))
-    h_g, g_g, w_g = host_and_gpu(run.graph.replay)
+    h_g, g_g, w_g = host_and_gpu(run.replay)
     h_r, g_r, w_r = host_and_gpu(lambda: run(va))
     rec.update({"graph_replay_ms_per_step": round(w_g * 1e3, 4), "graph_replay_host_us_per_step": round(h_g * 1e6, 1),
                 "graph_run_incl_operand_copy_and_result_clone_ms": round(w_r * 1e3, 4), "graph_bit_identical_to_eager": same})
@@ -102,7 +105,7 @@ del run, drv
 torch.cuda.empty_cache()
 # the whole matrix on this GPU through the module surface (what config4_1gpu of bench.py times)
 free, _ = torch.cuda.mem_get_info()
-if free > 40e9:
+if free > 40e9 and not block_only:
     ei, ev = gla.UtilsGNN.laplacianfun_torch(Nx, device=dev)
     n = Nx * Nx
     ea = torch.cat([ev, torch.zeros_like(ev)], 1)
