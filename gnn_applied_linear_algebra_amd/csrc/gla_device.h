@@ -21,6 +21,7 @@ struct TileMap {
   int n_tiles;                // tiles to run in this launch
   int tiles_per_xcd;
   int xcd_chunk;              // see map_tile
+  int balanced = 0;           // 1 / 2: XCD e takes floor(n / 8) consecutive tiles, the n % 8 extra ones go to the first (1) / last (2) XCDs
   int lds_cap = 0x7fffffff;   // tiles with more nonzeros than this are single long rows (CSR-adaptive "long" bin)
   int vec = 0;                // CSR-adaptive "vector" bin: rows of >= GLA_WAVE_ROW nonzeros are summed by their wave (option row_sum)
 };
@@ -51,6 +52,19 @@ __device__ __forceinline__ int map_tile(const TileMap& m) {
   // common region of HBM, and a tile's x window (a few grid lines) is re-fetched by neighbouring XCDs from the
   // Infinity Cache rather than from DRAM.
   int slot;
+  if (m.balanced) {
+    // Two launches that share the chip (the interior and the edge launch of a split multi-GPU pass: 442 + 68 workgroups on 512
+    // slots, two per CU) must fit PER XCD -- 64 slots each.  The chunked numbering below gives seven XCDs 56 + 9 = 65 workgroups:
+    // one edge workgroup per XCD waited ~95 us for an interior workgroup to finish, and with it the next pass's exchange
+    // (tools/time_edge_blocks.py: the edge launch took 90 us beside the interior launch, 32 us alone).  Balanced: every XCD gets
+    // floor(n / 8) tiles and the n % 8 extra ones go to the FIRST XCDs in one launch (1), to the LAST in the other (2).
+    const int xcd = bid % GLA_XCDS, j = bid / GLA_XCDS, q = m.n_tiles / GLA_XCDS, r = m.n_tiles % GLA_XCDS;
+    const int extra = m.balanced == 1 ? (xcd < r ? 1 : 0) : (xcd >= GLA_XCDS - r ? 1 : 0);
+    if (j >= q + extra) return -1;
+    const int before = m.balanced == 1 ? (xcd < r ? xcd : r) : (xcd > GLA_XCDS - r ? xcd - (GLA_XCDS - r) : 0);
+    slot = xcd * q + before + j;
+    return m.tile_list ? m.tile_list[slot] : slot;
+  }
   if (m.xcd_chunk > 0) {
     const int C = m.xcd_chunk, xcd = bid % GLA_XCDS, j = bid / GLA_XCDS;
     slot = (j / C) * (GLA_XCDS * C) + xcd * C + (j % C);

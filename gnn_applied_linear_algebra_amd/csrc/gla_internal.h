@@ -104,6 +104,7 @@ struct gla_tuning {
   int jacobi_diag_flag = 1; // gla_jacobi_sweeps_aos on 5-point march plans: 1 = no A_ii copy; the first pass flags whether A_ii repeats the matrix
                             // diagonal, the later passes skip the A_ii stream if so (else read the AoS column); 0 = contiguous copies as before
   int m5_variant = 0;       // (experiments: GLA_M5_VARIANTS builds only)
+  int edge_prio = 1;        // the edge launch of a split multi-GPU pass runs at raised wave priority (A/B: option edge_prio)
   int jacobi_march = 1;     // canonical 5-point plans: 1 = the register-history march kernel, 0 = the generic LDS-ring kernel
   int64_t jacobi_min_rows = 1 << 19;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
                                        // is faster: 512^2 takes 4.5 us per sweep single vs 5.9 fused, 768^2 8.4 vs 6.0)

@@ -50,7 +50,9 @@ template <> struct KLim<float> {
 };
 
 // D = 5: diagonals (-1,0) (0,-1) (0,0) (0,1) (1,0); D = 9: (a, b) in {-1, 0, 1}^2 row-major
-template <typename T, int KV, int TS, int D, int NT>
+// DBG (GLA_MK_VARIANTS builds only; results are WRONG with any bit set -- timing experiments, tools/ab_mk_variants.py): 1 no
+// barrier, 2 no output store, 4 no levels (the memory side alone), 8 no global loads in the line step (the compute side alone)
+template <typename T, int KV, int TS, int D, int NT, int DBG = 0>
 __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __restrict__ diag, const T* __restrict__ bvec,
                                                            int64_t ldb, const T* __restrict__ x0, int64_t ldx0,
                                                            T* __restrict__ xout, int64_t ldxo, T w, int lines, int nstrips,
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
     if constexpr (D == 5) {
       // 5-point: a level only needs the i -/+ 1 neighbours of ITS OWN line, which the level below wrote one line step
       // earlier: two lines per level (slot = line parity) and ONE barrier per line step (as jacobi_march5 / cheby_march5)
-      __syncthreads();
+      if constexpr (!(DBG & 1)) __syncthreads();
       const int pj = (jl + 64) & 1;
       if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
       TV* const row_e = buf + pj * LWV + ii * KV + q;          // lines of the parity of jl: [0] left, [KV] own, [2 KV] right
@@ -211,11 +213,20 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
       const bool whole_next = wave_in && jl + 1 >= jlo && jl + 1 < jhi;
       h[0][2] = (whole_next | live_at(jl + 1)) ? xpre : TV(T(0));
       row_o[KV] = h[0][2];                         // level 0, line jl + 1
-      xpre = x0_load(jl + 2);
-      c[(u + 1) % NC] = coef_at(jl + 1);
-      cb[(u + 1) % NC] = b_at(jl + 1);
+      if constexpr (!(DBG & 8)) {
+        xpre = x0_load(jl + 2);
+        c[(u + 1) % NC] = coef_at(jl + 1);
+        cb[(u + 1) % NC] = b_at(jl + 1);
+      }
       classify(jl, u);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((DBG & 4) != 0) {              // the memory side alone: every loaded value consumed, one store per (row, vector)
+        const Coef& cc = c[u % NC];
+        TV sum_ = (h[0][1] + cb[u % NC]) + (row_e[0] + row_e[2 * KV]);
+        sum_ = sum_ + TV((((cc.v[0] + cc.v[1]) + (cc.v[2] + cc.v[3])) + cc.v[4]) + cc.dg + (T)cc.m);
+        if (nact == TS && owner) stv<TV>(xout + ((J0 + jl - (TS - 1)) * S + gi) * ldxo + q * VW, sum_);
+        return;
+      }
       bool fast = true;
 #pragma unroll
       for (int t = 1; t <= TS; ++t)
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
             TV num;
             const TV xn = fast_level(c[ci], cb[ci], crc[ci], xs, h[t - 1][1], bad, num);
             if (t < TS) { h[t][2] = xn; row[2 * LWV + KV] = xn; }                     // level t, same line (same parity)
-            else if (owner) stv<TV>(xout + ((J0 + jl - (TS - 1)) * S + gi) * ldxo + q * VW, xn);
+            else if ((DBG & 2) ? (owner && xn[0] == T(123.456)) : owner) stv<TV>(xout + ((J0 + jl - (TS - 1)) * S + gi) * ldxo + q * VW, xn);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -369,6 +380,22 @@ int launch_marchk(gla_csr* A, const T* diag, const T* b, int64_t ldb, const T* x
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = (int)(((nlines + lines - 1) / lines) * nstrips);
   set_tile_mapping(tm);
+#ifdef GLA_MK_VARIANTS
+  if constexpr (sizeof(T) == 8 && KV == 8 && TS == 5 && D == 5) {
+    const int v = g_tuning.m5_variant;
+#define MKD(DBGV) do { if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)jacobi_marchk_kernel<T, KV, TS, D, NT, DBGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((jacobi_marchk_kernel<T, KV, TS, D, NT, DBGV>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(NT), lds, st, jv, diag, b, ldb, x, ldx, xo, ldxo, w, lines, nstrips, nlines, tm); } while (0)
+    if (v > 0) {
+      switch (v) {
+        case 1: MKD(1); break; case 2: MKD(2); break; case 3: MKD(4); break; case 4: MKD(8); break;
+        case 5: MKD(9); break; case 6: MKD(5); break; case 7: MKD(10); break;
+        default: return GLA_ERR_INVALID_ARG;
+      }
+      GLA_LAUNCH_CHECK();
+      return GLA_OK;
+    }
+  }
+#endif
   hipLaunchKernelGGL((jacobi_marchk_kernel<T, KV, TS, D, NT>), dim3((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), dim3(NT), lds,
                      st, jv, diag, b, ldb, x, ldx, xo, ldxo, w, lines, nstrips, nlines, tm);
   GLA_LAUNCH_CHECK();

@@ -62,6 +62,10 @@ struct M5View {
   const uint16_t* mask;       // [n_rows]
   int64_t S, n_rows, nlines;  // grid line length, rows (= columns), grid lines (the last one may be ragged)
   int32_t edge, nlb;          // multi-GPU interior / boundary split: height of the first / last line block (0: uniform), line blocks
+#ifdef GLA_M5_VARIANTS
+  unsigned long long* stamps; // experiments: per workgroup {start, end (s_memrealtime, 100 MHz), tile, HW_ID, XCC_ID, line steps}
+#endif
+  int32_t prio_hi;            // 1: the edge launch of a split pass (part 2) -- its waves run at raised priority throughout (below)
   int64_t aos_off, aos_rows;  // MODE 1: plan row r is row r - aos_off of an AoS tensor of aos_rows rows
   int64_t aos_wlo, aos_whi;   // MODE 1: grid lines [aos_wlo, aos_whi) get their contiguous copies of A_ii and b written by this launch
   int64_t ldd;                // MODE 0 / 2: stride of `diag` (1, or the row stride of the AoS tensor whose column 0 it points at)
@@ -147,6 +151,7 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
   const int jlo = (int)max((int64_t)-64, -J0), jhi = (int)min((int64_t)L + 64, nfull - J0);
   const bool wave_in = __all(in_i) != 0;
 
+  if (dv.prio_hi) __builtin_amdgcn_s_setprio(3);
   for (int i = tid; i < LV * 2 * LW; i += BW) buf[i] = T(0);   // (the pads stay +0: what lies beyond a line's ends)
   __syncthreads();
 
@@ -224,7 +229,10 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
     const int u = ic_val(u_c), nact = ic_val(nact_c);
     if constexpr (!(DBG & 1)) __syncthreads();
     const int pj = (jl + 64) & 1;
-    if constexpr (!(DBG & 4)) { if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+    // (the edge launch of a split pass keeps the raised priority it took at kernel start: its 2 x nstrips workgroups share their
+    //  SIMDs with OLDER interior waves, which the arbiter serves first -- 94 us beside the interior launch against 32 us alone
+    //  (tools/time_edge_blocks.py), and the next pass's exchange waits for exactly these blocks)
+    if constexpr (!(DBG & 4)) { if (!dv.prio_hi) { if (pj ^ late) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
     T* const row_e = buf + pj * LW + tid;          // lines of the parity of jl:     [0] left, [1] own, [2] right
     T* const row_o = buf + (1 - pj) * LW + tid;    // lines of the other parity
     auto lds_row = [&](int t) -> T* { return ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LW; };   // level t - 1, line of level t
@@ -414,6 +422,21 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
                                                                      T* __restrict__ xo, T w, int lines, int nstrips, TileMap tm,
                                                                      int tile_base0, int tile_split, int tile_base1, int64_t ldva,
                                                                      T* __restrict__ diag_out, T* __restrict__ b_out) {
+#ifdef GLA_M5_VARIANTS
+  struct Stamp {
+    unsigned long long* p; unsigned long long t0;
+    __device__ Stamp(unsigned long long* buf) : p(buf), t0(buf ? __builtin_amdgcn_s_memrealtime() : 0) {}
+    __device__ ~Stamp() {
+      if (p && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* q = p + 4 * (size_t)blockIdx.x;
+        q[0] = t0; q[1] = __builtin_amdgcn_s_memrealtime(); q[2] = ((unsigned long long)xcc << 32) | hw; q[3] = blockIdx.x;
+      }
+    }
+  } stamp_(dv.stamps);
+#endif
   if constexpr (DGM == 1) {
     m5_body<T, TS, MODE, RCP, HD, STATIC_IDX, SYM, FM, true, PF, DBG>(dv, diag, bvec, x, xo, w, lines, nstrips, tm, tile_base0, tile_split,
                                                            tile_base1, ldva, diag_out, b_out);
@@ -444,6 +467,10 @@ template <typename T, int TS, int MODE, int LV, bool SYM, bool FM, int DGM> stru
   static constexpr auto kernel = jacobi_march5_kernel<T, TS, MODE, C::rcp, C::hd, C::static_idx, SYM, FM, DGM>;
 };
 #define M5_KERNEL(T, TS, MODE, LV, SYM, FM, DGM) M5Pick<T, TS, MODE, LV, SYM, FM, DGM>::kernel
+
+#ifdef GLA_M5_VARIANTS
+unsigned long long* g_m5_stamps[2] = {nullptr, nullptr};      // [0]: parts 0 / 1, [1]: part 2 (experiments: gla_debug_m5_stamps)
+#endif
 
 template <typename T, int TS, int MODE, bool SYM, bool FM, int DGM>
 int m5_blocks_per_cu() {
@@ -508,8 +535,17 @@ int m5_launch_sym(const gla_march5_args& a) {
     // a second stream launches once the ghost lines are in.  A march workgroup takes half a CU's registers, so on a chip full
     // of interior workgroups the edge launch (and even the small ghost-fill kernel before it) waits for the interior launch
     // to drain -- 54 us behind it instead of beside it (kernel trace of the one-GPU rehearsal, profiles/r03).
+    // Round 5: slots are 32 x per_cu PER XCD, workgroup b of either launch runs on XCD b % 8, and the last slot of an XCD is not
+    // reliably there for a second launch (per-workgroup time stamps, profiles/r05/edge_blocks_trace.txt: with 56 + 9 workgroups on an
+    // XCD -- and even with 55 + 1 that exits at once + 9 -- one edge workgroup per XCD started ~45 us late, behind another edge
+    // workgroup, and the edge launch took 90 us instead of 32; the next pass's exchange waits for exactly these blocks).  The
+    // interior launch therefore takes at most 32 per_cu - 1 - ceil(2 nstrips / 8) workgroups per XCD.
     int64_t slots = 256 * (int64_t)per_cu;
-    if (edge && slots > 4 * (int64_t)nstrips) slots -= 2 * (int64_t)nstrips;
+    if (edge && slots > 4 * (int64_t)nstrips) {
+      const int64_t edge_x = (2 * (int64_t)nstrips + GLA_XCDS - 1) / GLA_XCDS;
+      const int64_t int_x = 32 * (int64_t)per_cu - (g_tuning.edge_prio ? 1 : 0) - edge_x;
+      slots = g_tuning.edge_prio ? GLA_XCDS * int_x : slots - 2 * (int64_t)nstrips;
+    }
     lines = gla_pick_block_lines(inner_lines, nstrips, slots, 2 * (LV - 1), 2 * LV);
     if (lines > 1024) lines = 1024;
   }
@@ -517,6 +553,10 @@ int m5_launch_sym(const gla_march5_args& a) {
   const int nlb_all = (int)((inner_lines + lines - 1) / lines) + (edge ? 2 : 0);
   dv.edge = edge;
   dv.nlb = nlb_all;
+  dv.prio_hi = (part == 2 && edge && g_tuning.edge_prio) ? 1 : 0;
+#ifdef GLA_M5_VARIANTS
+  dv.stamps = g_m5_stamps[part == 2 ? 1 : 0];
+#endif
   int base0 = 0, split = nlb_all * nstrips, base1 = 0, count = nlb_all * nstrips;
   if (part == 1) {                                  // line blocks 1 .. nlb - 2
     if (!edge) return GLA_OK;
@@ -528,6 +568,10 @@ int m5_launch_sym(const gla_march5_args& a) {
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = count;
   set_tile_mapping(tm);
+  if (part != 0 && edge && g_tuning.edge_prio) {    // the two launches of a split pass share the chip: they must fit per XCD (map_tile)
+    tm.balanced = part == 1 ? 1 : 2;
+    tm.tiles_per_xcd = (count + GLA_XCDS - 1) / GLA_XCDS;
+  }
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
 #ifdef GLA_M5_VARIANTS
@@ -595,6 +639,13 @@ int m5_dispatch_ts(const gla_march5_args& a) {
 // (gla_rows.hip) has checked the plan (jacobi_fused_ok + gla_dia_canon5) and the operands.
 // Two translation units (the instances take minutes to compile): this file holds the fp64 instances and the entry point,
 // gla_march5_f32.hip includes it with GLA_M5_F32_TU defined and holds the fp32 ones.
+#if defined(GLA_M5_VARIANTS) && !defined(GLA_M5_F32_TU)
+extern "C" int gla_debug_m5_stamps(void* interior_buf, void* edge_buf) {
+  g_m5_stamps[0] = (unsigned long long*)interior_buf;
+  g_m5_stamps[1] = (unsigned long long*)edge_buf;
+  return 0;
+}
+#endif
 #ifdef GLA_M5_F32_TU
 int gla_march5_pass_f32(const gla_march5_args& a) {
   if (a.res) return m5_dispatch_ts<float, M5_RES>(a);

@@ -1527,8 +1527,12 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
       if (per_cu > 2) per_cu = 2;
     }
     else per_cu = sizeof(T) == 8 ? (A->dia_D <= 5 ? (TS >= 4 ? 4 : 7) : 4) : (A->dia_D <= 5 ? 8 : 5);
-    int64_t slots = 256 * per_cu;                     // (interior / boundary split: room for the two edge line blocks, gla_march5.hip)
-    if (edge && slots > 4 * (int64_t)nstrips) slots -= 2 * (int64_t)nstrips;
+    int64_t slots = 256 * per_cu;                     // (interior / boundary split: room for the two edge line blocks PER XCD, gla_march5.hip)
+    if (edge && slots > 4 * (int64_t)nstrips) {
+      const int64_t edge_x = (2 * (int64_t)nstrips + GLA_XCDS - 1) / GLA_XCDS;
+      const int64_t int_x = 32 * (int64_t)per_cu - (g_tuning.edge_prio ? 1 : 0) - edge_x;
+      slots = g_tuning.edge_prio ? GLA_XCDS * int_x : slots - 2 * (int64_t)nstrips;
+    }
     lines = gla_pick_block_lines(inner_lines, nstrips, slots, 2 * (TS - 1), 2 * TS);
     if (lines > 1024) lines = 1024;
   }
@@ -1547,6 +1551,10 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
   tm.tile_row = nullptr; tm.tile_info = nullptr; tm.tile_list = nullptr;
   tm.n_tiles = count;
   set_tile_mapping(tm);
+  if (part != 0 && edge && g_tuning.edge_prio) {    // the two launches of a split pass must fit PER XCD (map_tile, gla_device.h)
+    tm.balanced = part == 1 ? 1 : 2;
+    tm.tiles_per_xcd = (count + GLA_XCDS - 1) / GLA_XCDS;
+  }
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   if constexpr (TS <= JACOBI_TS_MAX9) {
     if (canon9) {                                   // the same march for the canonical 9-point pattern

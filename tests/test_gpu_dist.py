@@ -144,6 +144,64 @@ def test_two_ranks_one_gpu(overlap, world):
         assert status == "ok", f"rank {rank}: {status}"
 
 
+def _oracle_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import c_oracle
+        import gnn_applied_linear_algebra_amd as gla
+        from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi
+        dev = torch.device("cuda:0")
+        N, sweeps = 1024, 20
+        n = N * N
+        lines = N // world
+        lo, hi = rank * lines * N, (rank + 1) * lines * N
+        gen = torch.Generator().manual_seed(24601)
+        b = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+        x = torch.rand(n, 1, generator=gen, dtype=torch.float64)
+        diag = torch.full((n, 1), -4.0, dtype=torch.float64)
+        ei, ev = gla.UtilsGNN.laplacianfun_torch(N, device=dev)
+        A = c_oracle.Csr(ei.cpu().numpy(), ev.cpu().numpy(), n)
+        want = torch.from_numpy(A.jacobi(diag.numpy(), b.numpy(), x.numpy(), 0.7, sweeps))
+        del ei, ev
+        ei_l, ev_l = gla.UtilsGNN.laplacianfun_torch(N, row_range=(lo, hi), device=dev)
+        jac = RowBlockJacobi(ei_l, ev_l, n, lo, hi, overlap=True)
+        default_layout = not any(k in os.environ.get("GLA_OPTIONS", "") for k in ("dia=0", "compress=1", "jacobi_fuse=", "jacobi_march="))
+        if default_layout:
+            assert jac.ext is not None and tuple(jac._sched(sweeps)) == (7, 7, 6), "the temporally blocked route, 7 + 7 + 6"
+        va = torch.cat([diag, b, x], 1)[lo:hi].contiguous().to(dev)
+        got = jac.forward(sweeps, va, torch.tensor([0.7], dtype=torch.float64))
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want[lo:hi]), f"rank {rank}: max |d| = {float((got.cpu() - want[lo:hi]).abs().max()):.3e}"
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_1024_20_sweeps_vs_c_oracle():
+    """the multi-rank route against the ORACLE itself (the other tests of this file compare with the
+    single-rank module): JacobiGNN's 20 sweeps on the 1024^2 Laplacian cut into two row blocks of 512 grid lines (2 gloo ranks
+    sharing the GPU; on a multi-GPU node the same drivers run over RCCL), temporally blocked 7 + 7 + 6 with one ghost-line
+    exchange per pass, every rank's rows bit-exact against the single-threaded C restatement (JacobiGNN.py:138-148)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_oracle_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in sorted(res):
+        assert status == "ok", f"rank {rank}: {status}"
+
+
 def _long_rows_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -732,6 +790,49 @@ def _temporal_route_case(plan, drv, va, g, d_e, b_e, periodic, up, down, n, n_ex
             else:
                 Er = (2 * drv.TS_MAX + plan.jacobi_schedule(its)[0]) * drv.ext["S"]
                 assert torch.equal(d_ext[:Er], d_e[:Er]) and torch.equal(d_ext[-Er:], d_e[-Er:]), (a_name, its, overlap, "A_ii windows")
+
+
+def test_temporal_route_as_a_hip_graph_self_halo_rccl():
+    """Round 5: the temporally blocked route -- gla_dist_jacobi_temporal: per pass a pack launch,
+    ncclAllGather, the interior launch, ghost fill + edge launch on a second stream, fork / join, the A_ii flag -- captured into
+    a HIP graph, by torch (RowBlockJacobi.capture_forward) and by the library itself (capture_forward_native ->
+    gla_dist_jacobi_temporal_graph), over a real one-rank RCCL communicator whose neighbours are the rank itself.  Replays are
+    bit-identical to the eager route (which the test above pins sweep by sweep) for A_ii = the diagonal (flag clean) and a
+    random A_ii (flag raised in every replay), with eager calls in between (graph and eager calls never share a flag word:
+    gla_jacobi_dg_slot hands captured calls words of their own with a memset node in front)."""
+    import gnn_applied_linear_algebra_amd as gla
+    from gnn_applied_linear_algebra_amd.dist import RowBlockJacobi
+    dev = torch.device("cuda:0")
+    Nx, lines = 300, 120
+    drv = RowBlockJacobi.rehearsal_self_halo(Nx, lines, dev)
+    if drv._sched(2) != (2,):
+        pytest.skip("no temporally blocked kernel under these GLA_OPTIONS")
+    n = Nx * lines
+    gen = torch.Generator().manual_seed(9)
+    g = torch.tensor([0.7], dtype=torch.float64)           # (a CPU tensor: no device-to-host read inside a capture)
+    va_d = torch.rand(n, 3, generator=gen, dtype=torch.float64).to(dev)
+    va_d[:, 0] = -4.0
+    va_r = va_d.clone()
+    va_r[:, 0] = torch.rand(n, generator=gen, dtype=torch.float64).to(dev) + 3.0
+    try:
+        for its in (20, 7):
+            want_d, want_r = drv.forward(its, va_d, g).clone(), drv.forward(its, va_r, g).clone()
+            assert not torch.equal(want_d, want_r)
+            for kind in ("torch", "native"):
+                run = drv.capture_forward(its, va_d, g) if kind == "torch" else drv.capture_forward_native(its, va_d, g)
+                for rep in range(3):
+                    assert torch.equal(run(va_d), want_d), (kind, its, rep, "A_ii = the diagonal")
+                    assert torch.equal(run(va_r), want_r), (kind, its, rep, "A_ii random: the flag must be raised in THIS replay")
+                    assert torch.equal(drv.forward(its, va_r if rep % 2 else va_d, g), want_r if rep % 2 else want_d), (kind, its, rep, "eager call between replays")
+                assert torch.equal(run(va_d), want_d), (kind, its, "flag cleared again by the memset node")
+                torch.cuda.synchronize()
+                if kind == "native":
+                    run.close()
+                del run
+    finally:
+        torch.cuda.synchronize()
+        gla._lib.lib().gla_comm_destroy(drv.comm._h)
+        drv.comm._h = None
 
 
 def test_k_wide_ghost_routes_self_halo_rccl():
