@@ -458,7 +458,11 @@ __global__ __launch_bounds__(GLA_BLOCK, 2) void jacobi_march5_kernel(M5View dv, 
 template <typename T, int LV, int MODE, bool SYM = false> struct M5Cfg {
   // (the symmetric AoS pass of six sweeps is the one instance the Markstein division does not fit in 256 registers: IEEE division;
   //  that pass is bound by its 16-24 bytes per row of writes anyway)
+#ifdef GLA_M5_VARIANTS
+  static constexpr bool rcp = sizeof(T) == 4 || ((LV <= 7 || LV >= 9) && !(SYM && MODE == M5_AOS && LV == 6));     // (9, 10 levels: experiments)
+#else
   static constexpr bool rcp = sizeof(T) == 4 || (LV <= 7 && !(SYM && MODE == M5_AOS && LV == 6));
+#endif
   static constexpr int hd = sizeof(T) == 4 ? 2 : (LV >= 8 || (MODE == M5_AOS && LV == 6) ? 0 : 2);
   static constexpr bool static_idx = sizeof(T) == 4 || LV >= 8;
 };
@@ -575,8 +579,8 @@ int m5_launch_sym(const gla_march5_args& a) {
   const dim3 grid((unsigned)(tm.tiles_per_xcd * GLA_XCDS)), block(GLA_BLOCK);
   const size_t lds = (size_t)LV * 2 * (GLA_BLOCK + 2) * sizeof(T);
 #ifdef GLA_M5_VARIANTS
-  if constexpr (sizeof(T) == 8 && TS == 7 && MODE == M5_PLAIN && SYM && FM && DGM == 1) {
-    const int v = g_tuning.m5_variant;
+  if constexpr (sizeof(T) == 8 && (TS == 7 || TS == 9 || TS == 10) && MODE == M5_PLAIN && SYM && FM && DGM == 1) {
+    const int v = g_tuning.m5_variant >= 100 ? g_tuning.m5_variant % 100 : g_tuning.m5_variant;     // (1xx: with a forced sweep count, below)
 #define M5V(HDV, SIV, PFV) hipLaunchKernelGGL((jacobi_march5_kernel<T, TS, MODE, true, HDV, SIV, SYM, FM, DGM, PFV>), grid, block, lds, a.st, dv, (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1, a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out)
     if (v > 0) {
       switch (v) {
@@ -605,7 +609,11 @@ int m5_launch(const gla_march5_args& a) {
   if (!gla_dia_sym5(a.A)) return m5_launch_sym<T, TS, MODE, false, false>(a);
   // (the no-mask instances exist for the symmetric layout only: a plan whose values are not symmetric keeps its masks as well;
   //  ... and for up to seven levels: hipcc spills the eight-level no-mask instance, 205 registers of it)
+#ifdef GLA_M5_VARIANTS
+  constexpr bool fm_fits = TS + (MODE == M5_RES ? 1 : 0) <= 7 || (TS >= 9 && MODE == M5_PLAIN);
+#else
   constexpr bool fm_fits = TS + (MODE == M5_RES ? 1 : 0) <= 7;
+#endif
   if constexpr (fm_fits) {
     if (gla_dia_full5(a.A)) {
       if constexpr (MODE == M5_PLAIN) {             // A_ii = the centre coefficient: said so by the caller / decided by the flag
@@ -629,6 +637,10 @@ int m5_dispatch_ts(const gla_march5_args& a) {
     case 6: return m5_launch<T, 6, MODE>(a);
     case 7: return m5_launch<T, 7, MODE>(a);
     case 8: if constexpr (MODE != M5_RES) return m5_launch<T, 8, MODE>(a); else return GLA_ERR_UNSUPPORTED;
+#ifdef GLA_M5_VARIANTS
+    case 9: if constexpr (MODE == M5_PLAIN && sizeof(T) == 8) return m5_launch<T, 9, MODE>(a); else return GLA_ERR_UNSUPPORTED;
+    case 10: if constexpr (MODE == M5_PLAIN && sizeof(T) == 8) return m5_launch<T, 10, MODE>(a); else return GLA_ERR_UNSUPPORTED;
+#endif
     default: return GLA_ERR_UNSUPPORTED;
   }
 }
@@ -654,7 +666,12 @@ int gla_march5_pass_f32(const gla_march5_args& a) {
 }
 #else
 int gla_march5_pass_f32(const gla_march5_args& a);
-int gla_march5_pass(const gla_march5_args& a) {
+int gla_march5_pass(const gla_march5_args& a_in) {
+  gla_march5_args a = a_in;
+#ifdef GLA_M5_VARIANTS
+  // experiments: option m5_variant = 100 * ts + v runs a plain 7-sweep call with ts = 9 / 10 levels instead (timing only)
+  if (g_tuning.m5_variant >= 900 && a.ts == 7 && !a.res && a.ldva <= 0 && a.part == 0 && a.dtype == GLA_F64) a.ts = g_tuning.m5_variant / 100;
+#endif
   if (!a.A || !gla_dia_canon5(a.A) || a.part < 0 || a.part > 2) return GLA_ERR_UNSUPPORTED;
   const int lv = a.ts + (a.res ? 1 : 0);
   if (a.ghost < lv && a.part != 0) return GLA_ERR_INVALID_ARG;
