@@ -52,3 +52,21 @@ def test_rank_processes_write_the_json_line_to_the_saved_stdout():
     body = src[src.index("def single_gpu("):]
     assert "print(json.dumps" not in body, "rank code must call emit(), not print()"
     assert len(re.findall(r"\bemit\(out\)", body)) >= 2            # the N = 1 line and the N > 1 line
+
+
+def test_layout_byte_accounting_of_the_bench_line():
+    """bench.py's per-pass byte accounting (the line must say what the kernels move): 5-point plans, symmetric
+    value set + full stencil + A_ii = the diagonal -> the module step moves 64 (AoS first pass) + 48 + 48 bytes per row; an
+    unsymmetric plan 5 diagonals and masks; an A_ii array 8 more per plain pass."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    info = types.SimpleNamespace(dia=5, dia_canon5=1, dia_sym=3, dia_full=1)
+    assert [rb for _, _, rb in bench.step_layout(info, (7, 7, 6), True, True)] == [64, 48, 48]
+    assert [k for k, _, _ in bench.step_layout(info, (7, 7, 6), True, True)] == ["aos", "plain", "plain"]
+    assert [rb for _, _, rb in bench.step_layout(info, (7, 7, 6), False, True)] == [72, 56, 56]       # A_ii streamed, copies of A_ii and b written
+    info_u = types.SimpleNamespace(dia=5, dia_canon5=1, dia_sym=0, dia_full=0)
+    assert [rb for _, _, rb in bench.step_layout(info_u, (7, 7, 6), False, True)] == [90, 74, 74]
+    assert bench.pass_row_bytes(5, 2, True, "plain", False) == 48 and bench.pass_row_bytes(5, 0, False, "plain", True) == 74
