@@ -930,7 +930,11 @@ def single_gpu(args, gla, dev):
                         "default build is bit-exact against the oracle)",
                 "default_build": rec_d, "contracted_build": rec_c,
                 "speedup": (round(rec_d["ms_per_step"] / rec_c["ms_per_step"], 4)
-                            if "ms_per_step" in rec_d and "ms_per_step" in rec_c else None)}
+                            if "ms_per_step" in rec_d and "ms_per_step" in rec_c else None),
+                "speedup_scaled_matrix_DAD": (round(rec_d["scaled_matrix_DAD"]["ms_per_step"] / rec_c["scaled_matrix_DAD"]["ms_per_step"], 4)
+                                              if "scaled_matrix_DAD" in rec_d and "scaled_matrix_DAD" in rec_c else None),
+                "note": "the Laplacian's products and quotients are exact (coefficients -4 and 1): there the two builds agree bit for bit; "
+                        "D A D with a random diagonal D (entries a_ij (d_i d_j): still a symmetric value set) is the case where they differ"}
         # ---- side: non-stencil matrices through the CSR-adaptive kernels (stream / vector / long bins) ----------------------
         try:
             out["csr_irregular"] = side_irregular(gla, dev)
