@@ -104,6 +104,7 @@ SIGNATURES = {
     "gla_halo_begin": (_I, [_P, _I, _I, _P, _I64, _P, _I64, _I64, _P, _P]),
     "gla_halo_end": (_I, [_P, _P]),
     "gla_comm_all_gather_begin": (_I, [_P, _I, _P, _P, _I64, _P]),
+    "gla_comm_all_gather": (_I, [_P, _I, _P, _P, _I64, _P]),
     "gla_comm_all_reduce_sum": (_I, [_P, _I, _P, _I64, _P]),
     "gla_dist_jacobi_sweeps": (_I, [_P, _P, _I, _I, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _P, _D, _I, _I, _P]),
     "gla_dist_jacobi_temporal": (_I, [_P, _P, _I, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _D,

@@ -230,6 +230,14 @@ int gla_comm_all_gather_begin(gla_comm_t c, int dtype, const void* send, void* r
   return GLA_OK;
 }
 
+int gla_comm_all_gather(gla_comm_t c, int dtype, const void* send, void* recv, int64_t count, gla_stream_t stream) {
+  if (!c || !send || !recv || count < 0 || (dtype != GLA_F32 && dtype != GLA_F64)) return GLA_ERR_INVALID_ARG;
+  if (count == 0) return GLA_OK;
+  GLA_RCCL_CHECK(g_rccl.all_gather(send, recv, (size_t)count, dtype == GLA_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32, c->comm,
+                                   (hipStream_t)stream));
+  return GLA_OK;
+}
+
 // Makes `stream` wait for the all-gather started by the last gla_halo_begin / gla_comm_all_gather_begin (stream-ordered;
 // the host does not block).
 int gla_halo_end(gla_comm_t c, gla_stream_t stream) {

@@ -475,9 +475,15 @@ class RowBlockOps:
                 pairs += [(own[:m], send[pos:pos + m]), (own[-m:], send[pos + m:pos + 2 * m])]
                 pos += 2 * m
             self._copy_batch(pairs, st)
+            if not begin_only:
+                # nothing to overlap with: the gather runs IN LINE on the caller's stream.  Through the side stream it costs
+                # two cross-queue dependencies, 12 us each on this runtime around a 4 us gather (profiles/r05/dist_vcycle_trace.txt)
+                check(lib().gla_comm_all_gather(self.comm._h, dtype_code(dt), ptr(send), ptr(recv), chunk, st))
+                self._ghost_pending = (send, recv, widths, False)
+                return self._ghost_finish(st)
             check(lib().gla_comm_all_gather_begin(self.comm._h, dtype_code(dt), ptr(send), ptr(recv), chunk, st))
             self._ghost_pending = (send, recv, widths, True)
-            return None if begin_only else self._ghost_finish(st)
+            return None
         send = torch.cat([piece.reshape(-1) for own in owns for piece in (own[:m], own[-m:])])
         recv = torch.empty(p.world * chunk, dtype=send.dtype, device=send.device)
         if self.comm is not None:

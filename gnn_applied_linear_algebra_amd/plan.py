@@ -248,7 +248,7 @@ class CsrPlan:
         return Xout
 
     @_on_device
-    def jacobi_sweeps_residual(self, diag, B, X0, w, n_iters, diag_is_matrix_diagonal=False):
+    def jacobi_sweeps_residual(self, diag, B, X0, w, n_iters, diag_is_matrix_diagonal=False, r_out=None):
         """(x after n_iters sweeps, r = B - A x) with the residual formed inside the last temporally blocked pass
         (gla_jacobi_fused_residual), or None when the plan / count does not qualify (the caller runs jacobi_sweeps and
         residual).  Single contiguous rhs."""
@@ -271,7 +271,10 @@ class CsrPlan:
         if n_iters > last:                                   # the earlier passes of the schedule as usual
             x = self.jacobi_sweeps(diag, B, X0, w, n_iters - last, diag_is_matrix_diagonal=diag_is_matrix_diagonal)
         Xout = torch.empty((self.n_rows, 1), dtype=X0.dtype, device=self.device)
-        R = torch.empty_like(Xout)
+        if r_out is not None and r_out.is_contiguous() and r_out.dtype == X0.dtype and r_out.numel() >= self.n_rows and r_out.device == Xout.device:
+            R = r_out.reshape(-1)[:self.n_rows].reshape(-1, 1)      # (the caller's buffer: e.g. the restriction's operand, dist_amg.py)
+        else:
+            R = torch.empty_like(Xout)
         try:
             rc = lib().gla_jacobi_fused_residual(self._h, dtype_code(X0.dtype), None if diag_is_matrix_diagonal else ptr(diag),
                                                  ptr(B), ptr(x), ptr(Xout), ptr(R), float(w), last, stream_ptr(self.device))

@@ -413,6 +413,9 @@ int gla_halo_end(gla_comm_t comm, gla_stream_t stream);
  * for the ghost-line slabs of the temporally blocked multi-GPU sweep (dist.py). */
 int gla_comm_all_gather_begin(gla_comm_t comm, int dtype, const void* send, void* recv, int64_t count,
                               gla_stream_t stream);
+/* The same all-gather IN LINE on `stream` (no side stream, no gla_halo_end): for an exchange whose result the very next
+ * kernel needs -- the [b, x] ghost lines before a V-cycle level's smoothing pass (dist_amg.py). */
+int gla_comm_all_gather(gla_comm_t comm, int dtype, const void* send, void* recv, int64_t count, gla_stream_t stream);
 /* In-place sum over the ranks of `count` device values, stream-ordered (power method: the K resp. 2K partial sums
  * of PowerMethodGNN.py:50-61 vertex_to_global_aggregation). */
 int gla_comm_all_reduce_sum(gla_comm_t comm, int dtype, void* buf, int64_t count, gla_stream_t stream);

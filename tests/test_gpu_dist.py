@@ -688,6 +688,10 @@ def test_jacobi_fused_parts_and_library_all_gather():
     check(lib().gla_halo_end(comm._h, st))
     torch.cuda.synchronize()
     assert torch.equal(recv, send)
+    recv.zero_()                                               # the in-line form (the V-cycle levels' [b, x] ghost exchange)
+    check(lib().gla_comm_all_gather(comm._h, code, ptr(send), ptr(recv), 1000, st))
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send)
 
 
 @pytest.mark.parametrize("Nx,Ny,up,down", [(300, 200, 1, 1), (70, 40, 1, 1), (1000, 64, 1, 1), (257, 49, 1, 1),
