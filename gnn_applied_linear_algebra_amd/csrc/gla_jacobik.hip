@@ -40,12 +40,21 @@ struct KCoef {                                     // one row's matrix data, A_i
 template <typename T> struct KLim;
 template <> struct KLim<double> {
   static constexpr double dlo = 0x1p-500, dhi = 0x1p500, nlo = 0x1p-450, nhi = 0x1p450;
+  // range_word(v): a word whose bits 30 / 31 are clear only if 2^-255 <= |v| < 2^257 (inside [nlo, nhi]; a NaN, an infinity, a
+  // zero or a denormal sets one of them): (high word << 1) drops the sign and puts the exponent field at bit 21; minus 768 << 21
+  // maps exponent fields [768, 1280) to [0, 512 << 21) = below bit 30.  One v_lshl_add_u32 per value and one v_or3_b32 per two
+  // values instead of two compares and two scalar ORs per value (round 5).
+  static __device__ __forceinline__ unsigned range_word(double v) {
+    return ((unsigned)__double2hiint(v) << 1) - (768u << 21);
+  }
   static __device__ __forceinline__ bool all_ones(double v) {
     return (__builtin_bit_cast(unsigned long long, v) & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull;
   }
 };
 template <> struct KLim<float> {
   static constexpr float dlo = 0x1p-60f, dhi = 0x1p60f, nlo = 0x1p-50f, nhi = 0x1p50f;
+  // 2^-31 <= |v| < 2^33: exponent fields [96, 160) -> [0, 64 << 24) = below bit 30
+  static __device__ __forceinline__ unsigned range_word(float v) { return (__float_as_uint(v) << 1) - (96u << 24); }
   static __device__ __forceinline__ bool all_ones(float v) { return (__builtin_bit_cast(unsigned, v) & 0x7FFFFFu) == 0x7FFFFFu; }
 };
 
@@ -113,6 +122,19 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
     return c;
   };
   auto b_at = [&](int jl) -> TV { return ldv<TV>(bvec + row_clamped(jl) * ldb + q * VW); };
+  // Round 5: the addresses of a line step's loads without per-lane 64-bit arithmetic.  Where the lines jl + 1 and jl + 2 are whole
+  // grid lines for the whole wave (wave-uniform; everything but a block's first / last steps at the grid's ends) no row needs
+  // clamping: a load's address is a SCALAR base -- the strip's first point on that line -- plus a 32-bit lane offset that never
+  // changes.  The clamped per-lane form above cost ~100 of a step's 375 instructions (two 64-bit clamps, two 64-bit multiplies
+  // by the leading dimensions, eleven 64-bit adds), in a pass that is bound by its instruction stream (profiles/r05/marchk_sides.txt).
+  const bool fa_ok = wave_in && ldx0 < (1 << 20) && ldb < (1 << 20);
+  const unsigned off_x = (unsigned)(ii * (int)ldx0 + q * VW) * (unsigned)sizeof(T);
+  const unsigned off_b = (unsigned)(ii * (int)ldb + q * VW) * (unsigned)sizeof(T);
+  const unsigned off_r = (unsigned)ii * (unsigned)sizeof(T), off_m = (unsigned)ii * 2u;
+  auto at = [&](const auto* base, int64_t scalar_elems, unsigned lane_bytes) {
+    typedef decltype(base) P;
+    return reinterpret_cast<P>(reinterpret_cast<const char*>(base + scalar_elems) + lane_bytes);
+  };
   auto expected = [&](int jl) -> unsigned {        // (lines inside [jlo, jhi) only)
     const int64_t gj = J0 + jl;
     if constexpr (D == 5) {
@@ -143,7 +165,7 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
     return lv ? xn : TV(T(0));
   };
   // the fast level: unmasked sum, Markstein division through rc = RN(1 / A_ii); bad: an operand it is not proven for
-  auto fast_level = [&](const Coef& c, TV cb, T rc, const TV (&xs)[D], TV ctr, bool& bad, TV& num_out) -> TV {
+  auto fast_level = [&](const Coef& c, TV cb, T rc, const TV (&xs)[D], TV ctr, unsigned& bad, TV& num_out) -> TV {
     TV acc = TV(T(0));
 #pragma unroll
     for (int d = 0; d < D; ++d) acc = acc + c.v[d] * xs[d];
@@ -151,13 +173,40 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
     TV xn;
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
-      const T an = __builtin_fabs(num[e]);
-      bad = bad || !(an > Lim::nlo && an < Lim::nhi);
+      bad |= Lim::range_word(num[e]);                // (bits 30 / 31 set: outside the range, see KLim)
       const T q0 = num[e] * rc;
       const T rem = fma_t(-q0, c.dg, num[e]);
       xn[e] = ctr[e] + fma_t(rem, rc, q0);
     }
     num_out = num;
+    return xn;
+  };
+
+  // The 5-point fast level in two halves (round 5).  Of a level's in-order sum only the LAST term -- the point below, x of the
+  // level underneath on the line that level produces in this very step -- depends on this step's work; the first four terms
+  // (north, west, centre, east) were all produced a step ago.  lead4() of level t + 1 is issued next to finish() of level t:
+  // four dependent chains instead of two in a stream where one wave issues a dependent FP64 instruction every ~8 cycles and
+  // an independent one every ~5 (tools/micro/valu_rates.hip), and the LDS reads of the next level are in flight during the
+  // arithmetic of this one.  Same operations in the same order per (row, rhs): bit-identical.
+  auto lead4 = [&](const Coef& c, TV north, TV west, TV ctr, TV east) -> TV {
+    TV acc = TV(T(0));
+    acc = acc + c.v[0] * north;
+    acc = acc + c.v[1] * west;
+    acc = acc + c.v[2] * ctr;
+    acc = acc + c.v[3] * east;
+    return acc;
+  };
+  auto finish5 = [&](const Coef& c, TV cb, T rc, TV acc, TV south, TV ctr, unsigned& bad) -> TV {
+    acc = acc + c.v[4] * south;
+    const TV num = w * (cb - acc);
+    TV xn;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      bad |= Lim::range_word(num[e]);
+      const T q0 = num[e] * rc;
+      const T rem = fma_t(-q0, c.dg, num[e]);
+      xn[e] = ctr[e] + fma_t(rem, rc, q0);
+    }
     return xn;
   };
 
@@ -189,6 +238,31 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
 #pragma unroll
   for (int s = 0; s < NC; ++s) { cfast[s] = false; crc[s] = T(1); }
 
+  // level 0 of line jl + 1 from the prefetched x, then the loads of the step: x of line jl + 2, matrix row and b of line jl + 1
+  auto advance = [&](const int jl, const int u, TV& x_new) {
+    const bool whole_next = wave_in && jl + 1 >= jlo && jl + 1 < jhi;
+    if (fa_ok && jl + 1 >= jlo && jl + 2 < jhi) {
+      x_new = xpre;
+      if constexpr (!(DBG & 8)) {
+        const int64_t rb1 = (J0 + jl + 1) * S + P0;                  // (scalar: the strip's first row of line jl + 1)
+        xpre = ldv<TV>(at(x0, (rb1 + S) * ldx0, off_x));
+        Coef& cn = c[(u + 1) % NC];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cn.v[d] = *at(val, (int64_t)d * jv.n_rows + rb1, off_r);
+        cn.dg = *at(diag, rb1, off_r);
+        cn.m = (int)*at(jv.mask, rb1, off_m);
+        cb[(u + 1) % NC] = ldv<TV>(at(bvec, rb1 * ldb, off_b));
+      }
+    } else {
+      asm volatile("" ::: "memory");               // (keeps the two forms apart: merged, the clamps are computed on every step again)
+      x_new = (whole_next | live_at(jl + 1)) ? xpre : TV(T(0));
+      if constexpr (!(DBG & 8)) {
+        xpre = x0_load(jl + 2);
+        c[(u + 1) % NC] = coef_at(jl + 1);
+        cb[(u + 1) % NC] = b_at(jl + 1);
+      }
+    }
+  };
   // first use of the set of line jl (loaded a step ago): expected mask, divisor range, reciprocal
   auto classify = [&](const int jl, const int u) {
     const Coef& cu = c[u % NC];
@@ -210,14 +284,8 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
       TV* const row_o = buf + (1 - pj) * LWV + ii * KV + q;
 #pragma unroll
       for (int t = 0; t < TS; ++t) { h[t][0] = h[t][1]; h[t][1] = h[t][2]; }     // (levels only assign h[t][2]: a step is idempotent)
-      const bool whole_next = wave_in && jl + 1 >= jlo && jl + 1 < jhi;
-      h[0][2] = (whole_next | live_at(jl + 1)) ? xpre : TV(T(0));
+      advance(jl, u, h[0][2]);
       row_o[KV] = h[0][2];                         // level 0, line jl + 1
-      if constexpr (!(DBG & 8)) {
-        xpre = x0_load(jl + 2);
-        c[(u + 1) % NC] = coef_at(jl + 1);
-        cb[(u + 1) % NC] = b_at(jl + 1);
-      }
       classify(jl, u);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr ((DBG & 4) != 0) {              // the memory side alone: every loaded value consumed, one store per (row, vector)
@@ -231,23 +299,29 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
 #pragma unroll
       for (int t = 1; t <= TS; ++t)
         if (t <= nact) fast = fast && cfast[((u - (t - 1)) % NC + NC) % NC];
-      bool bad = false;
+      unsigned bad = 0;
       if (fast) {
+        // row of level t: the LDS line of level t - 1 on line jl - (t - 1) (written a step ago): [0] west, [2 KV] east
+        auto row_of = [&](int t) -> TV* { return ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LWV; };
+        auto set_of = [&](int t) -> int { return ((u - (t - 1)) % NC + NC) % NC; };
+        TV lead = lead4(c[set_of(1)], h[0][0], row_of(1)[0], h[0][1], row_of(1)[2 * KV]);
 #pragma unroll
         for (int t = 1; t <= TS; ++t) {
           if (t <= nact) {
-            TV* const row = ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LWV;   // level t - 1, line jl - (t - 1)
-            const int ci = ((u - (t - 1)) % NC + NC) % NC;
-            const TV xs[5] = {h[t - 1][0], row[0], h[t - 1][1], row[2 * KV], h[t - 1][2]};
-            TV num;
-            const TV xn = fast_level(c[ci], cb[ci], crc[ci], xs, h[t - 1][1], bad, num);
+            TV* const row = row_of(t);
+            const int ci = set_of(t);
+            TV lead_next = lead;
+            if (t + 1 <= TS && t + 1 <= nact)
+              lead_next = lead4(c[set_of(t + 1)], h[t][0], row_of(t + 1)[0], h[t][1], row_of(t + 1)[2 * KV]);
+            const TV xn = finish5(c[ci], cb[ci], crc[ci], lead, h[t - 1][2], h[t - 1][1], bad);
             if (t < TS) { h[t][2] = xn; row[2 * LWV + KV] = xn; }                     // level t, same line (same parity)
             else if ((DBG & 2) ? (owner && xn[0] == T(123.456)) : owner) stv<TV>(xout + ((J0 + jl - (TS - 1)) * S + gi) * ldxo + q * VW, xn);
+            lead = lead_next;
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
-      if (!fast || __any(bad)) {
+      if (!fast || __any(bad >> 30)) {
         asm volatile("" ::: "memory");             // (keeps this path's LDS reads from being merged with the fast path's above the branch)
 #pragma unroll
         for (int t = 1; t <= TS; ++t) {
@@ -269,13 +343,9 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
       const int s1 = (jl + 1 + 63) % 3, s0 = (jl + 63) % 3, s2 = (jl - 1 + 63) % 3;
       // LDS rows of the lines jl + 1, jl, jl - 1 (level 0): [0] left, [KV] own, [2 KV] right of this lane's point
       TV* const rw[3] = {buf + s1 * LWV + ii * KV + q, buf + s0 * LWV + ii * KV + q, buf + s2 * LWV + ii * KV + q};
-      const bool whole_next = wave_in && jl + 1 >= jlo && jl + 1 < jhi;
       h[0][0] = h[0][1]; h[0][1] = h[0][2];
-      h[0][2] = (whole_next | live_at(jl + 1)) ? xpre : TV(T(0));
+      advance(jl, u, h[0][2]);
       rw[0][KV] = h[0][2];                         // level 0, line jl + 1
-      xpre = x0_load(jl + 2);
-      c[(u + 1) % NC] = coef_at(jl + 1);
-      cb[(u + 1) % NC] = b_at(jl + 1);
       classify(jl, u);
 #pragma unroll
       for (int t = 1; t <= TS; ++t) {
@@ -292,10 +362,10 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
           TV xn;
           bool live = true;
           if (cfast[ci]) {
-            bool bad = false;
+            unsigned bad = 0;
             TV num;
             xn = fast_level(c[ci], cb[ci], crc[ci], xs, h[t - 1][1], bad, num);
-            if (__any(bad)) {                      // same sum, IEEE division
+            if (__any(bad >> 30)) {                      // same sum, IEEE division
               asm volatile("" ::: "memory");
               xn = h[t - 1][1] + num / c[ci].dg;
             }
