@@ -14,6 +14,7 @@
 // RCCL is bound at run time (dlopen of librccl.so.1: the instance the process already has when torch is loaded), so
 // single-GPU hosts of libgla_hip.so carry no RCCL dependency.
 #include "gla_internal.h"
+#include <vector>
 
 #include <dlfcn.h>
 #include <mutex>
@@ -345,29 +346,68 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
   // its rows, dg_check_kernel the rows the edge blocks read -- and every later launch then runs the body that neither loads nor
   // keeps A_ii (gla_march5.hip, DGM 2).  The copy d_ext is what a raised flag falls back to: its edge windows and ghost lines are
   // always filled (by hand, below), its interior only by dg_repair_kernel, after pass 0, when the flag IS raised.
-  int* dg_flag = nullptr;
+  // Round 5, STAGGERED passes (option dist_stagger, default on; blocks tall enough).  With one edge height for every pass the
+  // interior launch of pass i + 1 reads lines the EDGE launch of pass i wrote: the main stream waited for the second stream once
+  // per pass, and a wait across two hardware queues costs ~12 us on this runtime even when the event fired long ago -- 12-19 us
+  // between consecutive interior launches in the kernel trace of config 4's 8-rank block, three times per step of 0.41 ms
+  // (profiles/r05/config4_block_stagger.txt).  Now the first / last line block of pass i is H_i lines high with
+  //     H_0 = max(ghost + ts_0, 2 ghost),    H_1 = H_0 + ts_0 + ts_1,    H_{i+1} = H_i + max(ts_i, ts_{i+1}):
+  // the interior launch of pass i + 1 reads lines >= H_{i+1} - ts_{i+1} >= H_i, all written by the interior launch of pass i (same
+  // stream, no wait), and writes lines >= H_{i+1} >= H_i + ts_i, past everything the edge launch of pass i still reads from that
+  // buffer.  (H_1: the AoS interior launch leaves the copies of A_ii and b of the H_0 + ts_0 lines either end to the hand copies
+  // of the second stream -- the edge blocks of pass 0 read them while it runs -- so the later interior launches stay off those.)
+  // The main stream runs its interior launches with an event record between them, nothing else, and waits for the second stream
+  // ONCE, at the end of the call; the second stream (pack, all-gather, ghost fill, edge blocks) waits for the main stream once
+  // per pass, off the critical path.  Each stream has its own A_ii flag word: the interior launches compute lines >= H_0 only,
+  // all compared by the AoS interior launch; the edge blocks compute lines < H_last only, all inside the windows
+  // dg_check_kernel compares (and that the hand copies of A_ii cover: win_lines).
+  std::vector<int> H((size_t)n_passes);
+  H[0] = ghost + passes[0] > 2 * ghost ? ghost + passes[0] : 2 * ghost;
+  for (int i = 1; i < n_passes; ++i)
+    H[(size_t)i] = i == 1 ? H[0] + passes[0] + passes[1] : H[(size_t)i - 1] + (passes[i - 1] > passes[i] ? passes[i - 1] : passes[i]);
+  const int win0 = 2 * ghost + passes[0];                      // lines either end the edge blocks of pass 0 read
+  int win_lines = win0;                                        // ... and of every pass (H_i + ts_i at most) when staggered
+  const bool stag = g_tuning.dist_stagger && n_passes >= 2 &&
+                    n_ext / S >= 2 * (int64_t)(H[(size_t)n_passes - 1] + passes[n_passes - 1]) + 32 && H[(size_t)n_passes - 1] < 0x7fff;
+  if (stag)
+    for (int i = 0; i < n_passes; ++i) win_lines = H[(size_t)i] + passes[i] > win_lines ? H[(size_t)i] + passes[i] : win_lines;
+  auto gh = [&](int i) -> int { return stag ? (ghost | (H[(size_t)i] << 16)) : ghost; };   // (ghost lines | explicit edge height)
+  int* dg_flag = nullptr;                                      // the main stream's word (the only one when not staggered)
   int dg_epoch = 0;
+  int* dg_flag_s = nullptr;                                    // the second stream's
+  int dg_epoch_s = 0;
   if (g_tuning.jacobi_diag_flag && gla_dia_sym5(A) && gla_dia_full5(A) && A->dia_val) {
     rc = gla_jacobi_dg_slot(A, (hipStream_t)main_stream, &dg_flag, &dg_epoch);
     if (rc) return rc;
+    dg_flag_s = dg_flag; dg_epoch_s = dg_epoch;
+    if (stag) {
+      rc = gla_jacobi_dg_slot(A, (hipStream_t)main_stream, &dg_flag_s, &dg_epoch_s);
+      if (rc) return rc;
+    }
   }
-  auto parts = [&](const void* dg, const void* bb, const void* xin, void* xout, int ts, int part, hipStream_t st) -> int {
-    if (dg_flag) return gla_jacobi_parts_flagged(A, dtype, nullptr, 0, 0, 0, dg, bb, xin, nullptr, nullptr, xout, w, ts, part, ghost, dg_flag, dg_epoch, st);
-    return gla_jacobi_fused_parts(A, dtype, dg, bb, xin, xout, w, ts, part, ghost, st);
+  auto parts = [&](const void* dg, const void* bb, const void* xin, void* xout, int ts, int part, int pass, hipStream_t st) -> int {
+    int* const fl = part == 2 ? dg_flag_s : dg_flag;
+    const int ep = part == 2 ? dg_epoch_s : dg_epoch;
+    if (fl) return gla_jacobi_parts_flagged(A, dtype, nullptr, 0, 0, 0, dg, bb, xin, nullptr, nullptr, xout, w, ts, part, gh(pass), fl, ep, st);
+    return gla_jacobi_fused_parts(A, dtype, dg, bb, xin, xout, w, ts, part, gh(pass), st);
   };
   // ---- pass 0 ---------------------------------------------------------------------------------------------------------------
   {
     const int ts = passes[0];
-    const int64_t E = (int64_t)(2 * ghost + ts) * S;          // rows the first / last edge block reads
+    const int64_t E = (int64_t)win0 * S;                      // rows the first / last edge block of THIS pass reads
+    // ... of every pass: what the hand copy of A_ii covers when the passes run on the flag (the AoS interior launch writes no copy
+    // of A_ii then, and an edge block of a later pass whose stream's flag is raised reads it up there)
+    const int64_t Ed = (int64_t)(stag && dg_flag ? win_lines : win0) * S;
     void* dst3[3] = {d_ext, b_ext, cur};
     const void* src[8]; void* dst[8]; int64_t cnt[8], strd[8];
     int k = 0;
-    const int64_t win[2][2] = {{0, E}, {n_ext - E, n_ext}};
     for (int wdx = 0; wdx < 2; ++wdx) {
-      const int64_t a = win[wdx][0] > off ? win[wdx][0] : off;
-      const int64_t b = win[wdx][1] < off + n_local ? win[wdx][1] : off + n_local;
-      if (a >= b) continue;
       for (int col = 0; col < 3; ++col) {
+        const int64_t Ec = col == 0 ? Ed : E;
+        const int64_t w0 = wdx == 0 ? 0 : n_ext - Ec, w1 = wdx == 0 ? Ec : n_ext;
+        const int64_t a = w0 > off ? w0 : off;
+        const int64_t b = w1 < off + n_local ? w1 : off + n_local;
+        if (a >= b) continue;
         src[k] = at(va, (a - off) * ldva + col); dst[k] = atw(dst3[col], a); cnt[k] = b - a; strd[k] = ldva; ++k;
       }
     }
@@ -378,8 +418,8 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
     forked = true;
-    if (dg_flag) rc = gla_jacobi_parts_flagged(A, dtype, va, ldva, off, n_local, nullptr, nullptr, nullptr, nullptr, b_ext, nxt, w, ts, 1, ghost, dg_flag, dg_epoch, mn);
-    else rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, ghost, mn);
+    if (dg_flag) rc = gla_jacobi_parts_flagged(A, dtype, va, ldva, off, n_local, nullptr, nullptr, nullptr, nullptr, b_ext, nxt, w, ts, 1, gh(0), dg_flag, dg_epoch, mn);
+    else rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, gh(0), mn);
     if (rc) return bail(rc);
     // (the interior launch reads the AoS rows and leaves the edge windows of d_ext / b_ext alone: the hand copies may run beside it)
     if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return bail(rc); }
@@ -397,18 +437,65 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
       if (down) { src[k] = at(recv, (int64_t)down_src * 6 * m + 2 * m * col); dst[k] = atw(dst3[col], off + n_local); cnt[k] = m; strd[k] = 1; ++k; }
     }
     if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return bail(rc); }
-    if (dg_flag) {                                            // the rows the edge blocks read: [0, E) and [n_ext - E, n_ext)
-      const int64_t nchk = 2 * E;
+    if (dg_flag) {                                            // the rows the edge blocks read: [0, Ed) and [n_ext - Ed, n_ext)
+      const int64_t nchk = 2 * Ed;
       const unsigned grid = (unsigned)((nchk + 255) / 256 < 1024 ? (nchk + 255) / 256 : 1024);
       if (dtype == GLA_F64)
         hipLaunchKernelGGL((dg_check_kernel<unsigned long long>), dim3(grid), dim3(256), 0, sd, (const unsigned long long*)d_ext,
-                           (const unsigned long long*)A->dia_val + 2 * n_ext, (int64_t)0, E, n_ext - E, n_ext, dg_flag, dg_epoch);
+                           (const unsigned long long*)A->dia_val + 2 * n_ext, (int64_t)0, Ed, n_ext - Ed, n_ext, dg_flag_s, dg_epoch_s);
       else
         hipLaunchKernelGGL((dg_check_kernel<unsigned>), dim3(grid), dim3(256), 0, sd, (const unsigned*)d_ext,
-                           (const unsigned*)A->dia_val + 2 * n_ext, (int64_t)0, E, n_ext - E, n_ext, dg_flag, dg_epoch);
+                           (const unsigned*)A->dia_val + 2 * n_ext, (int64_t)0, Ed, n_ext - Ed, n_ext, dg_flag_s, dg_epoch_s);
       if (hipGetLastError() != hipSuccess) return bail(GLA_ERR_INVALID_ARG);
     }
-    rc = parts(d_ext, b_ext, cur, nxt, ts, 2, sd); if (rc) return bail(rc);
+    rc = parts(d_ext, b_ext, cur, nxt, ts, 2, 0, sd); if (rc) return bail(rc);
+  }
+  // ---- passes 1 .., staggered ---------------------------------------------------------------------------------------------
+  if (stag) {
+    for (int i = 1; i < n_passes; ++i) {
+      // second stream: the own lines the neighbours want are complete (edge launch of pass i - 1) -> exchange of pass i
+      {
+        const void* src[2] = {at(nxt, off), at(nxt, off + n_local - m)};
+        void* dst[2] = {send, atw(send, m)};
+        const int64_t cnt[2] = {m, m};
+        rc = gla_copy_batch(dtype, 2, src, dst, cnt, nullptr, sd); if (rc) return bail(rc);
+        const int r_ = g_rccl.all_gather(send, recv, (size_t)(2 * m), dtype == GLA_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32, c->comm, sd);
+        if (r_ != 0) return bail(-(3000 + r_));
+      }
+      // ... its edge blocks also read what the interior launch of pass i - 1 wrote
+      GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
+      GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
+      if (i == 1 && dg_flag) {                                // (the main stream's word is final: its only writer was the AoS interior launch)
+        // Every own row beyond the windows of pass 0: what the later interior launches read.  Inside [win0, win_lines) lines the
+        // second stream's hand copy has put the SAME values (for its edge blocks, which may be reading them now): a duplicate
+        // write of identical words, and only when some A_ii is not the matrix diagonal.
+        const int64_t Ew = (int64_t)win0 * S;
+        const int64_t lo = Ew > off ? Ew : off, hi = n_ext - Ew < off + n_local ? n_ext - Ew : off + n_local;
+        if (hi > lo) {
+        if (dtype == GLA_F64)
+          hipLaunchKernelGGL((dg_repair_kernel<unsigned long long>), dim3(1024), dim3(256), 0, mn, (const unsigned long long*)va, ldva, off,
+                             (unsigned long long*)d_ext, lo, hi, dg_flag, dg_epoch);
+        else
+          hipLaunchKernelGGL((dg_repair_kernel<unsigned>), dim3(1024), dim3(256), 0, mn, (const unsigned*)va, ldva, off, (unsigned*)d_ext, lo, hi,
+                             dg_flag, dg_epoch);
+        if (hipGetLastError() != hipSuccess) return bail(GLA_ERR_INVALID_ARG);
+        }
+      }
+      { void* t = cur; cur = nxt; nxt = t; }
+      if (i == 1) nxt = xb == cur ? xa : xb;
+      if (i == n_passes - 1) nxt = x_last;
+      const int ts = passes[i];
+      rc = parts(d_ext, b_ext, cur, nxt, ts, 1, i, mn); if (rc) return bail(rc);
+      const void* src[2]; void* dst[2]; int64_t cnt[2];
+      int k = 0;
+      if (up) { src[k] = at(recv, (int64_t)up_src * 2 * m + m); dst[k] = cur; cnt[k] = m; ++k; }
+      if (down) { src[k] = at(recv, (int64_t)down_src * 2 * m); dst[k] = atw(cur, off + n_local); cnt[k] = m; ++k; }
+      if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, nullptr, sd); if (rc) return bail(rc); }
+      rc = parts(d_ext, b_ext, cur, nxt, ts, 2, i, sd); if (rc) return bail(rc);
+    }
+    GLA_HIP_CHECK(hipEventRecord(c->ev_join, sd));
+    GLA_HIP_CHECK(hipStreamWaitEvent(mn, c->ev_join, 0));
+    return GLA_OK;
   }
   // ---- passes 1 .. ----------------------------------------------------------------------------------------------------------
   for (int i = 1; i <= n_passes; ++i) {
@@ -445,13 +532,13 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
     forked = true;
-    rc = parts(d_ext, b_ext, cur, nxt, ts, 1, mn); if (rc) return bail(rc);
+    rc = parts(d_ext, b_ext, cur, nxt, ts, 1, i, mn); if (rc) return bail(rc);
     const void* src[2]; void* dst[2]; int64_t cnt[2];
     int k = 0;
     if (up) { src[k] = at(recv, (int64_t)up_src * 2 * m + m); dst[k] = cur; cnt[k] = m; ++k; }
     if (down) { src[k] = at(recv, (int64_t)down_src * 2 * m); dst[k] = atw(cur, off + n_local); cnt[k] = m; ++k; }
     if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, nullptr, sd); if (rc) return bail(rc); }
-    rc = parts(d_ext, b_ext, cur, nxt, ts, 2, sd); if (rc) return bail(rc);
+    rc = parts(d_ext, b_ext, cur, nxt, ts, 2, i, sd); if (rc) return bail(rc);
   }
   return GLA_OK;
 }

@@ -105,6 +105,7 @@ struct gla_tuning {
                             // diagonal, the later passes skip the A_ii stream if so (else read the AoS column); 0 = contiguous copies as before
   int m5_variant = 0;       // (experiments: GLA_M5_VARIANTS builds only)
   int edge_prio = 1;        // the edge launch of a split multi-GPU pass runs at raised wave priority (A/B: option edge_prio)
+  int dist_stagger = 1;     // gla_dist_jacobi_temporal: interior launches of consecutive passes depend on one another only (option dist_stagger)
   int jacobi_march = 1;     // canonical 5-point plans: 1 = the register-history march kernel, 0 = the generic LDS-ring kernel
   int64_t jacobi_min_rows = 1 << 19;   // gla_jacobi_sweeps fuses only at this many rows or more (below, one sweep per launch
                                        // is faster: 512^2 takes 4.5 us per sweep single vs 5.9 fused, 768^2 8.4 vs 6.0)
@@ -160,6 +161,8 @@ struct gla_march5_args {
   int64_t ldva;
   void *diag_out, *b_out;      // AoS pass: contiguous copies of A_ii and b; res: the residual
   int ghost;                   // ghost lines either end (parts 1 / 2)
+  int edge_h = 0;              // parts 1 / 2: height of the first / last line block (0: max(ghost + levels, 2 ghost)); gla_dist.hip's
+                               // staggered passes grow it from pass to pass
   int64_t aos_off, aos_rows;
   int64_t ldd = 1;             // stride of `diag` (plain / residual passes): 1, or an AoS row stride
   int dg_epoch = 0;            // the call's number: `*dg_flag == dg_epoch` means raised in this call

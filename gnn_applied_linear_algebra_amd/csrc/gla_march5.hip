@@ -512,7 +512,9 @@ int m5_launch_sym(const gla_march5_args& a) {
   // lines (an interior block reads x from LV lines above its first line); at least 2 x ghost, so that the edge launch alone
   // produces the `ghost` own lines either end that the neighbours want next -- their exchange can start when the edge launch
   // ends, long before the interior launch does.
-  const int edge_h = a.ghost + LV > 2 * a.ghost ? a.ghost + LV : 2 * a.ghost;
+  // (a.edge_h: given by the caller -- the staggered multi-GPU passes of gla_dist.hip, whose edge blocks grow from pass to pass so
+  // that an interior launch needs the previous INTERIOR launch only; never less than ghost + LV)
+  const int edge_h = a.edge_h > 0 ? a.edge_h : (a.ghost + LV > 2 * a.ghost ? a.ghost + LV : 2 * a.ghost);
   // The interior launch (part 1) leaves the lines the two edge blocks READ (edge_h + TS either end, copied by the host
   // beforehand) alone: the edge launch runs concurrently on a second stream, and the two must not touch the same words of
   // diag_out / b_out

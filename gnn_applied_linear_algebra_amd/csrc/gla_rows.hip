@@ -1489,11 +1489,13 @@ int launch_jacobi_fused(gla_csr* A, const T* diag, const T* b, const T* x, T* xo
     gla_march5_args a;
     a.A = A; a.dtype = sizeof(T) == 8 ? GLA_F64 : GLA_F32; a.ts = TS; a.res = false;
     a.diag = diag; a.b = b; a.x = x; a.xo = xo; a.w = (double)w; a.st = st; a.part = part;
-    a.ldva = ldva; a.diag_out = diag_out; a.b_out = b_out; a.ghost = ghost; a.aos_off = aos_off; a.aos_rows = aos_rows;
+    // (ghost >> 16, internal callers only -- gla_dist.hip's staggered passes: an explicit height of the first / last line block)
+    a.ldva = ldva; a.diag_out = diag_out; a.b_out = b_out; a.ghost = ghost & 0xffff; a.edge_h = ghost >> 16; a.aos_off = aos_off; a.aos_rows = aos_rows;
     a.ldd = ldd; a.dg_flag = dg_flag; a.dg_epoch = dg_epoch;
-    if (part < 0 || part > 2 || ghost < TS) return GLA_ERR_INVALID_ARG;
+    if (part < 0 || part > 2 || a.ghost < TS || (a.edge_h && (part == 0 || a.edge_h < a.ghost + TS))) return GLA_ERR_INVALID_ARG;
     return gla_march5_pass(a);
   }
+  if (ghost >> 16) return GLA_ERR_UNSUPPORTED;
   // (A_ii from the centre diagonal / a strided array / by a device flag: the 5-point march kernel only)
   if (ldd != 1 || dg_flag || (ldva <= 0 && !diag && !canon9)) return GLA_ERR_UNSUPPORTED;
   if (!canon && !canon9 && !generic_ts) return GLA_ERR_UNSUPPORTED;
