@@ -388,6 +388,11 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
   auto parts = [&](const void* dg, const void* bb, const void* xin, void* xout, int ts, int part, int pass, hipStream_t st) -> int {
     int* const fl = part == 2 ? dg_flag_s : dg_flag;
     const int ep = part == 2 ? dg_epoch_s : dg_epoch;
+    // (staggered interior launches whose flag is raised read A_ii from the caller's AoS rows -- plan row r = tensor row r - off, and
+    // they touch own rows only -- so no contiguous copy has to be repaired for them between the passes)
+    if (fl && stag && part == 1)
+      return gla_jacobi_parts_flagged(A, dtype, nullptr, ldva, 0, 0, (const void*)((uintptr_t)va - (uintptr_t)((size_t)off * (size_t)ldva * esz)), bb,
+                                      xin, nullptr, nullptr, xout, w, ts, part, gh(pass), fl, ep, st);
     if (fl) return gla_jacobi_parts_flagged(A, dtype, nullptr, 0, 0, 0, dg, bb, xin, nullptr, nullptr, xout, w, ts, part, gh(pass), fl, ep, st);
     return gla_jacobi_fused_parts(A, dtype, dg, bb, xin, xout, w, ts, part, gh(pass), st);
   };
@@ -465,22 +470,6 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
       // ... its edge blocks also read what the interior launch of pass i - 1 wrote
       GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
       GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
-      if (i == 1 && dg_flag) {                                // (the main stream's word is final: its only writer was the AoS interior launch)
-        // Every own row beyond the windows of pass 0: what the later interior launches read.  Inside [win0, win_lines) lines the
-        // second stream's hand copy has put the SAME values (for its edge blocks, which may be reading them now): a duplicate
-        // write of identical words, and only when some A_ii is not the matrix diagonal.
-        const int64_t Ew = (int64_t)win0 * S;
-        const int64_t lo = Ew > off ? Ew : off, hi = n_ext - Ew < off + n_local ? n_ext - Ew : off + n_local;
-        if (hi > lo) {
-        if (dtype == GLA_F64)
-          hipLaunchKernelGGL((dg_repair_kernel<unsigned long long>), dim3(1024), dim3(256), 0, mn, (const unsigned long long*)va, ldva, off,
-                             (unsigned long long*)d_ext, lo, hi, dg_flag, dg_epoch);
-        else
-          hipLaunchKernelGGL((dg_repair_kernel<unsigned>), dim3(1024), dim3(256), 0, mn, (const unsigned*)va, ldva, off, (unsigned*)d_ext, lo, hi,
-                             dg_flag, dg_epoch);
-        if (hipGetLastError() != hipSuccess) return bail(GLA_ERR_INVALID_ARG);
-        }
-      }
       { void* t = cur; cur = nxt; nxt = t; }
       if (i == 1) nxt = xb == cur ? xa : xb;
       if (i == n_passes - 1) nxt = x_last;

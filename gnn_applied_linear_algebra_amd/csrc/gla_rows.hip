@@ -2091,7 +2091,7 @@ int gla_jacobi_parts_status(const gla_csr* A, int dtype, int sweeps) {
 // gla_jacobi_fused_parts / gla_jacobi_fused_parts_aos with the A_ii flag of a call (gla_dist.hip; arguments checked by the
 // caller, canonical 5-point plans only).  va != NULL: the AoS first pass -- copies of A_ii / b go to diag_out / b_out AND every
 // owned row whose A_ii differs from its centre coefficient raises the flag; va == NULL: a plain pass that takes A_ii from the
-// centre coefficient unless the flag is raised (then from `diag`).
+// centre coefficient unless the flag is raised (then from `diag`, of stride ldva elements where ldva > 0: the AoS rows themselves).
 int gla_jacobi_parts_flagged(gla_csr* A, int dtype, const void* va, int64_t ldva, int64_t row_offset, int64_t n_attr_rows,
                              const void* diag, const void* B, const void* X, void* diag_out, void* b_out, void* Xout, double w,
                              int sweeps, int part, int ghost_lines, int* dg_flag, int dg_epoch, hipStream_t st) {
@@ -2100,12 +2100,12 @@ int gla_jacobi_parts_flagged(gla_csr* A, int dtype, const void* va, int64_t ldva
     if (va) return launch_jacobi_fused_ts<double>(sweeps, A, nullptr, nullptr, (const double*)va, (double*)Xout, (double)w, st, part, ldva,
                                                   (double*)diag_out, (double*)b_out, ghost_lines, row_offset, n_attr_rows, 1, dg_flag, dg_epoch);
     return launch_jacobi_fused_ts<double>(sweeps, A, (const double*)diag, (const double*)B, (const double*)X, (double*)Xout, (double)w, st,
-                                          part, 0, nullptr, nullptr, ghost_lines, 0, -1, 1, dg_flag, dg_epoch);
+                                          part, 0, nullptr, nullptr, ghost_lines, 0, -1, ldva > 0 ? ldva : 1, dg_flag, dg_epoch);
   }
   if (va) return launch_jacobi_fused_ts<float>(sweeps, A, nullptr, nullptr, (const float*)va, (float*)Xout, (float)w, st, part, ldva,
                                                (float*)diag_out, (float*)b_out, ghost_lines, row_offset, n_attr_rows, 1, dg_flag, dg_epoch);
   return launch_jacobi_fused_ts<float>(sweeps, A, (const float*)diag, (const float*)B, (const float*)X, (float*)Xout, (float)w, st, part,
-                                       0, nullptr, nullptr, ghost_lines, 0, -1, 1, dg_flag, dg_epoch);
+                                       0, nullptr, nullptr, ghost_lines, 0, -1, ldva > 0 ? ldva : 1, dg_flag, dg_epoch);
 }
 
 extern "C" {

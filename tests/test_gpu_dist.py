@@ -803,8 +803,9 @@ def _temporal_route_case(plan, drv, va, g, d_e, b_e, periodic, up, down, n, n_ex
                     Hs.append(Hs[-1] + (a_ + b_ if len(Hs) == 1 else max(a_, b_)))
                 if n_ext // drv.ext["S"] >= 2 * (Hs[-1] + sched[-1]) + 32:
                     staggered, win = True, max(h_ + t_ for h_, t_ in zip(Hs, sched))
-            # staggered: each stream has its own flag word; the interior is repaired when a row the INTERIOR launches compute is off
-            full = a_name != "diagonal" and len(sched) >= 2 and not (staggered and a_name in ("ghost line", "last own row"))
+            # staggered: each stream has its own flag word, and an interior launch whose flag is raised reads A_ii from the AoS
+            # rows themselves -- the copy's interior is never needed, only the windows the edge blocks read
+            full = a_name != "diagonal" and len(sched) >= 2 and not staggered
             if not bool(torch.isnan(d_ext).any()) or full:
                 assert torch.equal(d_ext, d_e), (a_name, its, overlap, stagger, "A_ii copy")
             else:
