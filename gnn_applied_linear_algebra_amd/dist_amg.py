@@ -77,6 +77,10 @@ class RowBlockAMG:
     # step of a rank's cycle except the neighbours' data.  What it costs next to AMGHierarchy.cycle on the same rows is the
     # per-rank overhead of the distributed cycle before inter-GPU latency.
     REHEARSE_ONE_RANK = False
+    # As AMGHierarchy._diag_from_matrix (VCycle.py): the smoothers' A_ii IS each level's matrix diagonal, and the extended blocks hold
+    # true global rows, so their extended A_ii is the extended plan's centre diagonal row for row: the march passes are told so and
+    # stream no A_ii (8 bytes per row of a level's pass: 23-27 us of each level-0 pass at 16.8 M rows, profiles/r05/dist_vcycle_trace.txt)
+    _diag_from_matrix = True
 
     def __init__(self, H, group=None, overlap=True, agglomerate_below=None):
         self.group = group
@@ -379,14 +383,15 @@ class RowBlockAMG:
             # slots overlap the block's lower ghost lines, whose r nobody reads, and are filled by the halo exchange AFTER the pass.
             # Before, restrict() copied r into its own buffer: 134 MB in and out at 16.8 M rows, 55-60 us of a 1.8 ms cycle.
             carrier = self._r_carrier(level, b.dtype)
-            xr = plan.jacobi_sweeps_residual(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_pre, r_out=carrier)
+            xr = plan.jacobi_sweeps_residual(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_pre, r_out=carrier,
+                                             diag_is_matrix_diagonal=self._diag_from_matrix)
             if xr is not None:                               # (fresh extended tensors: the caller keeps their own-row views, no copy)
                 r_own = own(xr[1])
                 if carrier is not None and xr[1].data_ptr() == carrier.data_ptr():
                     r_own = carrier[ops.ext["off"]:ops.ext["off"] + ops.part.n_local].reshape(-1, 1)
                     r_own._gla_io = (carrier, level)
                 return own(xr[0]), r_own
-            x1 = plan.jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_pre)       # (rows within n_pre lines of the
+            x1 = plan.jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_pre, diag_is_matrix_diagonal=self._diag_from_matrix)       # (rows within n_pre lines of the
             return own(x1), own(plan.residual(b_e.reshape(-1, 1), x1))                               #  extension's ends are not valid: never read)
         x = self.smooth(level, self.n_pre, b, x)
         return x, self.residual(b, x, level)
@@ -396,7 +401,8 @@ class RowBlockAMG:
         w = float(torch.tensor(self.w, dtype=b.dtype))
         if ops.ext is not None and b.shape[1] == 1 and 1 <= self.n_post <= ops.TS_MAX and 1 <= self.n_pre < ops.TS_MAX:
             d_e, b_e, x_e, own = self._ghost_operands(level, None, x)      # (b and its ghost lines are still there from the pre-smoothing)
-            return own(ops.ext["plan"].jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_post))
+            return own(ops.ext["plan"].jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_post,
+                                                     diag_is_matrix_diagonal=self._diag_from_matrix))
         return self.smooth(level, self.n_post, b, x)
 
     def _r_carrier(self, level, dtype):
