@@ -695,7 +695,8 @@ def test_jacobi_fused_parts_and_library_all_gather():
 
 
 @pytest.mark.parametrize("Nx,Ny,up,down", [(300, 200, 1, 1), (70, 40, 1, 1), (1000, 64, 1, 1), (257, 49, 1, 1),
-                                            (300, 120, 1, 0), (300, 120, 0, 1)])
+                                            (300, 120, 1, 0), (300, 120, 0, 1),
+                                            (8192, 1024, 1, 1)])      # (BASELINE config 4's block of one of 8 ranks, at size)
 def test_temporal_route_self_halo_rccl(Nx, Ny, up, down):
     """dist.RowBlockJacobi._forward_temporal with a REAL (one-rank) RCCL communicator: the rank's upper and lower neighbour
     are the rank itself (a grid periodic in the line direction), so every pass goes through pack -> ncclAllGather on the
