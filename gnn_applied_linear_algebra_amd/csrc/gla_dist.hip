@@ -423,8 +423,11 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
     GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
     forked = true;
+    // (staggered: the interior launch carries the event the second stream's NEXT edge launch waits for as its completion signal)
+    if (stag) gla_march5_set_stop_event(c->ev_pack);
     if (dg_flag) rc = gla_jacobi_parts_flagged(A, dtype, va, ldva, off, n_local, nullptr, nullptr, nullptr, nullptr, b_ext, nxt, w, ts, 1, gh(0), dg_flag, dg_epoch, mn);
     else rc = gla_jacobi_fused_parts_aos(A, dtype, va, ldva, off, n_local, d_ext, b_ext, nxt, w, ts, 1, gh(0), mn);
+    gla_march5_set_stop_event(nullptr);
     if (rc) return bail(rc);
     // (the interior launch reads the AoS rows and leaves the edge windows of d_ext / b_ext alone: the hand copies may run beside it)
     if (k) { rc = gla_copy_batch(dtype, k, src, dst, cnt, strd, sd); if (rc) return bail(rc); }
@@ -467,14 +470,16 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
         const int r_ = g_rccl.all_gather(send, recv, (size_t)(2 * m), dtype == GLA_F64 ? NCCL_FLOAT64 : NCCL_FLOAT32, c->comm, sd);
         if (r_ != 0) return bail(-(3000 + r_));
       }
-      // ... its edge blocks also read what the interior launch of pass i - 1 wrote
-      GLA_HIP_CHECK(hipEventRecord(c->ev_fork, mn));
-      GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_fork, 0));
+      // ... its edge blocks also read what the interior launch of pass i - 1 wrote (whose completion event is ev_pack)
+      GLA_HIP_CHECK(hipStreamWaitEvent(sd, c->ev_pack, 0));
       { void* t = cur; cur = nxt; nxt = t; }
       if (i == 1) nxt = xb == cur ? xa : xb;
       if (i == n_passes - 1) nxt = x_last;
       const int ts = passes[i];
-      rc = parts(d_ext, b_ext, cur, nxt, ts, 1, i, mn); if (rc) return bail(rc);
+      if (i + 1 < n_passes) gla_march5_set_stop_event(c->ev_pack);
+      rc = parts(d_ext, b_ext, cur, nxt, ts, 1, i, mn);
+      gla_march5_set_stop_event(nullptr);
+      if (rc) return bail(rc);
       const void* src[2]; void* dst[2]; int64_t cnt[2];
       int k = 0;
       if (up) { src[k] = at(recv, (int64_t)up_src * 2 * m + m); dst[k] = cur; cnt[k] = m; ++k; }

@@ -182,6 +182,11 @@ inline bool gla_dia_sym5(const gla_csr* A) { return g_tuning.sym && gla_dia_cano
 // ... and no row lacks a neighbour its grid position has (and the option allows using that): no mask stream
 inline bool gla_dia_full5(const gla_csr* A) { return g_tuning.full_mask && gla_dia_canon5(A) && A->dia_full == 1; }
 int gla_march5_pass(const gla_march5_args& a);
+// The NEXT march pass this thread launches carries `ev` as its completion event (hipExtLaunchKernelGGL's stop event: the kernel's
+// own packet signals it, no barrier packet between this kernel and the next one of the stream -- an event RECORD between two kernels
+// of one queue costs ~7 us on this runtime, profiles/r05/config4_block_stagger.txt).  Streams being captured get a plain record.
+extern thread_local hipEvent_t gla_m5_stop_event;            // (defined in gla_march5.hip)
+inline void gla_march5_set_stop_event(hipEvent_t ev) { gla_m5_stop_event = ev; }
 // GLA_OK iff gla_jacobi_fused_parts(_aos) would run `sweeps` sweeps on this canonical 5-point plan with these value types
 // (gla_rows.hip); otherwise the status it would return.  For callers that must know BEFORE they enqueue anything (gla_dist.hip).
 int gla_jacobi_parts_status(const gla_csr* A, int dtype, int sweeps);

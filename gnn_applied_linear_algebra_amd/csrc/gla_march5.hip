@@ -47,6 +47,7 @@
 // attribute tensor (JacobiGNN.py:104-106); the lane that owns a row leaves contiguous copies of its A_ii and b in diag_out /
 // b_out for the later passes.  MODE 2 (gla_jacobi_fused_residual): one more level forms r = b - A x^(k+TS) (-> b_out).
 #include "gla_device.h"
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 #include <utility>
@@ -599,10 +600,24 @@ int m5_launch_sym(const gla_march5_args& a) {
     }
   }
 #endif
+  hipEvent_t stop_ev = gla_m5_stop_event;
+  gla_m5_stop_event = nullptr;
+  if (stop_ev) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(a.st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap == hipStreamCaptureStatusNone && g_tuning.dist_stagger != 2) {
+      hipExtLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV, SYM, FM, DGM)), grid, block, lds, a.st, nullptr, stop_ev, 0, dv,
+                            (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1,
+                            a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out);
+      GLA_LAUNCH_CHECK();
+      return GLA_OK;
+    }
+  }
   hipLaunchKernelGGL((M5_KERNEL(T, TS, MODE, LV, SYM, FM, DGM)), grid, block, lds, a.st, dv,
                      (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1,
                      a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out);
   GLA_LAUNCH_CHECK();
+  if (stop_ev) GLA_HIP_CHECK(hipEventRecord(stop_ev, a.st));
   return GLA_OK;
 }
 
@@ -667,6 +682,7 @@ int gla_march5_pass_f32(const gla_march5_args& a) {
   return m5_dispatch_ts<float, M5_PLAIN>(a);
 }
 #else
+thread_local hipEvent_t gla_m5_stop_event = nullptr;         // gla_march5_set_stop_event (gla_internal.h): consumed by the thread's next launch
 int gla_march5_pass_f32(const gla_march5_args& a);
 int gla_march5_pass(const gla_march5_args& a_in) {
   gla_march5_args a = a_in;

@@ -820,7 +820,7 @@ int gla_set_option(const char* name, int64_t value) {
   if (!strcmp(name, "jacobi_diag_flag")) { g_tuning.jacobi_diag_flag = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "m5_variant")) { g_tuning.m5_variant = (int)value; return GLA_OK; }
   if (!strcmp(name, "edge_prio")) { g_tuning.edge_prio = value != 0; return GLA_OK; }
-  if (!strcmp(name, "dist_stagger")) { g_tuning.dist_stagger = value != 0; return GLA_OK; }
+  if (!strcmp(name, "dist_stagger")) { if (value < 0 || value > 2) return GLA_ERR_INVALID_ARG; g_tuning.dist_stagger = (int)value; return GLA_OK; }   // (2: staggered, plain event records -- A/B)
   if (!strcmp(name, "full_mask")) { g_tuning.full_mask = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "row_sum")) { g_tuning.row_sum = value ? 1 : 0; return GLA_OK; }
   if (!strcmp(name, "jacobi_fuse")) { if (value < 0 || value > 2) return GLA_ERR_INVALID_ARG; g_tuning.jacobi_fuse = (int)value; return GLA_OK; }
