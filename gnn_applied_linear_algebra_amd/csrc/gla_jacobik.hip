@@ -304,7 +304,10 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
         // row of level t: the LDS line of level t - 1 on line jl - (t - 1) (written a step ago): [0] west, [2 KV] east
         auto row_of = [&](int t) -> TV* { return ((t - 1) % 2 == 0 ? row_e : row_o) + (t - 1) * 2 * LWV; };
         auto set_of = [&](int t) -> int { return ((u - (t - 1)) % NC + NC) % NC; };
-        TV lead = lead4(c[set_of(1)], h[0][0], row_of(1)[0], h[0][1], row_of(1)[2 * KV]);
+        // (DBG & 16, timing experiments: no LDS traffic in the levels -- the neighbours read as the own column)
+        auto west_of = [&](int t) -> TV { if constexpr ((DBG & 16) != 0) return h[t - 1][0]; else return row_of(t)[0]; };
+        auto east_of = [&](int t) -> TV { if constexpr ((DBG & 16) != 0) return h[t - 1][2]; else return row_of(t)[2 * KV]; };
+        TV lead = lead4(c[set_of(1)], h[0][0], west_of(1), h[0][1], east_of(1));
 #pragma unroll
         for (int t = 1; t <= TS; ++t) {
           if (t <= nact) {
@@ -312,9 +315,9 @@ __global__ __launch_bounds__(NT) void jacobi_marchk_kernel(JacK jv, const T* __r
             const int ci = set_of(t);
             TV lead_next = lead;
             if (t + 1 <= TS && t + 1 <= nact)
-              lead_next = lead4(c[set_of(t + 1)], h[t][0], row_of(t + 1)[0], h[t][1], row_of(t + 1)[2 * KV]);
+              lead_next = lead4(c[set_of(t + 1)], h[t][0], west_of(t + 1), h[t][1], east_of(t + 1));
             const TV xn = finish5(c[ci], cb[ci], crc[ci], lead, h[t - 1][2], h[t - 1][1], bad);
-            if (t < TS) { h[t][2] = xn; row[2 * LWV + KV] = xn; }                     // level t, same line (same parity)
+            if (t < TS) { h[t][2] = xn; if constexpr (!(DBG & 16)) row[2 * LWV + KV] = xn; }   // level t, same line (same parity)
             else if ((DBG & 2) ? (owner && xn[0] == T(123.456)) : owner) stv<TV>(xout + ((J0 + jl - (TS - 1)) * S + gi) * ldxo + q * VW, xn);
             lead = lead_next;
             __builtin_amdgcn_sched_barrier(0);
@@ -459,6 +462,7 @@ int launch_marchk(gla_csr* A, const T* diag, const T* b, int64_t ldb, const T* x
       switch (v) {
         case 1: MKD(1); break; case 2: MKD(2); break; case 3: MKD(4); break; case 4: MKD(8); break;
         case 5: MKD(9); break; case 6: MKD(5); break; case 7: MKD(10); break;
+        case 8: MKD(16); break; case 9: MKD(17); break; case 10: MKD(24); break; case 11: MKD(25); break;
         default: return GLA_ERR_INVALID_ARG;
       }
       GLA_LAUNCH_CHECK();

@@ -20,7 +20,8 @@ dg = torch.full((n,), -4.0, dtype=torch.float64, device=dev)
 out, tmp = torch.empty_like(x), torch.empty_like(x)
 st = stream_ptr(dev)
 names = {0: "shipped", 1: "NO BARRIER", 2: "NO OUTPUT STORE", 3: "MEMORY SIDE ONLY (no levels)", 4: "COMPUTE SIDE ONLY (no loads)",
-         5: "compute side only, no barrier", 6: "memory side only, no barrier", 7: "no store, no loads"}
+         5: "compute side only, no barrier", 6: "memory side only, no barrier", 7: "no store, no loads",
+         8: "NO LDS traffic in the levels", 9: "no LDS traffic, no barrier", 10: "no LDS traffic, no loads", 11: "no LDS traffic, no loads, no barrier"}
 
 
 def med(fn, reps=9):
@@ -39,7 +40,7 @@ for _ in range(30):
 torch.cuda.synchronize()
 ref = out.clone()
 for rnd in range(2):
-    for v in range(8):
+    for v in range(12):
         if lib().gla_set_option(b"m5_variant", v) != 0:
             continue
         m, mn = med(run)
