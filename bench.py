@@ -913,8 +913,13 @@ def single_gpu(args, gla, dev):
         out["dist_vcycle_one_rank"] = side_dist_vcycle(120.0)
         # ---- side: BASELINE config 4's REAL 8-rank block (1024 lines x 8192 points) over a one-rank RCCL communicator, eager and
         # replayed from a HIP graph, next to the whole 8192^2 matrix on this GPU (child process: tools/bench_dist_config4_block.py)
-        out["dist_route_one_gpu_config4_block"] = side_child_json([os.path.join(ROOT, "tools", "bench_dist_config4_block.py"), "8192", "8",
-                                                                    str(args.sweeps), "--json"], 240.0)
+        c4_tool = [os.path.join(ROOT, "tools", "bench_dist_config4_block.py"), "8192", "8", str(args.sweeps), "--json"]
+        out["dist_route_one_gpu_config4_block"] = side_child_json(c4_tool, 240.0)
+        # (A/B in the same line: the passes NOT staggered -- one edge height, the main stream joins the second one every pass;
+        # option dist_stagger = 0)
+        c4_plain = side_child_json(c4_tool + ["--block-only"], 120.0, extra_env={"GLA_OPTIONS": "dist_stagger=0"})
+        if isinstance(out["dist_route_one_gpu_config4_block"], dict) and isinstance(c4_plain, dict):
+            out["dist_route_one_gpu_config4_block"]["eager_ms_per_step_one_join_per_pass"] = c4_plain.get("eager_ms_per_step", c4_plain.get("error"))
         # ---- side: the price of bit-exactness, measured once (never the default): the same step through the
         # opt-in build variant libgla_hip_contracted.so (FMA contraction in the row sums, division as one multiply-add with
         # RN(1 / A_ii)) next to the default library, each in a child process of its own (tools/bench_contracted_fp.py)
