@@ -401,9 +401,30 @@ class RowBlockAMG:
         w = float(torch.tensor(self.w, dtype=b.dtype))
         if ops.ext is not None and b.shape[1] == 1 and 1 <= self.n_post <= ops.TS_MAX and 1 <= self.n_pre < ops.TS_MAX:
             d_e, b_e, x_e, own = self._ghost_operands(level, None, x)      # (b and its ghost lines are still there from the pre-smoothing)
-            return own(ops.ext["plan"].jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_post,
-                                                     diag_is_matrix_diagonal=self._diag_from_matrix))
+            # a coarse level's result is read once, by the prolongation of the level above: it lands in a carrier that is both this
+            # pass's output (extended-block positions) and that operator's operand ([own rows | halo slots], filled afterwards)
+            carrier = self._x_carrier(level, x.dtype) if level > 0 else None
+            got = ops.ext["plan"].jacobi_sweeps(d_e, b_e.reshape(-1, 1), x_e.reshape(-1, 1), w, self.n_post,
+                                                diag_is_matrix_diagonal=self._diag_from_matrix, out=carrier)
+            res = own(got)
+            if carrier is not None and got.data_ptr() == carrier.data_ptr():
+                res._gla_px = (carrier, level)
+            return res
         return self.smooth(level, self.n_post, b, x)
+
+    def _x_carrier(self, level, dtype):
+        """The buffer that is BOTH the post-smoothing pass's output on ghost-line level `level` (>= 1) and the operand of the
+        prolongation from it (correct(level - 1)); None where the two layouts do not line up."""
+        a_ops, pr = self.A_ops[level], (self.P_ops[level - 1] if 0 < level <= len(self.P_ops) else None)
+        e = a_ops.ext
+        if e is None or pr is None or pr.part.n_in != a_ops.part.n_local:
+            return None
+        key = ("x_carrier", dtype)
+        buf = e["amg"].get(key)
+        if buf is None:
+            need = max(e["n_ext"], e["off"] + pr.part.n_in + pr.part.halo_size)
+            buf = e["amg"][key] = torch.zeros(need, dtype=dtype, device=e["dev"])
+        return buf
 
     def _r_carrier(self, level, dtype):
         """The buffer that is BOTH the residual output of a ghost-line level's smoothing pass and the restriction's operand
@@ -452,7 +473,14 @@ class RowBlockAMG:
         # the result is the post-smoother's operand: allocated with the ghost rows of the level's extended block, so that the
         # smoothing pass reads it in place
         out = a_ops.ext_tensor(1, dtype=x.dtype, zero=False) if (a_ops.ext is not None and x.shape[1] == 1) else torch.empty_like(x)
-        self._apply(ops, xc, lambda buf, which: ops.plan.spmm_add(x, buf, out=out, which=which))
+        px = getattr(xc, "_gla_px", None)
+        if px is not None and px[1] == level + 1 and xc.shape[1] == 1:
+            # xc already sits at the head of this operator's operand (postsmooth's carrier): no copy
+            e = self.A_ops[level + 1].ext
+            buf = px[0][e["off"]:e["off"] + ops.part.n_in + ops.part.halo_size].reshape(-1, 1)
+            ops.run(buf, lambda which: ops.plan.spmm_add(x, buf, out=out, which=which))
+        else:
+            self._apply(ops, xc, lambda buf, which: ops.plan.spmm_add(x, buf, out=out, which=which))
         return out
 
     def capture_cycle(self, dtype=torch.float64):

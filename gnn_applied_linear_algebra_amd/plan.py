@@ -205,8 +205,9 @@ class CsrPlan:
         return len(sched) > 0 and min(sched) >= 2
 
     @_on_device
-    def jacobi_sweeps(self, diag, B, X0, w, n_iters, diag_is_matrix_diagonal=False):
-        """n_iters fused sweeps; returns a new [n, K] tensor, X0 untouched (JacobiGNN.py:138-148)."""
+    def jacobi_sweeps(self, diag, B, X0, w, n_iters, diag_is_matrix_diagonal=False, out=None):
+        """n_iters fused sweeps; returns a new [n, K] tensor, X0 untouched (JacobiGNN.py:138-148).  out: a contiguous buffer of at
+        least n x K elements of X0's dtype on this device that receives the result instead (dist_amg.py: the prolongation's operand)."""
         assert self.n_rows == self.n_cols
         X0, K, ldx0 = _dense(X0, self.n_cols, "X0")
         B, Kb, ldb = _dense(B, self.n_rows, "B")
@@ -215,7 +216,11 @@ class CsrPlan:
         assert Kb == K and B.dtype == X0.dtype == diag.dtype
         if n_iters <= 0:
             return X0.clone()
-        Xout = torch.empty((self.n_rows, K), dtype=X0.dtype, device=self.device)
+        if out is not None and out.is_contiguous() and out.dtype == X0.dtype and out.device == X0.device and out.numel() >= self.n_rows * K \
+                and out.data_ptr() != X0.data_ptr():
+            Xout = out.reshape(-1)[:self.n_rows * K].reshape(self.n_rows, K)
+        else:
+            Xout = torch.empty((self.n_rows, K), dtype=X0.dtype, device=self.device)
         Xtmp = torch.empty_like(Xout) if n_iters > 1 else None
         no_stream = diag_is_matrix_diagonal and self._diag_from_matrix(K, n_iters, X0.dtype, ldb == 1 and ldx0 == 1)
 
