@@ -156,7 +156,19 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
   for (int i = tid; i < LV * 2 * LW; i += BW) buf[i] = T(0);   // (the pads stay +0: what lies beyond a line's ends)
   __syncthreads();
 
-  auto row_clamped = [&](int jl) -> int64_t { return min(max((J0 + jl) * dv.S + gi, (int64_t)0), dv.n_rows - 1); };
+  // (DBG & 16, variants builds, timing only -- the results are WRONG: every array addressed as if line j of block lb were STORED at
+  // line slot (j - J0) * nlb + lb, so that what all the line blocks touch in one step is contiguous; profiles/r05/march5_memory_side.txt)
+  auto perm_row = [&](int jl) -> int64_t {
+    int64_t sl;
+    if (jl < 0) sl = (int64_t)(lines + jl) * dv.nlb + max(lb - 1, 0);
+    else if (jl >= L) sl = (int64_t)(jl - L) * dv.nlb + min(lb + 1, dv.nlb - 1);
+    else sl = (int64_t)jl * dv.nlb + lb;
+    return min(max(sl * dv.S + gi, (int64_t)0), dv.n_rows - 1);
+  };
+  auto row_clamped = [&](int jl) -> int64_t {
+    if constexpr ((DBG & 16) != 0) return perm_row(jl);
+    else return min(max((J0 + jl) * dv.S + gi, (int64_t)0), dv.n_rows - 1);
+  };
   auto live_at = [&](int jl) -> bool {             // the row (line J0 + jl, this lane's point) exists (generic path, level 0)
     return in_i & (J0 + jl >= 0) & ((J0 + jl) * dv.S + gi < dv.n_rows);
   };
@@ -338,7 +350,7 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
               xn = h[t - 1][1] + num / (DGC ? cc.v[2] : cc.dg);
             }
             if (t < LV) { h[t][2] = xn; row[2 * LW + 1] = xn; }     // level t, same line (same parity)
-            if (t == TS) { if ((DBG & 2) ? (owner && xn == T(123.456)) : (owner && (!RES || (line >= 0 && line < L)))) xo[(J0 + line) * dv.S + gi] = xn; }
+            if (t == TS) { if ((DBG & 2) ? (owner && xn == T(123.456)) : (owner && (!RES || (line >= 0 && line < L)))) xo[(DBG & 16) ? perm_row(line) : (J0 + line) * dv.S + gi] = xn; }
           }
           __builtin_amdgcn_sched_barrier(0);       // levels stay in program order: the scheduler's own interleaving of seven
         }                                          // levels costs more registers than the two waves per SIMD leave
@@ -593,6 +605,7 @@ int m5_launch_sym(const gla_march5_args& a) {
 #define M5D(DBGV) hipLaunchKernelGGL((jacobi_march5_kernel<T, TS, MODE, true, 2, false, SYM, FM, DGM, 1, DBGV>), grid, block, lds, a.st, dv, (const T*)a.diag, (const T*)a.b, (const T*)a.x, (T*)a.xo, (T)a.w, lines, nstrips, tm, base0, split, base1, a.ldva > 0 ? a.ldva : (int64_t)1, (T*)a.diag_out, (T*)a.b_out)
         case 9: M5D(1); break; case 10: M5D(2); break; case 11: M5D(4); break; case 12: M5D(8); break;
         case 13: M5D(3); break; case 14: M5D(9); break; case 15: M5D(5); break;
+        case 16: M5D(16); break; case 17: M5D(24); break; case 18: M5D(17); break;
         default: return GLA_ERR_INVALID_ARG;
       }
       GLA_LAUNCH_CHECK();
