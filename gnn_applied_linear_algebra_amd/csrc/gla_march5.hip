@@ -260,9 +260,9 @@ __device__ __forceinline__ void m5_body(const M5View& dv, const T* __restrict__ 
     // jacobi_marchk_kernel's line step -- profiles/r03/marchk_miscompile.txt; a plain v_cndmask has no such region)
     h[0][2] = (whole_next | live_at(jl + 1)) ? (PF > 1 ? c[u % NC].xv : xpre) : T(0);
     row_o[1] = h[0][2];                            // level 0, line jl + 1
-    if constexpr (PF == 1) xpre = x0_load(jl + 2);
+    if constexpr (PF == 1 && !(DBG & 32)) xpre = x0_load(jl + 2);
     if constexpr (SYM) s_ev = c[(u + PF) % NC].v[4];   // the set about to be replaced is line jl - LV: its south is the north of the last level's line
-    c[(u + PF) % NC] = coef_at(jl + PF);
+    if constexpr (!(DBG & 32)) c[(u + PF) % NC] = coef_at(jl + PF);      // (DBG & 32: the compute side alone -- no global loads in the line step)
     {                                              // first use of the set of line jl (loaded a step ago)
       const M5Coef<T>& cu = c[u % NC];
       const int64_t gj = J0 + jl;
@@ -606,6 +606,7 @@ int m5_launch_sym(const gla_march5_args& a) {
         case 9: M5D(1); break; case 10: M5D(2); break; case 11: M5D(4); break; case 12: M5D(8); break;
         case 13: M5D(3); break; case 14: M5D(9); break; case 15: M5D(5); break;
         case 16: M5D(16); break; case 17: M5D(24); break; case 18: M5D(17); break;
+        case 19: M5D(32); break; case 20: M5D(33); break; case 21: M5D(34); break;
         default: return GLA_ERR_INVALID_ARG;
       }
       GLA_LAUNCH_CHECK();

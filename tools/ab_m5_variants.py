@@ -19,7 +19,8 @@ st = stream_ptr(dev)
 names = {0: "shipped (hd2)", 1: "hd0", 2: "hd1", 3: "hd3", 4: "pf2 hd2", 5: "pf2 hd0", 6: "pf2 hd3", 7: "pf3 hd2", 8: "pf3 hd0",
          9: "NO BARRIER", 10: "NO OUTPUT STORE", 11: "no s_setprio", 12: "MEMORY SIDE ONLY (no levels)", 13: "no barrier, no store",
          14: "memory side only, no barrier", 15: "no barrier, no s_setprio", 16: "LINE-INTERLEAVED addressing (all arrays)",
-         17: "line-interleaved, memory side only", 18: "line-interleaved, no barrier"}
+         17: "line-interleaved, memory side only", 18: "line-interleaved, no barrier", 19: "COMPUTE SIDE ONLY (no loads in the step)",
+         20: "compute side only, no barrier", 21: "compute side only, no store"}
 
 
 def med(fn, reps=15):
@@ -38,7 +39,7 @@ for _ in range(300):
 torch.cuda.synchronize()
 ref = out.clone()
 for rnd in range(3):
-    for v in (0, 9, 12, 16, 17, 18):
+    for v in (0, 9, 12, 19, 20, 21):
         if lib().gla_set_option(b"m5_variant", v) != 0:
             continue
         m, mn = med(run)
