@@ -778,7 +778,7 @@ class RowBlockJacobi(RowBlockOps):
         return own(cur).unsqueeze(1)
 
     @classmethod
-    def rehearsal_self_halo(cls, Nx, lines, device, comm=None):
+    def rehearsal_self_halo(cls, Nx, lines, device, comm=None, dtype=None):
         """A driver for ONE rank's block of `lines` grid lines x Nx points whose upper and lower neighbour are the rank itself (the
         grid is periodic in the line direction), over a real one-rank RCCL communicator of the library: everything a rank of an
         N-rank job does per forward() -- pack, ncclAllGather on the library's stream, interior line blocks, ghost fill + edge
@@ -790,6 +790,8 @@ class RowBlockJacobi(RowBlockOps):
         from .plan import CsrPlan
         T = cls.TS_MAX
         ei, ev = UtilsGNN.laplacianfun_torch(Nx, Ny=lines + 2 * T, device=device)
+        if dtype is not None:
+            ev = ev.to(dtype)
         plan = CsrPlan(ei, Nx * (lines + 2 * T))
         plan.set_values(ev)
         drv = cls.__new__(cls)
