@@ -563,14 +563,19 @@ int gla_dist_jacobi_temporal_graph(gla_csr_t A, gla_comm_t c, int dtype, const v
   hipError_t e = hipStreamCreateWithFlags(&g->mn, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->sd, hipStreamNonBlocking);
   if (e != hipSuccess) { (void)hipGetLastError(); gla_graph_destroy(g); return -(1000 + (int)e); }
+  // (the PLAIN form is what gets captured: replayed from a graph the staggered passes are slower than the plain ones -- 0.60 against
+  // 0.49 ms on config 4's block, profiles/r05/config4_block_stagger.txt -- the opposite of the eager queues; same results bit for bit)
+  const int stagger_was = g_tuning.dist_stagger;
+  g_tuning.dist_stagger = 0;
   int rc = gla_dist_jacobi_temporal(A, c, dtype, va, ldva, off, n_local, d_ext, b_ext, xa, xb, x_last, send, recv, ghost, up, down,
                                     up_src, down_src, w, passes, n_passes, g->mn, g->sd);
   if (rc == GLA_OK && hipStreamSynchronize(g->mn) != hipSuccess) rc = GLA_ERR_INVALID_ARG;
-  if (rc != GLA_OK) { (void)hipGetLastError(); gla_graph_destroy(g); return rc; }
+  if (rc != GLA_OK) { g_tuning.dist_stagger = stagger_was; (void)hipGetLastError(); gla_graph_destroy(g); return rc; }
   e = hipStreamBeginCapture(g->mn, hipStreamCaptureModeRelaxed);
-  if (e != hipSuccess) { (void)hipGetLastError(); gla_graph_destroy(g); return -(1000 + (int)e); }
+  if (e != hipSuccess) { g_tuning.dist_stagger = stagger_was; (void)hipGetLastError(); gla_graph_destroy(g); return -(1000 + (int)e); }
   rc = gla_dist_jacobi_temporal(A, c, dtype, va, ldva, off, n_local, d_ext, b_ext, xa, xb, x_last, send, recv, ghost, up, down,
                                 up_src, down_src, w, passes, n_passes, g->mn, g->sd);
+  g_tuning.dist_stagger = stagger_was;
   e = hipStreamEndCapture(g->mn, &g->graph);           // (also after a failed enqueue: the stream must leave capture mode)
   if (rc != GLA_OK || e != hipSuccess || !g->graph) {
     (void)hipGetLastError();
