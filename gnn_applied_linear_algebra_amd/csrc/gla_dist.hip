@@ -367,7 +367,11 @@ int gla_dist_jacobi_temporal(gla_csr_t A, gla_comm_t c, int dtype, const void* v
     H[(size_t)i] = i == 1 ? H[0] + passes[0] + passes[1] : H[(size_t)i - 1] + (passes[i - 1] > passes[i] ? passes[i - 1] : passes[i]);
   const int win0 = 2 * ghost + passes[0];                      // lines either end the edge blocks of pass 0 read
   int win_lines = win0;                                        // ... and of every pass (H_i + ts_i at most) when staggered
-  const bool stag = g_tuning.dist_stagger && n_passes >= 2 &&
+  // (not while the caller's stream is being captured -- by gla_dist_jacobi_temporal_graph or by torch: replayed from a graph the
+  // staggered form is the slower one)
+  hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)main_stream, &cap_st) != hipSuccess) { (void)hipGetLastError(); cap_st = hipStreamCaptureStatusNone; }
+  const bool stag = g_tuning.dist_stagger && cap_st == hipStreamCaptureStatusNone && n_passes >= 2 &&
                     n_ext / S >= 2 * (int64_t)(H[(size_t)n_passes - 1] + passes[n_passes - 1]) + 32 && H[(size_t)n_passes - 1] < 0x7fff;
   if (stag)
     for (int i = 0; i < n_passes; ++i) win_lines = H[(size_t)i] + passes[i] > win_lines ? H[(size_t)i] + passes[i] : win_lines;
